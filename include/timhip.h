@@ -1,0 +1,240 @@
+/*
+ * timhip.h — C ABI of libtimhip.so: the MI355X (gfx950) implementation of the
+ * TIM (time_interval_machine) encoder hot path, forward and backward.
+ *
+ * Drop-in boundary.  Each stage entry point replaces the
+ * torch.nn call chain the reference runs for that stage:
+ *
+ *   timhip_layer_{fwd,bwd}     <- TransformerEncoderLayer.forward over nn.MultiheadAttention
+ *                                 .../models/helpers/transformers.py:92-111 with the mask of
+ *                                 recognition/.../models/tim.py:161-166 (det tim.py:320-325,384-389)
+ *   timhip_gemm_nt, timhip_wgrad <- nn.Linear forward / input-gradient / weight-gradient:
+ *                                 tim.py:66-74 (time MLP), encodings.py:21-26,140-153 (embedders),
+ *                                 head.py:8-15 (CLS heads), det head.py:99-114 (regression heads)
+ *   timhip_layernorm_{fwd,bwd} <- nn.LayerNorm (+ the ReLU/GELU in front of it) tim.py:72-73,
+ *                                 encodings.py:23-25
+ *   timhip_time_l1_{fwd,bwd}   <- the K=2 first Linear+ReLU of TIM.time_mlp, tim.py:67-68
+ *   timhip_assemble_{fwd,bwd}  <- *FeatureEncoding.forward concat/add/dropout, encodings.py:190-250
+ *   timhip_gather_rows / _scatter_rows_add <- the tail slicing of *CLSHead.forward, head.py:18-36
+ *   timhip_cast_weight         <- (no reference counterpart) operand-dtype working copies of the
+ *                                 fp32 master weights, plain and transposed, once per optimizer step.
+ *
+ * Conventions
+ *   - Plain C: pointers and sizes only.  Every device buffer is allocated and owned by the caller;
+ *     the library never allocates device memory, never synchronises, never keeps a pointer after
+ *     the call returns, and has no global mutable state (re-entrant; forward is called from the
+ *     Python main thread and backward from PyTorch's autograd thread).
+ *   - All work is enqueued on the `stream` argument (a hipStream_t passed as void*).
+ *   - Return value: 0 on success, a negative TIMHIP_E* code otherwise (timhip_strerror()).
+ *     No exception crosses the ABI.
+ *   - Layout: batch-first.  A window is S = F + Q token rows (F feature tokens first, then Q query
+ *     tokens); activations are row-major [B*S, E].  "Operand dtype" T is bf16 for
+ *     TIMHIP_PREC_BF16 / _BF16X3 and fp32 for TIMHIP_PREC_FP32.  Operand matrices are K-contiguous
+ *     with a leading dimension that is a multiple of 64 elements, zero padded.
+ */
+#ifndef TIMHIP_H
+#define TIMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIMHIP_VERSION 1
+
+enum {
+  TIMHIP_OK = 0,
+  TIMHIP_EINVAL = -1,       /* null pointer / bad descriptor field */
+  TIMHIP_EUNSUPPORTED = -2, /* shape outside what the kernels handle */
+  TIMHIP_EWORKSPACE = -3,   /* workspace too small */
+  TIMHIP_ELAUNCH = -4,      /* hipGetLastError() reported a launch failure */
+  TIMHIP_EALIGN = -5        /* pointer or leading dimension not aligned */
+};
+
+enum { TIMHIP_PREC_BF16 = 0, TIMHIP_PREC_BF16X3 = 1, TIMHIP_PREC_FP32 = 2 };
+
+/* epilogue selector of the generic GEMM entry point (unit tests, heads) */
+enum {
+  TIMHIP_EPI_STORE_T = 0,   /* out0(T)   = acc + bias */
+  TIMHIP_EPI_RELU_T = 1,    /* out0(T)   = relu(acc + bias) */
+  TIMHIP_EPI_STORE_F32 = 2, /* out0(f32) = acc + bias */
+  TIMHIP_EPI_GELU_DROP_T2 = 3, /* out1(T) = acc+bias ; out0(T) = drop(gelu(out1)) */
+  TIMHIP_EPI_DROP_RES_F32 = 4, /* out0(f32) = res + drop(acc + bias) */
+  TIMHIP_EPI_ADD_F32 = 5,   /* out0(f32) = acc + res (res may be null) */
+  TIMHIP_EPI_DGELU_T = 6,   /* out0(T)   = acc * dropmask * gelu'(aux(T)) */
+  TIMHIP_EPI_DRELU_T = 7,   /* out0(T)   = acc * (aux(T) > 0) */
+  TIMHIP_EPI_ATOMIC_F32 = 8,/* out0(f32) += acc (split-K weight gradients) */
+  TIMHIP_EPI_SIGMOID_F32 = 9,/* out0(f32) = sigmoid(acc + bias) */
+  TIMHIP_EPI_DRELU_F32IN_T = 10 /* out0(T) = acc * (aux(f32) > 0) */
+};
+
+/* Shape of one call.  M = B*S rows flow through the encoder. */
+typedef struct TimDesc {
+  int32_t B;         /* windows in this batch */
+  int32_t S;         /* tokens per window = F + Q */
+  int32_t F;         /* feature tokens per window (keys every token may attend to) */
+  int32_t d;         /* d_model */
+  int32_t E;         /* transformer width = 2*d_model */
+  int32_t H;         /* heads */
+  int32_t FF;        /* feed-forward width */
+  int32_t precision; /* TIMHIP_PREC_* */
+  float p_drop;      /* encoder dropout probability; 0 => evaluation mode */
+  uint64_t seed;     /* Philox key for this step */
+  int32_t layer;     /* layer index (part of the Philox stream id) */
+  int32_t reserved;
+} TimDesc;
+
+/* One encoder layer.  *_op are operand-dtype working copies made by timhip_prepare_weights:
+ * w (as stored, [N,K]) and wt (transposed, [K,N]).  Biases and LayerNorm parameters are the
+ * fp32 master tensors. */
+typedef struct TimLayerParams {
+  const void *in_w, *in_wt;   /* [3E,E] / [E,3E]   self_attn.in_proj_weight */
+  const void *out_w, *out_wt; /* [E,E]             self_attn.out_proj.weight */
+  const void *l1_w, *l1_wt;   /* [FF,E] / [E,FF]   linear1.weight */
+  const void *l2_w, *l2_wt;   /* [E,FF] / [FF,E]   linear2.weight */
+  const float *in_b, *out_b, *l1_b, *l2_b;
+  const float *n1_w, *n1_b, *n2_w, *n2_b;
+} TimLayerParams;
+
+/* fp32 gradient accumulators, same shapes as the master parameters (+=). */
+typedef struct TimLayerGrads {
+  float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b;
+  float *n1_w, *n1_b, *n2_w, *n2_b;
+} TimLayerGrads;
+
+int timhip_version(void);
+const char* timhip_strerror(int code);
+
+/* bytes of the per-layer saved-for-backward block and of the scratch workspace */
+size_t timhip_layer_saved_bytes(const TimDesc* d);
+size_t timhip_layer_workspace_bytes(const TimDesc* d);
+
+/* ---------------------------------------------------------------- weights ---- */
+/* dst[rows, ld] (T) = cast(src[rows, cols] fp32), zero padded to ld columns.
+ * transpose != 0: dst[cols, ld] = src^T.  ld % 64 == 0. */
+int timhip_cast_weight(int precision, const float* src, int rows, int cols, void* dst, int ld,
+                       int transpose, void* stream);
+
+/* ---------------------------------------------------------------- generic ops (also unit-test hooks) */
+typedef struct TimEpi {
+  void* out0;
+  void* out1;
+  const float* bias;
+  const float* res;
+  const void* aux;
+  int32_t ld0, ld1, ldres, ldaux;
+  float p_drop;
+  uint32_t site;   /* Philox stream id of the dropout site */
+  uint64_t seed;
+} TimEpi;
+
+/* C[M,N] = A[M,K] * B[N,K]^T through epilogue `epi` (TIMHIP_EPI_*).  A, B operand dtype,
+ * lda/ldb multiples of 64 and >= K.  splitk > 1 only with TIMHIP_EPI_ATOMIC_F32. */
+int timhip_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M,
+                   int N, int K, const TimEpi* e, int splitk, void* stream);
+
+/* dst[cols, ld] (T) = src[rows, lds]^T (T); pad columns rows..ld are zeroed.  */
+int timhip_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,
+                     void* stream);
+
+/* out[n] += sum_m src[m, n]  (T source, fp32 accumulate): bias gradients */
+int timhip_colsum(int precision, const void* src, int rows, int cols, int ld, float* out,
+                  void* stream);
+
+/* fp32 -> T with optional dropout (p_drop > 0) and zero padding to ld */
+int timhip_cast_rows(int precision, const float* src, int rows, int cols, int lds, void* dst, int ld,
+                     float p_drop, uint64_t seed, uint32_t site, void* stream);
+
+/* LayerNorm over the last dim of act(y): x = LN(act(y)) * w + b.
+ * act: 0 none, 1 relu, 2 gelu(erf).  Writes x_f32 (may be null, row stride ldx, column
+ * offset already applied by the caller), x_T (may be null, ld ldt) and stats[rows,2]=(mean,rstd).
+ * p_drop>0 applies (sequence) dropout to the outputs. */
+int timhip_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
+                         const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,
+                         float* stats, void* stream);
+/* dy = LN'(dx) (through act'); dgamma += , dbeta +=.  dy_f32 (may be null) and
+ * dy_T = dropmask(site) * dy (may be null). */
+int timhip_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
+                         const float* stats, int rows, int cols, int act, const float* w,
+                         float* dy_f32, int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed,
+                         uint32_t site, float* dgamma, float* dbeta, void* stream);
+
+/* structured attention over qkv[B*S, 3E] (T): token i attends to the F feature tokens and to
+ * itself.  o[B*S,E] (T), lse[B,H,S] fp32. */
+int timhip_attention_fwd(const TimDesc* d, const void* qkv, void* o, float* lse, void* stream);
+int timhip_attention_bwd(const TimDesc* d, const void* qkv, const void* o, const float* lse,
+                         const void* d_o, void* dqkv, void* workspace, size_t workspace_bytes,
+                         void* stream);
+size_t timhip_attention_bwd_workspace_bytes(const TimDesc* d);
+
+/* dW[Nout,Kout] += dY[M,Nout]^T X[M,Kout] and (db != NULL) db[Nout] += colsum(dY): weight/bias
+ * gradients of one nn.Linear.  tA / tB: scratch for the transposed operand copies,
+ * >= Nout*round_up(M,64) and Kout*round_up(M,64) elements of T. */
+int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout,
+                 int M, float* dW, float* db, void* tA, void* tB, void* stream);
+
+/* dx[r,c] = g[r,c] * keep-mask/(1-p): backward of the feature dropout applied by timhip_cast_rows */
+int timhip_dropout_rows_bwd(const float* g, int rows, int cols, int ldg, float* dx, int ldx,
+                            float p_drop, uint64_t seed, uint32_t site, void* stream);
+
+/* time MLP layer 1 (K = 2, tim.py:67): h[r,j] = relu(t[r,0] w[j,0] + t[r,1] w[j,1] + b[j]) (T, ld) */
+int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const float* w,
+                       const float* b, void* h, int ld, void* stream);
+/* dh: gradient w.r.t. the pre-activation of layer 1 (T).  dw[d,2] +=, db[d] +=, dt[rows,2] = (may be NULL) */
+int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const float* w,
+                       const void* dh, int ld, float* dw, float* db, float* dt, void* stream);
+
+/* keep-mask (1/0 bytes) of a dropout site, as the kernels generate it: test hook */
+int timhip_dropout_mask(uint64_t seed, uint32_t site, float p, int rows, int cols, uint8_t* out,
+                        void* stream);
+
+/* ---------------------------------------------------------------- stages ---- */
+/* One post-norm encoder layer.  x_in (fp32 [M,E]) and x_in_T (T [M,E]) are the layer input,
+ * x_out / x_out_T the output.  `saved` (timhip_layer_saved_bytes) is read back by the backward. */
+int timhip_layer_fwd(const TimDesc* d, const TimLayerParams* w, const float* x_in,
+                     const void* x_in_T, float* x_out, void* x_out_T, void* saved, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* dx_out: gradient w.r.t. the layer output (fp32 [M,E], clobbered).  dx_in: gradient w.r.t. the
+ * layer input (fp32 [M,E]).  Parameter gradients are accumulated (+=) into *g. */
+int timhip_layer_bwd(const TimDesc* d, const TimLayerParams* w, const void* x_in_T,
+                     const void* saved, float* dx_out, float* dx_in, const TimLayerGrads* g,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- front end --------------------------------------------------------------
+ * The time MLP (tim.py:66-74), the modality embedders and the sequence assembly
+ * (encodings.py:41-75,102-121,181-251) are sequenced by the host mirror
+ * (tim_amd/functional.py) from the generic entry points above plus the two below. */
+
+/* Sequence assembly (encodings.py:190-250): token row s of every window is described by
+ * rows[s]: x[b,s,:d] = (kind 0: e0[b,src] | kind 2: e1[b,src] | kind 1: cls[src]),
+ * x[b,s,d:] = te[b,te_row], + mod[mod] over all 2d columns (mod < 0: none), then sequence
+ * dropout; writes the fp32 residual stream and its operand-dtype copy. */
+typedef struct TimSeqRow {
+  int32_t kind;
+  int32_t src;
+  int32_t te_row;
+  int32_t mod;
+} TimSeqRow;
+int timhip_assemble_fwd(int precision, const TimSeqRow* rows /*device, [S]*/, int B, int S, int d,
+                        const float* e0, const float* e1, int n_e_rows, const float* cls,
+                        const float* te, int T, const float* mod, float p_seq_drop, uint64_t seed,
+                        uint32_t site, float* x, void* x_T, void* stream);
+/* d_e0/d_e1 are written; d_cls, d_te, d_mod are accumulated (+=, must be zeroed by the caller) */
+int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float* dx, int n_e_rows,
+                        int T, float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0,
+                        float* d_e1, float* d_cls, float* d_te, float* d_mod, void* stream);
+
+/* ---- heads ------------------------------------------------------------------ */
+/* rows_T[B*n, E] (T) = x_T[b, s0 + i, :] for i < n : gathers the query rows a head reads */
+int timhip_gather_rows(int precision, const void* x_T, int B, int S, int E, int s0, int n,
+                       void* rows_T, void* stream);
+/* dx[b, s0+i, :] += d_rows[b*n+i, :]  (fp32) */
+int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, int n, float* dx,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMHIP_H */

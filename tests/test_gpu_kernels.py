@@ -1,0 +1,252 @@
+"""Kernel-level parity through the C ABI (include/timhip.h) on a real MI355X.
+
+Each HIP kernel is compared with the corresponding oracle function
+(oracle/tim_oracle.py) or a plain torch-CPU fp32/fp64 statement of the same op on
+identical seeded inputs.  Tolerances: fp32 kernels 1e-5 relative to the output
+scale; bf16 kernels are compared with the same op evaluated on bf16-rounded
+operands (fp32 accumulate), tolerance 1e-3 relative to the output scale.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tim_oracle as O  # noqa: E402
+from tim_amd import _lib as L  # noqa: E402
+from tim_amd.functional import Runtime, _ru  # noqa: E402
+
+DEV = "cuda:0"
+PRECS = ["fp32", "bf16"]
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def to_op(rt, x, ld=None):
+    """fp32 CPU [R,C] -> device operand buffer [R, ru(C)] (zero padded) and its value as fp32 CPU"""
+    R, Cc = x.shape
+    buf = torch.zeros((R, ld or _ru(Cc)), dtype=rt.op_dtype, device=DEV)
+    buf[:, :Cc] = x.to(DEV).to(rt.op_dtype)
+    return buf, buf[:, :Cc].float().cpu()
+
+
+def tol(prec, ref):
+    s = max(1.0, float(ref.abs().max()))
+    return (1e-5 if prec == "fp32" else 1e-3) * s
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (9, 3806, 128), (333, 64, 2304), (1, 5, 24)])
+def test_gemm_store(prec, M, N, K):
+    rt = Runtime(prec)
+    A, Ar = to_op(rt, rnd(M, K, seed=1))
+    B, Br = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3).to(DEV)
+    ref = Ar.double() @ Br.double().t() + bias.cpu().double()
+    # fp32 output with an unaligned leading dimension (N may be odd)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    rt.gemm(L.EPI_STORE_F32, A, B, M, N, K, out, N, bias=bias)
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= tol(prec, ref), err
+    # operand-dtype output into a padded buffer; pad columns must stay untouched
+    outT = torch.zeros((M, _ru(N)), dtype=rt.op_dtype, device=DEV)
+    rt.gemm(L.EPI_RELU_T, A, B, M, N, K, outT, outT.shape[1], bias=bias)
+    torch.cuda.synchronize()
+    got = outT.float().cpu()
+    assert (got[:, N:] == 0).all()
+    lim = tol(prec, ref) + (0.0 if prec == "fp32" else 2 ** -8 * float(ref.abs().max()))
+    assert (got[:, :N].double() - ref.clamp(min=0)).abs().max().item() <= lim
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_transpose_detecting(prec):
+    """A = I-like with an asymmetric B: catches swapped row/col output mappings."""
+    rt = Runtime(prec)
+    M = N = K = 128
+    a = torch.zeros(M, K)
+    a[torch.arange(M), (torch.arange(M) * 7 + 3) % K] = 1.0
+    b = (torch.arange(N).float()[:, None] * 0.01 + torch.arange(K).float()[None, :] * 0.5) / 64.0
+    A, Ar = to_op(rt, a)
+    B, Br = to_op(rt, b)
+    out = torch.empty((M, N), device=DEV)
+    rt.gemm(L.EPI_STORE_F32, A, B, M, N, K, out, N)
+    torch.cuda.synchronize()
+    ref = Ar @ Br.t()
+    assert (out.cpu() - ref).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_gemm_fused_epilogues(prec):
+    rt = Runtime(prec)
+    M, N, K = 310, 256, 128
+    A, Ar = to_op(rt, rnd(M, K, seed=1))
+    B, Br = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3).to(DEV)
+    res = rnd(M, N, seed=4).to(DEV)
+    lin = Ar.double() @ Br.double().t() + bias.cpu().double()
+    # residual, no dropout
+    out = torch.empty((M, N), device=DEV)
+    rt.gemm(L.EPI_DROP_RES_F32, A, B, M, N, K, out, N, bias=bias, res=res, ldres=N)
+    torch.cuda.synchronize()
+    ref = res.cpu().double() + lin
+    assert (out.cpu().double() - ref).abs().max().item() <= tol(prec, ref)
+    # residual with dropout: the kept set must equal timhip_dropout_mask for the same (seed, site)
+    p, seed, site = 0.3, 1234567, 42
+    mask = torch.empty((M, N), dtype=torch.uint8, device=DEV)
+    L.call("timhip_dropout_mask", seed, site, p, M, N, L.ptr(mask), st())
+    rt.gemm(L.EPI_DROP_RES_F32, A, B, M, N, K, out, N, bias=bias, res=res, ldres=N, p_drop=p, seed=seed, site=site)
+    torch.cuda.synchronize()
+    mk = mask.cpu().double()
+    assert abs(mk.mean().item() - (1 - p)) < 0.01
+    ref = res.cpu().double() + lin * mk / (1 - p)
+    assert (out.cpu().double() - ref).abs().max().item() <= tol(prec, ref)
+    # GELU + dropout, two outputs
+    u = torch.zeros((M, N), dtype=rt.op_dtype, device=DEV)
+    h = torch.zeros((M, N), dtype=rt.op_dtype, device=DEV)
+    rt.gemm(L.EPI_GELU_DROP_T2, A, B, M, N, K, h, N, out1=u, ld1=N, bias=bias, p_drop=p, seed=seed, site=site)
+    torch.cuda.synchronize()
+    rnd_tol = 0.0 if prec == "fp32" else 2 ** -8 * float(lin.abs().max()) * 2
+    assert (u.float().cpu().double() - lin).abs().max().item() <= tol(prec, lin) + rnd_tol
+    href = O._gelu(lin) * mk / (1 - p)
+    assert (h.float().cpu().double() - href).abs().max().item() <= tol(prec, href) + rnd_tol
+    # gelu' * mask epilogue (dgrad through the FFN)
+    g = torch.zeros((M, N), dtype=rt.op_dtype, device=DEV)
+    rt.gemm(L.EPI_DGELU_T, A, B, M, N, K, g, N, aux=u, ldaux=N, p_drop=p, seed=seed, site=site)
+    torch.cuda.synchronize()
+    uu = u.float().cpu().double().requires_grad_(True)
+    O._gelu(uu).sum().backward()
+    gref = (Ar.double() @ Br.double().t()) * mk / (1 - p) * uu.grad
+    assert (g.float().cpu().double() - gref).abs().max().item() <= tol(prec, gref) + rnd_tol
+    # split-K accumulate
+    acc = torch.ones((M, N), device=DEV)
+    rt.gemm(L.EPI_ATOMIC_F32, A, B, M, N, K, acc, N, splitk=2)
+    torch.cuda.synchronize()
+    ref = 1.0 + Ar.double() @ Br.double().t()
+    assert (acc.cpu().double() - ref).abs().max().item() <= tol(prec, ref)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_wgrad_and_colsum(prec):
+    rt = Runtime(prec)
+    M, N, K = 523, 200, 72
+    dY, dYr = to_op(rt, rnd(M, N, seed=5))
+    X, Xr = to_op(rt, rnd(M, K, seed=6))
+    dW = torch.ones((N, K), device=DEV)
+    db = torch.ones((N,), device=DEV)
+    rt.wgrad(dY, N, X, K, M, dW, db)
+    torch.cuda.synchronize()
+    ref = 1.0 + dYr.double().t() @ Xr.double()
+    assert (dW.cpu().double() - ref).abs().max().item() <= tol(prec, ref) * 4
+    refb = 1.0 + dYr.double().sum(0)
+    assert (db.cpu().double() - refb).abs().max().item() <= tol(prec, refb) * 4
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cols,act", [(1024, 0), (512, 2), (64, 1), (32, 2), (256, 0)])
+def test_layernorm_fwd_bwd(prec, cols, act):
+    rt = Runtime(prec)
+    rows = 77
+    y = rnd(rows, cols, seed=7)
+    w = 1 + 0.1 * rnd(cols, seed=8)
+    b = 0.1 * rnd(cols, seed=9)
+    dxo = rnd(rows, cols, seed=10)
+    yd, wd, bd, dxd = [t.to(DEV) for t in (y, w, b, dxo)]
+    xf = torch.empty((rows, cols), device=DEV)
+    xt = torch.zeros((rows, _ru(cols)), dtype=rt.op_dtype, device=DEV)
+    stats = torch.empty((rows, 2), device=DEV)
+    rt.ln_fwd(yd, rows, cols, act, wd, bd, xf=xf, ldx=cols, xt=xt, ldt=xt.shape[1], stats=stats)
+    torch.cuda.synchronize()
+    y64 = y.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    a = {0: lambda t: t, 1: torch.relu, 2: O._gelu}[act](y64)
+    ref = O._ln(a, w64, b64)
+    assert (xf.cpu().double() - ref.detach()).abs().max().item() <= 2e-5
+    assert (xt[:, :cols].float().cpu().double() - ref.detach()).abs().max().item() <= (2e-5 if prec == "fp32" else 0.05)
+    (ref * dxo.double()).sum().backward()
+    dyf = torch.empty((rows, cols), device=DEV)
+    dg = torch.zeros(cols, device=DEV)
+    dbeta = torch.zeros(cols, device=DEV)
+    rt.ln_bwd(dxd, yd, stats, rows, cols, act, wd, dyf=dyf, dgamma=dg, dbeta=dbeta)
+    torch.cuda.synchronize()
+    assert (dyf.cpu().double() - y64.grad).abs().max().item() <= 1e-4 * max(1.0, y64.grad.abs().max().item())
+    assert (dg.cpu().double() - w64.grad).abs().max().item() <= 1e-4 * max(1.0, w64.grad.abs().max().item())
+    assert (dbeta.cpu().double() - b64.grad).abs().max().item() <= 1e-4 * max(1.0, b64.grad.abs().max().item())
+
+
+def _attn_case(prec, B, S, F, H, Dh, p=0.0, seed=11):
+    rt = Runtime(prec)
+    E = H * Dh
+    qkv, qkvr = to_op(rt, rnd(B * S, 3 * E, seed=seed, scale=1.0), ld=3 * E)
+    do, dor = to_op(rt, rnd(B * S, E, seed=seed + 1), ld=E)
+    desc = L.TimDesc(B, S, F, E // 2, E, H, 4 * E, rt.prec, p, 99, 1, 0)
+    o = torch.zeros((B * S, E), dtype=rt.op_dtype, device=DEV)
+    lse = torch.empty((B, H, S), device=DEV)
+    L.call("timhip_attention_fwd", C.byref(desc), L.ptr(qkv), L.ptr(o), L.ptr(lse), st())
+    torch.cuda.synchronize()
+    mask = None
+    if p > 0:
+        LP = (F + 1 + 3) // 4 * 4
+        mk = torch.empty((B * H * S, LP), dtype=torch.uint8, device=DEV)
+        L.call("timhip_dropout_mask", 99, 16 + 8 * 1 + 0, p, B * H * S, LP, L.ptr(mk), st())
+        torch.cuda.synchronize()
+        mask = mk.cpu().view(B, H, S, LP)[..., :F + 1].double()
+    x = qkvr.double().view(B, S, 3, H, Dh).requires_grad_(True)
+    q, k, v = [x[:, :, i].transpose(1, 2) for i in range(3)]
+    ref = O.attention_structured(q, k, v, F, mask, p).transpose(1, 2).reshape(B * S, E)
+    rnd_tol = 0.0 if prec == "fp32" else 2 ** -8 * float(ref.abs().max())
+    err = (o.float().cpu().double() - ref.detach()).abs().max().item()
+    assert err <= tol(prec, ref) + rnd_tol, ("fwd", err)
+    # backward
+    (ref * dor.double()).sum().backward()
+    gref = x.grad.reshape(B * S, 3 * E)
+    dqkv = torch.zeros((B * S, 3 * E), dtype=rt.op_dtype, device=DEV)
+    wsb = L.load().timhip_attention_bwd_workspace_bytes(C.byref(desc))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    L.call("timhip_attention_bwd", C.byref(desc), L.ptr(qkv), L.ptr(o), L.ptr(lse), L.ptr(do), L.ptr(dqkv),
+           L.ptr(ws), wsb, st())
+    torch.cuda.synchronize()
+    rnd_tol = 0.0 if prec == "fp32" else 2 ** -7 * float(gref.abs().max())
+    err = (dqkv.float().cpu().double() - gref).abs().max().item()
+    assert err <= 5 * tol(prec, gref) + rnd_tol, ("bwd", err)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("B,S,F,H,Dh", [(2, 22, 12, 2, 32), (2, 155, 100, 2, 128), (1, 80, 50, 1, 128),
+                                        (1, 12, 12, 2, 64), (1, 205, 150, 1, 128)])
+def test_attention_structured(prec, B, S, F, H, Dh):
+    _attn_case(prec, B, S, F, H, Dh)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_attention_dropout(prec):
+    _attn_case(prec, 2, 40, 24, 2, 64, p=0.25)
+
+
+def test_dropout_mask_statistics_and_determinism():
+    for p in (0.1, 0.5):
+        m1 = torch.empty((257, 1024), dtype=torch.uint8, device=DEV)
+        m2 = torch.empty_like(m1)
+        m3 = torch.empty_like(m1)
+        L.call("timhip_dropout_mask", 7, 3, p, 257, 1024, L.ptr(m1), st())
+        L.call("timhip_dropout_mask", 7, 3, p, 257, 1024, L.ptr(m2), st())
+        L.call("timhip_dropout_mask", 8, 3, p, 257, 1024, L.ptr(m3), st())
+        torch.cuda.synchronize()
+        assert torch.equal(m1, m2)
+        assert not torch.equal(m1, m3)
+        keep = m1.float().mean().item()
+        assert abs(keep - (1 - p)) < 4 * math.sqrt(p * (1 - p) / m1.numel()) + 1e-4
+        # no row/column structure
+        assert (m1.float().mean(0) - (1 - p)).abs().max().item() < 0.2
+        assert abs(np.corrcoef(m1.cpu().numpy().ravel()[:-1], m1.cpu().numpy().ravel()[1:])[0, 1]) < 0.01

@@ -1,0 +1,239 @@
+"""End-to-end parity of the HIP path (through tim_amd.TIM -> libtimhip C ABI) with the CPU
+oracle and with the golden vectors of the imported reference, on a real MI355X.
+
+Tolerances (BASELINE.json north_star): per-query logits within 1e-5 for the fp32 kernels
+and within 1e-3 for the bf16 kernels.  For bf16 the comparison point is the oracle
+evaluated in the same arithmetic (GEMM/attention operands rounded to bf16, fp32
+accumulate): bf16 operand rounding alone moves the logits by up to ~1e-2 from the
+fp32 reference (oracle-predicted, asserted below with a 3e-2 bound), which no bf16-MFMA
+implementation can avoid; see DESIGN.md "Precision".
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tim_oracle as O  # noqa: E402
+from tests import helpers as H  # noqa: E402
+from tim_amd.config import named_config  # noqa: E402
+
+DEV = "cuda:0"
+TOL_FP32 = 1e-5
+TOL_BF16 = 1e-3
+
+
+def build(cfg, precision, sd):
+    if cfg.variant == "detection":
+        from tim_amd.detection import TIM
+        m = TIM(cfg.num_class, visual_input_dim=cfg.visual_input_dim, audio_input_dim=cfg.audio_input_dim,
+                feat_drop=cfg.feat_drop, seq_drop=cfg.seq_drop, d_model=cfg.d_model,
+                feedfoward_scale=cfg.feedforward_scale, nhead=cfg.nhead, num_layers=cfg.num_layers,
+                enc_dropout=cfg.enc_dropout, input_modality=cfg.input_modality, data_modality=cfg.data_modality,
+                num_feats=cfg.num_feats, include_verb_noun=cfg.include_verb_noun, precision=precision)
+    else:
+        from tim_amd.tim import TIM
+        m = TIM(cfg.num_class, visual_input_dim=cfg.visual_input_dim, audio_input_dim=cfg.audio_input_dim,
+                feat_drop=cfg.feat_drop, seq_drop=cfg.seq_drop, d_model=cfg.d_model,
+                feedforward_scale=cfg.feedforward_scale, nhead=cfg.nhead, num_layers=cfg.num_layers,
+                enc_dropout=cfg.enc_dropout, input_modality=cfg.input_modality, data_modality=cfg.data_modality,
+                num_feats=cfg.num_feats, include_verb_noun=cfg.include_verb_noun, precision=precision)
+    missing, unexpected = m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    assert not missing and not unexpected
+    return m.to(DEV).eval()
+
+
+def run_model(m, inp, nv, na, grads=True, R=None):
+    vis = inp["visual"].to(DEV).float()
+    aud = inp["audio"].to(DEV).float()
+    times = inp["times"].to(DEV).float().requires_grad_(grads)
+    if vis.dim() == 3:
+        vis.requires_grad_(grads)
+    if aud.dim() == 3:
+        aud.requires_grad_(grads)
+    te = m(times, "time_mlp")
+    cls, feats = m([vis, aud], "encoder", te, nv, na)
+    outs = H.named_outputs(cls, feats)
+    res = {"outs": {k: v.detach().cpu() for k, v in outs.items()}, "te": te.detach().cpu()}
+    if grads:
+        loss = sum((outs[k] * R[k].to(DEV)).sum() for k in outs)
+        loss.backward()
+        res["grads"] = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+        res["gin"] = {k: t.grad.detach().cpu() for k, t in (("visual", vis), ("audio", aud), ("times", times))
+                      if t.grad is not None}
+    torch.cuda.synchronize()
+    return res
+
+
+def oracle_run(cfg, sd, inp, nv, na, R, dtype, rd=None):
+    sd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd.items()}
+    leaves = {k: inp[k].to(dtype).clone().requires_grad_(inp[k].dim() == 3) for k in ("visual", "audio", "times")}
+    te = O.time_mlp(sd, leaves["times"], rd)
+    cls, feats = O.encoder(sd, cfg, leaves["visual"], leaves["audio"], te, nv, na, rd=rd)[:2]
+    outs = H.named_outputs(cls, feats)
+    loss = sum((outs[k] * R[k].to(dtype)).sum() for k in outs)
+    loss.backward()
+    return ({k: v.detach() for k, v in outs.items()}, te.detach(),
+            {k: v.grad for k, v in sd.items() if v.grad is not None},
+            {k: v.grad for k, v in leaves.items() if v.grad is not None})
+
+
+def maxerr(a, b):
+    return (a.double() - b.double()).abs().max().item() if a.numel() else 0.0
+
+
+def relerr(a, b):
+    """max abs error relative to the tensor's own max magnitude"""
+    s = max(b.double().abs().max().item(), 1e-30) if b.numel() else 1.0
+    return maxerr(a, b) / s
+
+
+# ------------------------------------------------------------------------------------------------
+# tiny configs, every modality combination of the golden set: outputs AND gradients
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fname,im,dm,vn,nv,na", H.rec_golden_cases())
+def test_tiny_fp32_vs_golden_reference(fname, im, dm, vn, nv, na):
+    """fp32 HIP kernels vs the fp64 outputs/gradients of the imported reference."""
+    g = np.load(os.path.join(H.GOLDEN, fname))
+    cfg = H.tiny_cfg("recognition", im, dm, vn)
+    sd, inp = H.synth_torch(cfg, 3, nv, na, seed=1, dtype=torch.float64)
+    m = build(cfg, "fp32", sd)
+    shapes = {k[4:]: g[k].shape for k in g.files if k.startswith("out/") and k[4:] in
+              ("verb", "noun", "action", "audio", "feats")}
+    R = {k: torch.from_numpy(v).float() for k, v in
+         __import__("tim_amd.synth", fromlist=["x"]).make_cotangents(cfg, 3, nv, na, shapes, seed=1,
+                                                                     dtype=np.float64).items()}
+    res = run_model(m, inp, nv, na, True, R)
+    assert maxerr(res["te"], torch.from_numpy(g["out/te"])) <= TOL_FP32
+    assert set(res["outs"]) == set(shapes)
+    for k, v in res["outs"].items():
+        assert tuple(v.shape) == g["out/" + k].shape
+        assert maxerr(v, torch.from_numpy(g["out/" + k])) <= TOL_FP32, k
+    for k in g.files:
+        if k.startswith("grad/") and g[k].ndim > 0:
+            assert relerr(res["grads"][k[5:]], torch.from_numpy(g[k])) <= 1e-4, k
+        elif k.startswith("grad/"):
+            n = res["grads"][k[5:]].double().norm().item()
+            assert abs(n - float(g[k])) <= 1e-4 * max(1.0, float(g[k])), k
+        elif k.startswith("gin/"):
+            assert relerr(res["gin"][k[4:]], torch.from_numpy(g[k])) <= 1e-4, k
+
+
+@pytest.mark.parametrize("fname,im,dm,vn,nv,na", H.rec_golden_cases()[:3])
+def test_tiny_bf16_vs_oracle(fname, im, dm, vn, nv, na):
+    cfg = H.tiny_cfg("recognition", im, dm, vn)
+    sd, inp = H.synth_torch(cfg, 3, nv, na, seed=1, dtype=torch.float32)
+    m = build(cfg, "bf16", sd)
+    with torch.no_grad():
+        pre = O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na)
+    outs0 = H.named_outputs(*pre)
+    R = H.cotangents(cfg, 3, nv, na, outs0, seed=1, dtype=torch.float32)
+    res = run_model(m, inp, nv, na, True, R)
+    o_bf, te_bf, g_bf, gi_bf = oracle_run(cfg, sd, inp, nv, na, R, torch.float32, rd=torch.bfloat16)
+    o_32, te_32, g_32, gi_32 = oracle_run(cfg, sd, inp, nv, na, R, torch.float32)
+    for k, v in res["outs"].items():
+        assert maxerr(v, o_bf[k]) <= TOL_BF16 * max(1.0, o_bf[k].abs().max().item()), (k, maxerr(v, o_bf[k]))
+        assert maxerr(v, o_32[k]) <= 3e-2 * max(1.0, o_32[k].abs().max().item()), k
+    for k, v in res["grads"].items():
+        assert relerr(v, g_32[k]) <= 6e-2, (k, relerr(v, g_32[k]))
+
+
+# ------------------------------------------------------------------------------------------------
+# real model sizes (BASELINE configs[0] and configs[1] shapes at small batch)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cname,B,nv,na", [("C1", 2, 10, 0), ("C2a", 2, 15, 10), ("C3", 2, 15, 10)])
+def test_named_config_fp32(cname, B, nv, na):
+    g = np.load(os.path.join(H.GOLDEN, "%s_rec_summary.npz" % cname))
+    cfg = named_config(cname)
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
+    m = build(cfg, "fp32", sd)
+    with torch.no_grad():
+        o32 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+    R = H.cotangents(cfg, B, nv, na, o32, seed=2, dtype=torch.float32)
+    res = run_model(m, inp, nv, na, True, R)
+    for k, v in res["outs"].items():
+        # vs the fp32 CPU oracle and vs the committed slices of the fp32 reference
+        assert maxerr(v, o32[k]) <= TOL_FP32 * max(1.0, o32[k].abs().max().item()), (k, maxerr(v, o32[k]))
+        if k != "feats":
+            assert maxerr(v[:, :8], torch.from_numpy(g["out/%s/slice" % k])) <= 2e-5, k
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith("/stats"):
+            name = k[5:-6]
+            n = res["grads"][name].double().norm().item()
+            assert abs(n - g[k][3]) <= 5e-4 * max(1.0, g[k][3]), (name, n, g[k][3])
+
+
+@pytest.mark.parametrize("cname,B,nv,na", [("C1", 2, 10, 0), ("C2a", 4, 15, 10)])
+def test_named_config_bf16(cname, B, nv, na):
+    cfg = named_config(cname)
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
+    m = build(cfg, "bf16", sd)
+    res = run_model(m, inp, nv, na, grads=False)
+    with torch.no_grad():
+        obf = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na, rd=torch.bfloat16))
+        o32 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+    for k, v in res["outs"].items():
+        assert maxerr(v, obf[k]) <= TOL_BF16 * max(1.0, obf[k].abs().max().item()), (k, maxerr(v, obf[k]))
+        assert maxerr(v, o32[k]) <= 3e-2 * max(1.0, o32[k].abs().max().item()), k
+
+
+def test_train_mode_dropout_replay_is_deterministic_and_consistent():
+    """Philox dropout: same step seed => bit-identical outputs and gradients; a gradient check
+    against finite differences (fp32 kernels) proves the backward regenerates the forward masks."""
+    cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+    cfg.feat_drop, cfg.seq_drop, cfg.enc_dropout = 0.3, 0.25, 0.2
+    nv, na = 4, 2
+    sd, inp = H.synth_torch(cfg, 3, nv, na, seed=5, dtype=torch.float32)
+    m = build(cfg, "fp32", sd).train()
+    with torch.no_grad():
+        o32 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+    R = H.cotangents(cfg, 3, nv, na, o32, seed=5, dtype=torch.float32)
+
+    def loss_of(times):
+        m.rt.step = 100  # same Philox step => same masks
+        te = m(times, "time_mlp")
+        cls, feats = m([inp["visual"].to(DEV), inp["audio"].to(DEV)], "encoder", te, nv, na)
+        outs = H.named_outputs(cls, feats)
+        return sum((outs[k] * R[k].to(DEV)).sum() for k in outs), outs
+
+    t0 = inp["times"].to(DEV).requires_grad_(True)
+    l1, o1 = loss_of(t0)
+    l1.backward()
+    g1 = t0.grad.clone()
+    gw1 = m.time_mlp[2].weight.grad.clone()
+    m.zero_grad()
+    t1 = inp["times"].to(DEV).requires_grad_(True)
+    l2, o2 = loss_of(t1)
+    l2.backward()
+    assert l1.item() == l2.item()
+    assert torch.equal(g1, t1.grad)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k])
+    # dropout really happened
+    m.eval()
+    l3, _ = loss_of(inp["times"].to(DEV))
+    assert abs(l3.item() - l1.item()) > 1e-3
+    m.train()
+    # directional finite difference on the time inputs
+    torch.manual_seed(0)
+    dirn = torch.randn_like(t0)
+    eps = 1e-3
+    lp, _ = loss_of((inp["times"].to(DEV) + eps * dirn))
+    lm, _ = loss_of((inp["times"].to(DEV) - eps * dirn))
+    fd = (lp.item() - lm.item()) / (2 * eps)
+    an = (g1 * dirn).sum().item()
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (fd, an)
+    assert gw1.abs().sum().item() > 0
+
+
+def test_cpu_input_fails_loudly():
+    cfg = H.tiny_cfg("recognition", "visual", "visual", True)
+    sd, inp = H.synth_torch(cfg, 2, 5, 0, seed=1, dtype=torch.float32)
+    from tim_amd.tim import TIM
+    from tim_amd._lib import TimHipError
+    m = TIM(cfg.num_class, visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2,
+            input_modality="visual", data_modality="visual", num_feats=6)
+    with pytest.raises(TimHipError):
+        m(inp["times"], "time_mlp")

@@ -1,0 +1,119 @@
+"""CPU-only checks of the host mirror: drop-in boundary (state_dict names/shapes/order for every
+modality combo), C-ABI library symbols, token-row plan vs the oracle's assembly, loud failure
+without a GPU."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tim_oracle as O
+from tests import helpers as H
+from tim_amd import _lib
+from tim_amd.functional import EncoderPlan
+
+
+def _build(variant, cfg):
+    if variant == "detection":
+        from tim_amd.detection import TIM
+        return TIM(cfg.num_class, visual_input_dim=cfg.visual_input_dim, audio_input_dim=cfg.audio_input_dim,
+                   d_model=cfg.d_model, nhead=cfg.nhead, num_layers=cfg.num_layers,
+                   input_modality=cfg.input_modality, data_modality=cfg.data_modality, num_feats=cfg.num_feats,
+                   include_verb_noun=cfg.include_verb_noun)
+    from tim_amd.tim import TIM
+    return TIM(cfg.num_class, visual_input_dim=cfg.visual_input_dim, audio_input_dim=cfg.audio_input_dim,
+               d_model=cfg.d_model, nhead=cfg.nhead, num_layers=cfg.num_layers,
+               input_modality=cfg.input_modality, data_modality=cfg.data_modality, num_feats=cfg.num_feats,
+               include_verb_noun=cfg.include_verb_noun)
+
+
+def test_state_dict_keys_match_reference_recognition():
+    keys = json.load(open(os.path.join(H.GOLDEN, "keys_recognition.json")))
+    n = 0
+    for k, v in keys.items():
+        if k.startswith("_"):
+            continue
+        im, dm, vn = k.split("/")
+        m = _build("recognition", H.tiny_cfg("recognition", im, dm, bool(int(vn))))
+        assert [[a, list(b.shape)] for a, b in m.state_dict().items()] == v, k
+        n += 1
+    assert n == 10
+
+
+def test_state_dict_keys_match_reference_detection():
+    keys = json.load(open(os.path.join(H.GOLDEN, "keys_detection.json")))
+    for im, dm, nc, tag in H.DET_CASES:
+        m = _build("detection", H.tiny_cfg("detection", im, dm, tag == "vn", num_class=nc))
+        assert [[a, list(b.shape)] for a, b in m.state_dict().items()] == keys["%s/%s/%s" % (im, dm, tag)]
+        assert m.num_queries == 399 and m.train_pool.shape[1] == 799  # det tim.py:140-142
+
+
+def test_full_size_parameter_count_and_fresh_layers_identical():
+    from tim_amd.tim import TIM
+    m = TIM([[97, 300, 3806], 44])
+    assert sum(p.numel() for p in m.parameters()) == 58303640
+    l0, l5 = m.transformer_encoder.layers[0], m.transformer_encoder.layers[5]
+    assert torch.equal(l0.linear1.weight, l5.linear1.weight)  # _get_clones deepcopy, transformers.py:113-114
+
+
+def test_load_state_dict_roundtrip_with_reference_named_weights():
+    from tim_amd import synth
+    cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(cfg, seed=3).items()}
+    m = _build("recognition", cfg)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(os.path.dirname(H.GOLDEN), "..", "include", "timhip.h")).read()
+    declared = set(re.findall(r"\b(timhip_[a-z0-9_]+)\s*\(", hdr))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.exported_symbols())
+    assert lib.timhip_version() == 1
+    assert lib.timhip_strerror(-3).decode().startswith("workspace")
+
+
+def test_cpu_tensors_fail_loudly():
+    cfg = H.tiny_cfg("recognition", "visual", "visual", True)
+    m = _build("recognition", cfg)
+    with pytest.raises(_lib.TimHipError):
+        m(torch.zeros(2, 11, 2), "time_mlp")
+    with pytest.raises(_lib.TimHipError):
+        m([torch.zeros(2, 6, 24), torch.zeros(2, 0)], "encoder", torch.zeros(2, 11, 32), 5, 0)
+
+
+@pytest.mark.parametrize("fname,im,dm,vn,nv,na", H.rec_golden_cases())
+def test_token_row_plan_matches_oracle_assembly(fname, im, dm, vn, nv, na):
+    """Evaluate the row table on CPU and compare with the oracle's feature_encoding()."""
+    cfg = H.tiny_cfg("recognition", im, dm, vn)
+    sd, inp = H.synth_torch(cfg, 3, nv, na, seed=1, dtype=torch.float64)
+    te = O.time_mlp(sd, inp["times"])
+    want = O.feature_encoding(sd, cfg, inp["visual"], inp["audio"], te, nv, na)
+    plan = EncoderPlan(cfg, te.shape[1], nv, na)
+    assert plan.S == want.shape[1] == cfg.F + cfg.num_queries(nv, na)
+    d = cfg.d_model
+    e = {}
+    for name, slot in plan.embedders:
+        e[slot] = O._embed(sd, name, inp[name], None, cfg, None)
+    got = torch.zeros_like(want)
+    for s, (kind, src, te_row, mod) in enumerate(plan.rows):
+        left = sd["feature_encoding." + plan.cls_names[src]].reshape(d) if kind == 1 else e[0 if kind == 0 else 1][:, src]
+        row = torch.cat([left.expand(3, d) if kind == 1 else left, te[:, te_row]], -1)
+        if mod >= 0:
+            row = row + sd["feature_encoding." + plan.mod_names[mod]].reshape(-1)
+        got[:, s] = row
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-12)
+    # head slices agree with the oracle's tail slicing
+    cls = O.cls_heads(sd, cfg, want, nv, na)
+    for slot, pname, s0, n in plan.heads:
+        ref = dict(zip(("verb", "noun", "action", "audio"), cls))[slot]
+        w, b = sd["cls_head." + pname + ".weight"], sd["cls_head." + pname + ".bias"]
+        mine = (want[:, s0:s0 + n] @ w.t() + b).reshape(-1, w.shape[0])
+        np.testing.assert_allclose(mine.numpy(), ref.numpy(), atol=1e-12)

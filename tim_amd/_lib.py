@@ -1,0 +1,119 @@
+"""ctypes binding of libtimhip.so (include/timhip.h).
+
+The product path has NO fallback: if the library is missing or a call fails the
+error is raised.  PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtimhip.so")
+
+PREC_BF16, PREC_BF16X3, PREC_FP32 = 0, 1, 2
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32}
+
+(EPI_STORE_T, EPI_RELU_T, EPI_STORE_F32, EPI_GELU_DROP_T2, EPI_DROP_RES_F32, EPI_ADD_F32,
+ EPI_DGELU_T, EPI_DRELU_T, EPI_ATOMIC_F32, EPI_SIGMOID_F32, EPI_DRELU_F32IN_T) = range(11)
+
+# dropout site ids (csrc/common.h)
+SITE_FEAT_V, SITE_FEAT_A, SITE_SEQ = 1, 2, 3
+
+vp, i32, u32, u64, f32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
+
+
+class TimDesc(C.Structure):
+    _fields_ = [("B", i32), ("S", i32), ("F", i32), ("d", i32), ("E", i32), ("H", i32), ("FF", i32),
+                ("precision", i32), ("p_drop", f32), ("seed", u64), ("layer", i32), ("reserved", i32)]
+
+
+_LP = ["in_w", "in_wt", "out_w", "out_wt", "l1_w", "l1_wt", "l2_w", "l2_wt",
+       "in_b", "out_b", "l1_b", "l2_b", "n1_w", "n1_b", "n2_w", "n2_b"]
+_LG = ["in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w", "n2_b"]
+
+
+class TimLayerParams(C.Structure):
+    _fields_ = [(n, vp) for n in _LP]
+
+
+class TimLayerGrads(C.Structure):
+    _fields_ = [(n, vp) for n in _LG]
+
+
+class TimEpi(C.Structure):
+    _fields_ = [("out0", vp), ("out1", vp), ("bias", vp), ("res", vp), ("aux", vp),
+                ("ld0", i32), ("ld1", i32), ("ldres", i32), ("ldaux", i32),
+                ("p_drop", f32), ("site", u32), ("seed", u64)]
+
+
+_SIGS = {
+    "timhip_version": (C.c_int, []),
+    "timhip_strerror": (C.c_char_p, [C.c_int]),
+    "timhip_layer_saved_bytes": (sz, [C.POINTER(TimDesc)]),
+    "timhip_layer_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
+    "timhip_cast_weight": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, vp]),
+    "timhip_gemm_nt": (C.c_int, [i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(TimEpi), i32, vp]),
+    "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "timhip_transpose": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, vp]),
+    "timhip_colsum": (C.c_int, [i32, vp, i32, i32, i32, vp, vp]),
+    "timhip_cast_rows": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, f32, u64, u32, vp]),
+    "timhip_dropout_rows_bwd": (C.c_int, [vp, i32, i32, i32, vp, i32, f32, u64, u32, vp]),
+    "timhip_layernorm_fwd": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, vp, vp]),
+    "timhip_layernorm_bwd": (C.c_int, [i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, i32,
+                                       f32, u64, u32, vp, vp, vp]),
+    "timhip_attention_fwd": (C.c_int, [C.POINTER(TimDesc), vp, vp, vp, vp]),
+    "timhip_attention_bwd": (C.c_int, [C.POINTER(TimDesc), vp, vp, vp, vp, vp, vp, sz, vp]),
+    "timhip_attention_bwd_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
+    "timhip_time_l1_fwd": (C.c_int, [i32, vp, i32, i32, vp, vp, vp, i32, vp]),
+    "timhip_time_l1_bwd": (C.c_int, [i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
+    "timhip_dropout_mask": (C.c_int, [u64, u32, f32, i32, i32, vp, vp]),
+    "timhip_layer_fwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp, vp, vp, sz, vp]),
+    "timhip_layer_bwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp,
+                                   C.POINTER(TimLayerGrads), vp, sz, vp]),
+    "timhip_assemble_fwd": (C.c_int, [i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, f32, u64, u32,
+                                      vp, vp, vp]),
+    "timhip_assemble_bwd": (C.c_int, [vp, i32, i32, i32, vp, i32, i32, f32, u64, u32, vp, vp, vp, vp, vp, vp]),
+    "timhip_gather_rows": (C.c_int, [i32, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "timhip_scatter_rows_add": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+class TimHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtimhip.so (built by `__graft_entry__.build()` / csrc/Makefile).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TimHipError("libtimhip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (make -C tim_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().timhip_strerror(rc).decode()
+        raise TimHipError("libtimhip: %s failed: %s (%d)" % (what, msg, rc))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,222 @@
+// extern "C" stage entry points: one post-norm encoder layer forward/backward
+// (transformers.py:92-111), plus small utilities.  Pure launch sequencing: no
+// allocation, no synchronisation, no retained state.
+#include "common.h"
+
+namespace {
+
+struct SavedLayout {
+  size_t qkv, o, lse, y1, st1, x1t, u, h, y2, st2, total;
+};
+
+SavedLayout saved_layout(const TimDesc& d) {
+  const size_t M = (size_t)d.B * d.S, ts = opsize(d.precision);
+  SavedLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  L.qkv = take(M * 3 * d.E * ts);
+  L.o = take(M * d.E * ts);
+  L.lse = take((size_t)d.B * d.H * d.S * 4);
+  L.y1 = take(M * d.E * 4);
+  L.st1 = take(M * 2 * 4);
+  L.x1t = take(M * d.E * ts);
+  L.u = take(M * d.FF * ts);
+  L.h = take(M * d.FF * ts);
+  L.y2 = take(M * d.E * 4);
+  L.st2 = take(M * 2 * 4);
+  L.total = off;
+  return L;
+}
+
+struct WsLayout {
+  size_t f32a, f32b, Ta, Tb, Tc, tA, tB, attn, total;
+};
+
+WsLayout ws_layout(const TimDesc& d) {
+  const size_t M = (size_t)d.B * d.S, ts = opsize(d.precision);
+  const size_t Mp = round_up((int)M, 64);
+  const size_t wide = (size_t)(3 * d.E > d.FF ? 3 * d.E : d.FF);
+  const size_t mid = (size_t)(d.FF > d.E ? d.FF : d.E);
+  WsLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  L.f32a = take(M * d.E * 4);
+  L.f32b = take(M * d.E * 4);
+  L.Ta = take(M * wide * ts);
+  L.Tb = take(M * d.E * ts);
+  L.Tc = take(M * d.E * ts);
+  L.tA = take(wide * Mp * ts);
+  L.tB = take(mid * Mp * ts);
+  L.attn = take(tim_attention_bwd_ws(d));
+  L.total = off;
+  return L;
+}
+
+int check_layer_desc(const TimDesc& d) {
+  if (d.B <= 0 || d.S <= 0 || d.F <= 0 || d.F > d.S || d.E <= 0 || d.H <= 0 || d.FF <= 0) return TIMHIP_EINVAL;
+  if (d.E % 64 || d.FF % 64 || d.E % d.H) return TIMHIP_EUNSUPPORTED;
+  if (d.precision != TIMHIP_PREC_BF16 && d.precision != TIMHIP_PREC_FP32) return TIMHIP_EUNSUPPORTED;
+  if (d.p_drop < 0.f || d.p_drop >= 1.f) return TIMHIP_EINVAL;
+  return TIMHIP_OK;
+}
+
+TimEpi epi0() {
+  TimEpi e;
+  e.out0 = e.out1 = nullptr; e.bias = e.res = nullptr; e.aux = nullptr;
+  e.ld0 = e.ld1 = e.ldres = e.ldaux = 0; e.p_drop = 0.f; e.site = 0; e.seed = 0;
+  return e;
+}
+
+int splitk_for(int Mout, int Nout, int Kp) {
+  const int tiles = ((Mout + 127) / 128) * ((Nout + 127) / 128);
+  int sk = (768 + tiles - 1) / tiles;
+  const int maxk = Kp / 256 > 0 ? Kp / 256 : 1;
+  if (sk > maxk) sk = maxk;
+  if (sk < 1) sk = 1;
+  if (sk > 32) sk = 32;
+  return sk;
+}
+
+// dW[Nout, Kout] += dY[M, Nout]^T X[M, Kout]   (+ db[Nout] += colsum dY)
+int wgrad(int prec, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
+          void* tA, void* tB, hipStream_t s) {
+  const int Mp = round_up(M, 64);
+  int rc;
+  if (db && (rc = tim_colsum(prec, dY, M, Nout, ldy, db, s))) return rc;
+  if ((rc = tim_transpose(prec, dY, M, Nout, ldy, tA, Mp, s))) return rc;
+  if ((rc = tim_transpose(prec, X, M, Kout, ldx, tB, Mp, s))) return rc;
+  TimEpi e = epi0();
+  e.out0 = dW; e.ld0 = Kout;
+  return tim_gemm_nt(prec, TIMHIP_EPI_ATOMIC_F32, tA, Mp, tB, Mp, Nout, Kout, Mp, e, splitk_for(Nout, Kout, Mp), s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int timhip_version(void) { return TIMHIP_VERSION; }
+
+const char* timhip_strerror(int code) {
+  switch (code) {
+    case TIMHIP_OK: return "ok";
+    case TIMHIP_EINVAL: return "invalid argument (null pointer or bad descriptor field)";
+    case TIMHIP_EUNSUPPORTED: return "shape or precision not supported by the gfx950 kernels";
+    case TIMHIP_EWORKSPACE: return "workspace too small";
+    case TIMHIP_ELAUNCH: return "HIP kernel launch failed";
+    case TIMHIP_EALIGN: return "pointer or leading dimension not aligned";
+    default: return "unknown timhip error";
+  }
+}
+
+size_t timhip_layer_saved_bytes(const TimDesc* d) { return d ? saved_layout(*d).total : 0; }
+size_t timhip_layer_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).total : 0; }
+
+int timhip_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                   const TimEpi* e, int splitk, void* stream) {
+  if (!e) return TIMHIP_EINVAL;
+  return tim_gemm_nt(precision, epi, A, lda, B, ldb, M, N, K, *e, splitk, (hipStream_t)stream);
+}
+
+int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M,
+                 float* dW, float* db, void* tA, void* tB, void* stream) {
+  if (!dY || !X || !dW || !tA || !tB) return TIMHIP_EINVAL;
+  return wgrad(precision, dY, ldy, Nout, X, ldx, Kout, M, dW, db, tA, tB, (hipStream_t)stream);
+}
+
+int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_in, const void* x_in_T, float* x_out,
+                     void* x_out_T, void* saved, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !w || !x_in || !x_in_T || !x_out || !x_out_T || !saved || !workspace) return TIMHIP_EINVAL;
+  const TimDesc& d = *dp;
+  int rc = check_layer_desc(d);
+  if (rc) return rc;
+  const int M = d.B * d.S, E = d.E, FF = d.FF, prec = d.precision;
+  if (workspace_bytes < (size_t)M * E * 4) return TIMHIP_EWORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const SavedLayout L = saved_layout(d);
+  char* sv = (char*)saved;
+  void* qkv = sv + L.qkv; void* o = sv + L.o; float* lse = (float*)(sv + L.lse);
+  float* y1 = (float*)(sv + L.y1); float* st1 = (float*)(sv + L.st1); void* x1t = sv + L.x1t;
+  void* u = sv + L.u; void* h = sv + L.h; float* y2 = (float*)(sv + L.y2); float* st2 = (float*)(sv + L.st2);
+  float* x1 = (float*)workspace;
+
+  // 1. packed in-projection (F._in_projection_packed)
+  TimEpi e = epi0();
+  e.out0 = qkv; e.ld0 = 3 * E; e.bias = w->in_b;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, x_in_T, E, w->in_w, E, M, 3 * E, E, e, 1, s))) return rc;
+  // 2. structured attention
+  if ((rc = tim_attention_fwd(d, qkv, o, lse, s))) return rc;
+  // 3. out-projection + dropout1 + residual
+  e = epi0();
+  e.out0 = y1; e.ld0 = E; e.bias = w->out_b; e.res = x_in; e.ldres = E;
+  e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP1);
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, E, M, E, E, e, 1, s))) return rc;
+  // 4. norm1
+  if ((rc = tim_layernorm_fwd(prec, y1, M, E, E, 0, w->n1_w, w->n1_b, x1, E, x1t, E, st1, s))) return rc;
+  // 5. linear1 + GELU(erf) + dropout
+  e = epi0();
+  e.out0 = h; e.ld0 = FF; e.out1 = u; e.ld1 = FF; e.bias = w->l1_b;
+  e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_T2, x1t, E, w->l1_w, E, M, FF, E, e, 1, s))) return rc;
+  // 6. linear2 + dropout2 + residual
+  e = epi0();
+  e.out0 = y2; e.ld0 = E; e.bias = w->l2_b; e.res = x1; e.ldres = E;
+  e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP2);
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, FF, M, E, FF, e, 1, s))) return rc;
+  // 7. norm2
+  return tim_layernorm_fwd(prec, y2, M, E, E, 0, w->n2_w, w->n2_b, x_out, E, x_out_T, E, st2, s);
+}
+
+int timhip_layer_bwd(const TimDesc* dp, const TimLayerParams* w, const void* x_in_T, const void* saved, float* dx_out,
+                     float* dx_in, const TimLayerGrads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !w || !x_in_T || !saved || !dx_out || !dx_in || !g || !workspace) return TIMHIP_EINVAL;
+  const TimDesc& d = *dp;
+  int rc = check_layer_desc(d);
+  if (rc) return rc;
+  const WsLayout W = ws_layout(d);
+  if (workspace_bytes < W.total) return TIMHIP_EWORKSPACE;
+  const int M = d.B * d.S, E = d.E, FF = d.FF, prec = d.precision;
+  hipStream_t s = (hipStream_t)stream;
+  const SavedLayout L = saved_layout(d);
+  const char* sv = (const char*)saved;
+  const void* qkv = sv + L.qkv; const void* o = sv + L.o; const float* lse = (const float*)(sv + L.lse);
+  const float* y1 = (const float*)(sv + L.y1); const float* st1 = (const float*)(sv + L.st1);
+  const void* x1t = sv + L.x1t; const void* u = sv + L.u; const void* h = sv + L.h;
+  const float* y2 = (const float*)(sv + L.y2); const float* st2 = (const float*)(sv + L.st2);
+  char* ws = (char*)workspace;
+  float* f32a = (float*)(ws + W.f32a); float* f32b = (float*)(ws + W.f32b);
+  void* Ta = ws + W.Ta; void* Tb = ws + W.Tb; void* Tc = ws + W.Tc; void* tA = ws + W.tA; void* tB = ws + W.tB;
+
+  // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
+  if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, Tb, E, d.p_drop, d.seed,
+                              layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b, s))) return rc;
+  // linear2: dW2 += df^T h, db2 += colsum df
+  if ((rc = wgrad(prec, Tb, E, E, h, FF, FF, M, g->l2_w, g->l2_b, tA, tB, s))) return rc;
+  // du = (df W2) * dropout-mask * gelu'(u)
+  TimEpi e = epi0();
+  e.out0 = Ta; e.ld0 = FF; e.aux = u; e.ldaux = FF;
+  e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DGELU_T, Tb, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
+  // linear1: dW1 += du^T x1, db1 += colsum du
+  if ((rc = wgrad(prec, Ta, FF, FF, x1t, E, E, M, g->l1_w, g->l1_b, tA, tB, s))) return rc;
+  // dx1 = du W1 + dy2   (residual branch)
+  e = epi0();
+  e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, Ta, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
+  // norm1 backward -> dy1 (fp32) and da = dropout1-mask * dy1 (T)
+  if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, Tb, E, d.p_drop, d.seed,
+                              layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b, s))) return rc;
+  // out-projection: dWo += da^T o, dbo += colsum da ; do = da Wo
+  if ((rc = wgrad(prec, Tb, E, E, o, E, E, M, g->out_w, g->out_b, tA, tB, s))) return rc;
+  e = epi0();
+  e.out0 = Tc; e.ld0 = E;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, Tb, E, w->out_wt, E, M, E, E, e, 1, s))) return rc;
+  // attention backward -> dqkv
+  if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, Ta, ws + W.attn, W.total - W.attn, s))) return rc;
+  // in-projection: dWin += dqkv^T x_in, dbin += colsum dqkv ; dx_in = dqkv Win + dy1
+  if ((rc = wgrad(prec, Ta, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, tA, tB, s))) return rc;
+  e = epi0();
+  e.out0 = dx_in; e.ld0 = E; e.res = f32a; e.ldres = E;
+  return tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, Ta, 3 * E, w->in_wt, 3 * E, M, E, 3 * E, e, 1, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// Shared device/host helpers for libtimhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/timhip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+#define TIM_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH; \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ----------------------------------------------------------------------------
+// operand-type traits
+// ----------------------------------------------------------------------------
+template <typename T> struct OpT;
+template <> struct OpT<float> {
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct OpT<bf16_t> {
+  static __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+  static __device__ __forceinline__ bf16_t from_f(float v) { return (bf16_t)v; }
+};
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  bf16x4_t v;
+  v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
+  *reinterpret_cast<bf16x4_t*>(p) = v;
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float& a, float& b, float& c, float& d);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float& a, float& b, float& c, float& d) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  a = v.x; b = v.y; c = v.z; d = v.w;
+}
+template <>
+__device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float& a, float& b, float& c, float& d) {
+  bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+  a = (float)v[0]; b = (float)v[1]; c = (float)v[2]; d = (float)v[3];
+}
+
+// ----------------------------------------------------------------------------
+// Philox4x32-10 counter RNG: dropout masks are a pure function of
+// (seed, site, element index) so the backward regenerates them.
+// ----------------------------------------------------------------------------
+struct Philox4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t site, uint64_t ctr) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = site, c3 = 0x7149u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+
+// keep-threshold: element kept iff rnd >= thr  (P[drop] = thr / 2^32 = p)
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+// masks of the 4 consecutive elements whose linear index is 4*q .. 4*q+3
+__device__ __forceinline__ void drop_mask4(uint64_t seed, uint32_t site, uint64_t q, uint32_t thr,
+                                           float scale, float& m0, float& m1, float& m2, float& m3) {
+  Philox4 r = philox4x32_10(seed, site, q);
+  m0 = r.x >= thr ? scale : 0.f;
+  m1 = r.y >= thr ? scale : 0.f;
+  m2 = r.z >= thr ? scale : 0.f;
+  m3 = r.w >= thr ? scale : 0.f;
+}
+
+// dropout site ids (stream id = site; per-layer sites add 16*layer)
+enum {
+  SITE_FEAT_V = 1, SITE_FEAT_A = 2, SITE_SEQ = 3,
+  SITE_L_BASE = 16, SITE_L_ATTN = 0, SITE_L_DROP1 = 1, SITE_L_FFN = 2, SITE_L_DROP2 = 3, SITE_L_STRIDE = 8
+};
+static inline uint32_t layer_site(int layer, int which) {
+  return SITE_L_BASE + (uint32_t)layer * SITE_L_STRIDE + (uint32_t)which;
+}
+
+// ----------------------------------------------------------------------------
+// math
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float kInvSqrt2Pi = 0.3989422804014327f;
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ----------------------------------------------------------------------------
+// internal C++ launchers shared between translation units
+// ----------------------------------------------------------------------------
+int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
+                int K, const TimEpi& e, int splitk, hipStream_t s);
+int tim_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,
+                  hipStream_t s);
+int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
+int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
+                      const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,
+                      float* stats, hipStream_t s);
+int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
+                      const float* stats, int rows, int cols, int act, const float* w, float* dy_f32,
+                      int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,
+                      float* dgamma, float* dbeta, hipStream_t s);
+int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
+int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse,
+                      const void* d_o, void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);
+size_t tim_attention_bwd_ws(const TimDesc& d);
+
+static inline size_t opsize(int precision) { return precision == TIMHIP_PREC_FP32 ? 4 : 2; }

@@ -1,0 +1,414 @@
+// GEMM  C[M,N] = A[M,K] * B[N,K]^T  with fused epilogues (gfx950 MFMA).
+//
+// Both operands are K-contiguous ("NT"), which is the natural form of every
+// product on the TIM path once the weights are kept in two working copies
+// (W and W^T, timhip_cast_weight): forward  y = x W^T, dgrad  dx = dy (W^T)^T,
+// wgrad  dW = (dy^T)(x^T)^T.  Replaces nn.Linear / F._in_projection_packed at
+// transformers.py:102,107; encodings.py:21-26,140-153; tim.py:66-74; head.py:8-15.
+//
+// Orientation: the MFMA is issued as D = W_frag x X_frag so that D[i = n][j = m]:
+// a lane owns ONE output row m (= lane & 31) and, per accumulator quad, FOUR
+// consecutive output columns n.  Row-wise epilogues (bias, residual, GELU,
+// Philox dropout keyed on the element index) then work on 4-wide vectors and
+// store 8 B (bf16) / 16 B (fp32) per lane.
+//
+// bf16 kernel: 128x128x64 tile, 4 waves (2x2), each 64x64 = 2x2 MFMA 32x32x16,
+// operands staged HBM -> LDS with global_load_lds (16 B/lane), two LDS stages,
+// XOR swizzle applied on the SOURCE address (LDS image stays lane-linear) and on
+// the ds_read_b128 side so the fragment reads are bank-conflict free.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// epilogues
+// ---------------------------------------------------------------------------
+struct EpiDev {
+  void* out0; void* out1;
+  const float* bias; const float* res; const void* aux;
+  int ld0, ld1, ldres, ldaux;
+  uint32_t thr; float scale; uint32_t site; uint64_t seed;
+  int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
+};
+
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_one(const EpiDev& e, int m, int n, int N, float v, float mask) {
+  size_t i0 = (size_t)m * e.ld0 + n;
+  if (e.bias && EPI != TIMHIP_EPI_ADD_F32 && EPI != TIMHIP_EPI_DGELU_T && EPI != TIMHIP_EPI_DRELU_T &&
+      EPI != TIMHIP_EPI_ATOMIC_F32 && EPI != TIMHIP_EPI_DRELU_F32IN_T)
+    v += e.bias[n];
+  if (EPI == TIMHIP_EPI_STORE_T) {
+    ((T*)e.out0)[i0] = OpT<T>::from_f(v);
+  } else if (EPI == TIMHIP_EPI_RELU_T) {
+    ((T*)e.out0)[i0] = OpT<T>::from_f(fmaxf(v, 0.f));
+  } else if (EPI == TIMHIP_EPI_STORE_F32) {
+    ((float*)e.out0)[i0] = v;
+  } else if (EPI == TIMHIP_EPI_GELU_DROP_T2) {
+    ((T*)e.out1)[(size_t)m * e.ld1 + n] = OpT<T>::from_f(v);
+    ((T*)e.out0)[i0] = OpT<T>::from_f(gelu_f(v) * mask);
+  } else if (EPI == TIMHIP_EPI_DROP_RES_F32) {
+    ((float*)e.out0)[i0] = e.res[(size_t)m * e.ldres + n] + v * mask;
+  } else if (EPI == TIMHIP_EPI_ADD_F32) {
+    ((float*)e.out0)[i0] = v + (e.res ? e.res[(size_t)m * e.ldres + n] : 0.f);
+  } else if (EPI == TIMHIP_EPI_DGELU_T) {
+    float u = OpT<T>::to_f(((const T*)e.aux)[(size_t)m * e.ldaux + n]);
+    ((T*)e.out0)[i0] = OpT<T>::from_f(v * mask * gelu_grad_f(u));
+  } else if (EPI == TIMHIP_EPI_DRELU_T) {
+    float h = OpT<T>::to_f(((const T*)e.aux)[(size_t)m * e.ldaux + n]);
+    ((T*)e.out0)[i0] = OpT<T>::from_f(h > 0.f ? v : 0.f);
+  } else if (EPI == TIMHIP_EPI_DRELU_F32IN_T) {
+    float h = ((const float*)e.aux)[(size_t)m * e.ldaux + n];
+    ((T*)e.out0)[i0] = OpT<T>::from_f(h > 0.f ? v : 0.f);
+  } else if (EPI == TIMHIP_EPI_ATOMIC_F32) {
+    atomicAdd(((float*)e.out0) + i0, v);
+  } else if (EPI == TIMHIP_EPI_SIGMOID_F32) {
+    ((float*)e.out0)[i0] = 1.f / (1.f + __expf(-v));
+  }
+}
+
+constexpr bool epi_uses_dropout(int EPI) {
+  return EPI == TIMHIP_EPI_GELU_DROP_T2 || EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_DGELU_T;
+}
+
+// 4 consecutive columns n..n+3 of row m
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, float v0, float v1,
+                                         float v2, float v3) {
+  float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
+  if (epi_uses_dropout(EPI) && e.thr != 0u) {
+    // element index m*N + n, N % 4 == 0 wherever dropout is applied
+    drop_mask4(e.seed, e.site, ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2, e.thr, e.scale, k0, k1, k2, k3);
+  }
+  if (e.vec && n + 3 < N) {
+    size_t i0 = (size_t)m * e.ld0 + n;
+    if (EPI != TIMHIP_EPI_ADD_F32 && EPI != TIMHIP_EPI_DGELU_T && EPI != TIMHIP_EPI_DRELU_T &&
+        EPI != TIMHIP_EPI_ATOMIC_F32 && EPI != TIMHIP_EPI_DRELU_F32IN_T && e.bias) {
+      float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+      v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+    }
+    if (EPI == TIMHIP_EPI_STORE_T) {
+      store4<T>((T*)e.out0 + i0, v0, v1, v2, v3);
+    } else if (EPI == TIMHIP_EPI_RELU_T) {
+      store4<T>((T*)e.out0 + i0, fmaxf(v0, 0.f), fmaxf(v1, 0.f), fmaxf(v2, 0.f), fmaxf(v3, 0.f));
+    } else if (EPI == TIMHIP_EPI_STORE_F32) {
+      store4<float>((float*)e.out0 + i0, v0, v1, v2, v3);
+    } else if (EPI == TIMHIP_EPI_GELU_DROP_T2) {
+      store4<T>((T*)e.out1 + (size_t)m * e.ld1 + n, v0, v1, v2, v3);
+      store4<T>((T*)e.out0 + i0, gelu_f(v0) * k0, gelu_f(v1) * k1, gelu_f(v2) * k2, gelu_f(v3) * k3);
+    } else if (EPI == TIMHIP_EPI_DROP_RES_F32) {
+      float4 r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+      store4<float>((float*)e.out0 + i0, r.x + v0 * k0, r.y + v1 * k1, r.z + v2 * k2, r.w + v3 * k3);
+    } else if (EPI == TIMHIP_EPI_ADD_F32) {
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e.res) r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+      store4<float>((float*)e.out0 + i0, r.x + v0, r.y + v1, r.z + v2, r.w + v3);
+    } else if (EPI == TIMHIP_EPI_DGELU_T) {
+      float u0, u1, u2, u3;
+      load4<T>((const T*)e.aux + (size_t)m * e.ldaux + n, u0, u1, u2, u3);
+      store4<T>((T*)e.out0 + i0, v0 * k0 * gelu_grad_f(u0), v1 * k1 * gelu_grad_f(u1),
+                v2 * k2 * gelu_grad_f(u2), v3 * k3 * gelu_grad_f(u3));
+    } else if (EPI == TIMHIP_EPI_DRELU_T) {
+      float u0, u1, u2, u3;
+      load4<T>((const T*)e.aux + (size_t)m * e.ldaux + n, u0, u1, u2, u3);
+      store4<T>((T*)e.out0 + i0, u0 > 0.f ? v0 : 0.f, u1 > 0.f ? v1 : 0.f, u2 > 0.f ? v2 : 0.f,
+                u3 > 0.f ? v3 : 0.f);
+    } else if (EPI == TIMHIP_EPI_DRELU_F32IN_T) {
+      float4 u = *reinterpret_cast<const float4*>((const float*)e.aux + (size_t)m * e.ldaux + n);
+      store4<T>((T*)e.out0 + i0, u.x > 0.f ? v0 : 0.f, u.y > 0.f ? v1 : 0.f, u.z > 0.f ? v2 : 0.f,
+                u.w > 0.f ? v3 : 0.f);
+    } else if (EPI == TIMHIP_EPI_ATOMIC_F32) {
+      float* p = (float*)e.out0 + i0;
+      atomicAdd(p, v0); atomicAdd(p + 1, v1); atomicAdd(p + 2, v2); atomicAdd(p + 3, v3);
+    } else if (EPI == TIMHIP_EPI_SIGMOID_F32) {
+      store4<float>((float*)e.out0 + i0, 1.f / (1.f + __expf(-v0)), 1.f / (1.f + __expf(-v1)),
+                    1.f / (1.f + __expf(-v2)), 1.f / (1.f + __expf(-v3)));
+    }
+  } else {
+    if (n < N) epi_one<EPI, T>(e, m, n, N, v0, k0);
+    if (n + 1 < N) epi_one<EPI, T>(e, m, n + 1, N, v1, k1);
+    if (n + 2 < N) epi_one<EPI, T>(e, m, n + 2, N, v2, k2);
+    if (n + 3 < N) epi_one<EPI, T>(e, m, n + 3, N, v3, k3);
+  }
+}
+
+// XCD-aware tile order: block b runs on XCD b % 8 (observed); give each XCD a
+// contiguous range of logical tiles so that the tiles_n tiles sharing one A
+// row-panel hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ---------------------------------------------------------------------------
+constexpr int BK = 64;  // bf16 elements per K step = 128 B per tile row
+
+template <int EPI, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N,
+    int K, int ksteps_per_split, EpiDev e) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][A_BYTES + B_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+
+  const int nk_total = K / BK;
+  const int kt0 = blockIdx.z * ksteps_per_split;
+  const int kt1 = min(nk_total, kt0 + ksteps_per_split);
+  if (kt0 >= kt1) return;
+
+  // ---- staging: each wave-instruction moves 8 rows x 128 B ----
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  const bf16_t* a_src[A_INSTR];
+  const bf16_t* b_src[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (wave * A_INSTR + i) * 8 + lrow;
+    const int c = lchunk ^ ((row >> 1) & 7);
+    a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int row = (wave * B_INSTR + i) * 8 + lrow;
+    const int c = lchunk ^ ((row >> 1) & 7);
+    b_src[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    char* base = lds + buf * (A_BYTES + B_BYTES);
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * BK),
+          (__attribute__((address_space(3))) void*)(base + (wave * A_INSTR + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(b_src[i] + (size_t)kt * BK),
+          (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+  };
+
+  f32x16_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row = lane & 31, 16-B chunk = kk*2 + (lane >> 5), swizzled
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int a_off[TM], b_off[TN], a_swz[TM], b_swz[TN];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int row = wm * (BM / WM) + j * 32 + frow;
+    a_off[j] = row * 128;
+    a_swz[j] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * (BN / WN) + i * 32 + frow;
+    b_off[i] = A_BYTES + row * 128;
+    b_swz[i] = (row >> 1) & 7;
+  }
+
+  stage(kt0, 0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    __syncthreads();  // stage(kt) landed (vmcnt(0)) and every wave is done reading buf^1
+    if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+    const char* base = lds + buf * (A_BYTES + B_BYTES);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8_t xa[TM], wb[TN];
+      const int c = kk * 2 + fhalf;
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        xa[j] = *reinterpret_cast<const bf16x8_t*>(base + a_off[j] + ((c ^ a_swz[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wb[i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i], xa[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: D[i = n][j = m]; lane owns row m = lane & 31 ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm * (BM / WM) + j * 32 + frow;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int nb = n0 + wn * (BN / WN) + i * 32 + 4 * fhalf;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q;
+        if (n < N)
+          epi_quad<EPI, bf16_t>(e, m, n, N, acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fp32 kernel: exact f32 MFMA (v_mfma_f32_32x32x2_f32), parity mode.
+// 128x128x16 tile, 4 waves (2x2), register-staged, LDS rows padded to 17 floats.
+// ---------------------------------------------------------------------------
+constexpr int FBK = 16, FLD = 17;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb, int M,
+                                                          int N, int K, int ksteps_per_split, EpiDev e) {
+  constexpr int BM = 128, BN = 128;
+  __shared__ float sA[BM * FLD];
+  __shared__ float sB[BN * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  const int nk_total = K / FBK;
+  const int kt0 = blockIdx.z * ksteps_per_split;
+  const int kt1 = min(nk_total, kt0 + ksteps_per_split);
+  if (kt0 >= kt1) return;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256, row = idx >> 2, c4 = idx & 3;
+      ra[i] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + row, M - 1) * lda + kt * FBK + c4 * 4);
+      rb[i] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + row, N - 1) * ldb + kt * FBK + c4 * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256, row = idx >> 2, c4 = idx & 3;
+      float* pa = sA + row * FLD + c4 * 4;
+      pa[0] = ra[i].x; pa[1] = ra[i].y; pa[2] = ra[i].z; pa[3] = ra[i].w;
+      float* pb = sB + row * FLD + c4 * 4;
+      pb[0] = rb[i].x; pb[1] = rb[i].y; pb[2] = rb[i].z; pb[3] = rb[i].w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < FBK / 2; ++kk) {
+      float xa[2], wb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xa[j] = sA[(wm * 64 + j * 32 + frow) * FLD + kk * 2 + fhalf];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wb[i] = sB[(wn * 64 + i * 32 + frow) * FLD + kk * 2 + fhalf];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i], xa[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + frow;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nb = n0 + wn * 64 + i * 32 + 4 * fhalf;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q;
+        if (n < N)
+          epi_quad<EPI, float>(e, m, n, N, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                               acc[i][j][4 * q + 3]);
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch(int precision, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+           const EpiDev& e, int splitk, hipStream_t s) {
+  if (precision == TIMHIP_PREC_FP32) {
+    const int nk = K / FBK;
+    const int per = (nk + splitk - 1) / splitk;
+    dim3 grid(((M + 127) / 128) * ((N + 127) / 128), 1, splitk);
+    hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI>, grid, dim3(256), 0, s, (const float*)A, lda,
+                       (const float*)B, ldb, M, N, K, per, e);
+  } else {
+    constexpr int BM = 128, BN = 128;
+    const int nk = K / BK;
+    const int per = (nk + splitk - 1) / splitk;
+    dim3 grid(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splitk);
+    const size_t shmem = 2 * (BM + BN) * BK * 2;
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, 2, 2>), grid, dim3(256), shmem, s,
+                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, per, e);
+  }
+  if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
+  return TIMHIP_OK;
+}
+
+}  // namespace
+
+int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
+                int K, const TimEpi& te, int splitk, hipStream_t s) {
+  if (!A || !B || !te.out0) return TIMHIP_EINVAL;
+  if (M <= 0 || N <= 0 || K <= 0) return TIMHIP_EINVAL;
+  if (precision != TIMHIP_PREC_BF16 && precision != TIMHIP_PREC_FP32) return TIMHIP_EUNSUPPORTED;
+  const int Kp = round_up(K, 64);
+  if (lda % 64 || ldb % 64 || lda < Kp || ldb < Kp) return TIMHIP_EALIGN;
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return TIMHIP_EALIGN;
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && epi != TIMHIP_EPI_ATOMIC_F32) return TIMHIP_EINVAL;
+  EpiDev e;
+  e.out0 = te.out0; e.out1 = te.out1; e.bias = te.bias; e.res = te.res; e.aux = te.aux;
+  e.ld0 = te.ld0; e.ld1 = te.ld1; e.ldres = te.ldres; e.ldaux = te.ldaux;
+  e.thr = te.p_drop > 0.f ? drop_threshold(te.p_drop) : 0u;
+  e.scale = te.p_drop > 0.f ? 1.f / (1.f - te.p_drop) : 1.f;
+  e.site = te.site; e.seed = te.seed;
+  bool vec = (e.ld0 % 4 == 0) && (((uintptr_t)e.out0 & 15) == 0);
+  if (e.out1) vec = vec && (e.ld1 % 4 == 0) && (((uintptr_t)e.out1 & 15) == 0);
+  if (e.res) vec = vec && (e.ldres % 4 == 0) && (((uintptr_t)e.res & 15) == 0);
+  if (e.aux) vec = vec && (e.ldaux % 4 == 0) && (((uintptr_t)e.aux & 15) == 0);
+  if (e.bias) vec = vec && (((uintptr_t)e.bias & 15) == 0);
+  e.vec = vec ? 1 : 0;
+  if (e.thr != 0u && (N % 4) != 0) return TIMHIP_EUNSUPPORTED;
+  switch (epi) {
+#define CASE(X) case X: return launch<X>(precision, A, lda, B, ldb, M, N, Kp, e, splitk, s);
+    CASE(TIMHIP_EPI_STORE_T)
+    CASE(TIMHIP_EPI_RELU_T)
+    CASE(TIMHIP_EPI_STORE_F32)
+    CASE(TIMHIP_EPI_GELU_DROP_T2)
+    CASE(TIMHIP_EPI_DROP_RES_F32)
+    CASE(TIMHIP_EPI_ADD_F32)
+    CASE(TIMHIP_EPI_DGELU_T)
+    CASE(TIMHIP_EPI_DRELU_T)
+    CASE(TIMHIP_EPI_ATOMIC_F32)
+    CASE(TIMHIP_EPI_SIGMOID_F32)
+    CASE(TIMHIP_EPI_DRELU_F32IN_T)
+#undef CASE
+    default: return TIMHIP_EINVAL;
+  }
+}

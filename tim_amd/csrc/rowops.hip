@@ -1,0 +1,571 @@
+// HBM-bound row kernels of the TIM path: casts/transposes of operand copies,
+// LayerNorm forward/backward (nn.LayerNorm at transformers.py:98-99,108-110,
+// encodings.py:25,145,152, tim.py:73), bias-gradient column sums, sequence
+// assembly (encodings.py:190-250) and the K=2 first layer of the time MLP.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// weights: fp32 master -> operand dtype, plain or transposed, zero padded
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_weight_kernel(const float* __restrict__ src, int rows, int cols, T* __restrict__ dst,
+                                   int ld) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ld; c += gridDim.x * blockDim.x)
+    dst[(size_t)r * ld + c] = OpT<T>::from_f(c < cols ? src[(size_t)r * cols + c] : 0.f);
+}
+
+// dst[c, r] = src[r, c] through a 32x33 LDS tile; dst has ld >= rows, zero padded
+template <typename TS, typename TD>
+__global__ void transpose_kernel(const TS* __restrict__ src, int rows, int cols, int lds_, TD* __restrict__ dst,
+                                 int ld) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? OpT<TS>::to_f(src[(size_t)r * lds_ + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;  // dst row = c, dst col = r
+    if (c < cols && r < ld) dst[(size_t)c * ld + r] = OpT<TD>::from_f(tile[tx][i]);
+  }
+}
+
+// fp32 rows -> T rows with optional dropout and zero padding
+template <typename T>
+__global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int cols, int lds_, T* __restrict__ dst,
+                                 int ld, uint32_t thr, float scale, uint64_t seed, uint32_t site) {
+  const int r = blockIdx.y;
+  const int colsq = (cols + 3) >> 2;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < ld; q += gridDim.x * blockDim.x) {
+    float k[4] = {1.f, 1.f, 1.f, 1.f};
+    if (thr != 0u && q < colsq) drop_mask4(seed, site, (uint64_t)r * colsq + q, thr, scale, k[0], k[1], k[2], k[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = q * 4 + j;
+      if (c < ld) dst[(size_t)r * ld + c] = OpT<T>::from_f(c < cols ? src[(size_t)r * lds_ + c] * k[j] : 0.f);
+    }
+  }
+}
+
+// d_x[r, c] = g[r, c] * mask  (backward of the feature dropout on raw inputs)
+__global__ void drop_bwd_rows_kernel(const float* __restrict__ g, int rows, int cols, int ldg, float* __restrict__ dx,
+                                     int ldx, uint32_t thr, float scale, uint64_t seed, uint32_t site) {
+  const int r = blockIdx.y;
+  const int colsq = (cols + 3) >> 2;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < colsq; q += gridDim.x * blockDim.x) {
+    float k[4] = {1.f, 1.f, 1.f, 1.f};
+    if (thr != 0u) drop_mask4(seed, site, (uint64_t)r * colsq + q, thr, scale, k[0], k[1], k[2], k[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = q * 4 + j;
+      if (c < cols) dx[(size_t)r * ldx + c] = g[(size_t)r * ldg + c] * k[j];
+    }
+  }
+}
+
+// out[c] += sum_r src[r, c]
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ src, int rows, int cols, int ld, float* __restrict__ out,
+                              int rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += OpT<T>::to_f(src[(size_t)r * ld + c]);
+  atomicAdd(out + c, s);
+}
+
+__global__ void dropout_mask_kernel(uint64_t seed, uint32_t site, uint32_t thr, int rows, int cols, uint8_t* out) {
+  const int colsq = (cols + 3) >> 2;
+  const size_t total = (size_t)rows * colsq;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / colsq), q = (int)(i % colsq);
+    Philox4 p = philox4x32_10(seed, site, (uint64_t)r * colsq + q);
+    const uint32_t v[4] = {p.x, p.y, p.z, p.w};
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < cols) out[(size_t)r * cols + q * 4 + j] = v[j] >= thr ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm.  One wave per row; the row lives in registers (cols <= 64*4*NV).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float act_f(int act, float v) {
+  return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? gelu_f(v) : v);
+}
+__device__ __forceinline__ float act_grad_f(int act, float v) {
+  return act == 1 ? (v > 0.f ? 1.f : 0.f) : (act == 2 ? gelu_grad_f(v) : 1.f);
+}
+
+constexpr int LN_MAXV = 8;  // float4 per lane: cols <= 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ y, int rows, int cols, int ldy,
+                                                     int act, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ xf, int ldx,
+                                                     T* __restrict__ xt, int ldt, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = (cols + 255) >> 8;  // float4 slots per lane (cols % 4 == 0)
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (i < nv && c < cols) {
+      float4 t = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+      t.x = act_f(act, t.x); t.y = act_f(act, t.y); t.z = act_f(act, t.z); t.w = act_f(act, t.w);
+      v[i] = t;
+      s += (t.x + t.y) + (t.z + t.w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (i < nv && c < cols) {
+      const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  }
+  const float var = wave_sum(q) / (float)cols;
+  const float rstd = rsqrtf(var + 1e-5f);
+  if (lane == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (i < nv && c < cols) {
+      const float4 g = *reinterpret_cast<const float4*>(w + c);
+      const float4 be = *reinterpret_cast<const float4*>(b + c);
+      const float o0 = (v[i].x - mean) * rstd * g.x + be.x, o1 = (v[i].y - mean) * rstd * g.y + be.y;
+      const float o2 = (v[i].z - mean) * rstd * g.z + be.z, o3 = (v[i].w - mean) * rstd * g.w + be.w;
+      if (xf) store4<float>(xf + (size_t)row * ldx + c, o0, o1, o2, o3);
+      if (xt) store4<T>(xt + (size_t)row * ldt + c, o0, o1, o2, o3);
+    }
+  }
+}
+
+// Backward.  A block owns ROWS_PB consecutive rows (one wave walks rows wave, wave+4, ...) and
+// reduces dgamma/dbeta over its rows in registers, then LDS across its 4 waves, then one atomic
+// per column per block.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dx, int lddx,
+                                                     const float* __restrict__ y, int ldy,
+                                                     const float* __restrict__ stats, int rows, int cols, int act,
+                                                     const float* __restrict__ w, float* __restrict__ dyf, int lddy,
+                                                     T* __restrict__ dyt, int ldt, uint32_t thr, float scale,
+                                                     uint64_t seed, uint32_t site, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows_pb) {
+  extern __shared__ float red[];  // [4][2][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = (cols + 255) >> 8;
+  float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+  const int r0 = blockIdx.x * rows_pb, r1 = min(rows, r0 + rows_pb);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (i < nv && c < cols) {
+        float4 t = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+        const float4 d = *reinterpret_cast<const float4*>(dx + (size_t)row * lddx + c);
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        float4 h;
+        h.x = (act_f(act, t.x) - mean) * rstd; h.y = (act_f(act, t.y) - mean) * rstd;
+        h.z = (act_f(act, t.z) - mean) * rstd; h.w = (act_f(act, t.w) - mean) * rstd;
+        xh[i] = h;
+        ag[i].x += d.x * h.x; ag[i].y += d.y * h.y; ag[i].z += d.z * h.z; ag[i].w += d.w * h.w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        float4 gg = make_float4(d.x * ww.x, d.y * ww.y, d.z * ww.z, d.w * ww.w);
+        g[i] = gg;
+        s1 += (gg.x + gg.y) + (gg.z + gg.w);
+        s2 += (gg.x * h.x + gg.y * h.y) + (gg.z * h.z + gg.w * h.w);
+      }
+    }
+    s1 = wave_sum(s1) / (float)cols;
+    s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (i < nv && c < cols) {
+        float o0 = rstd * (g[i].x - s1 - xh[i].x * s2), o1 = rstd * (g[i].y - s1 - xh[i].y * s2);
+        float o2 = rstd * (g[i].z - s1 - xh[i].z * s2), o3 = rstd * (g[i].w - s1 - xh[i].w * s2);
+        if (act != 0) {
+          const float4 t = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+          o0 *= act_grad_f(act, t.x); o1 *= act_grad_f(act, t.y);
+          o2 *= act_grad_f(act, t.z); o3 *= act_grad_f(act, t.w);
+        }
+        if (dyf) store4<float>(dyf + (size_t)row * lddy + c, o0, o1, o2, o3);
+        if (dyt) {
+          float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
+          if (thr != 0u) drop_mask4(seed, site, ((uint64_t)row * cols + c) >> 2, thr, scale, k0, k1, k2, k3);
+          store4<T>(dyt + (size_t)row * ldt + c, o0 * k0, o1 * k1, o2 * k2, o3 * k3);
+        }
+      }
+    }
+  }
+  // block reduction of the column sums
+  float* rg = red + (size_t)wave * 2 * cols;
+  float* rb = rg + cols;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (i < nv && c < cols) {
+      *reinterpret_cast<float4*>(rg + c) = ag[i];
+      *reinterpret_cast<float4*>(rb + c) = ab[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sg += red[(size_t)k * 2 * cols + c]; sb += red[(size_t)k * 2 * cols + cols + c]; }
+    if (dgamma) atomicAdd(dgamma + c, sg);
+    if (dbeta) atomicAdd(dbeta + c, sb);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// time MLP layer 1 (K = 2: an outer product, tim.py:67)  h[r, j] = relu(t0 w[j,0] + t1 w[j,1] + b[j])
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void time_l1_fwd_kernel(const float* __restrict__ times, int rows, int d, const float* __restrict__ w,
+                                   const float* __restrict__ b, T* __restrict__ h, int ld) {
+  const int r = blockIdx.y;
+  const float t0 = times[2 * r], t1 = times[2 * r + 1];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < ld; j += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (j < d) v = fmaxf(fmaf(t0, w[2 * j], fmaf(t1, w[2 * j + 1], b[j])), 0.f);
+    h[(size_t)r * ld + j] = OpT<T>::from_f(v);
+  }
+}
+// dh: gradient w.r.t. the post-relu h (T, relu mask already applied by the dgrad epilogue).
+// dw[j,0] += sum_r dh t0 ; dw[j,1] += sum_r dh t1 ; db[j] += sum_r dh ; dt[r,:] = sum_j dh w[j,:]
+template <typename T>
+__global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restrict__ times, int rows, int d,
+                                                          const float* __restrict__ w, const T* __restrict__ dh,
+                                                          int ld, float* __restrict__ dw, float* __restrict__ db,
+                                                          float* __restrict__ dt, int rows_pb) {
+  // one block: rows [r0, r1); thread j-loop over columns accumulates dw/db; per-row dt via wave reduction
+  const int r0 = blockIdx.x * rows_pb, r1 = min(rows, r0 + rows_pb);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < d; j += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const float g = OpT<T>::to_f(dh[(size_t)r * ld + j]);
+      a0 += g * times[2 * r]; a1 += g * times[2 * r + 1]; a2 += g;
+    }
+    atomicAdd(dw + 2 * j, a0); atomicAdd(dw + 2 * j + 1, a1); atomicAdd(db + j, a2);
+  }
+  if (dt) {
+    for (int r = r0 + wave; r < r1; r += 4) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int j = lane; j < d; j += 64) {
+        const float g = OpT<T>::to_f(dh[(size_t)r * ld + j]);
+        s0 += g * w[2 * j]; s1 += g * w[2 * j + 1];
+      }
+      s0 = wave_sum(s0); s1 = wave_sum(s1);
+      if (lane == 0) { dt[2 * r] = s0; dt[2 * r + 1] = s1; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// sequence assembly (encodings.py:190-250), batch-first, no transposes
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void assemble_fwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
+                                    const float* __restrict__ e0, const float* __restrict__ e1, int n_e_rows,
+                                    const float* __restrict__ cls, const float* __restrict__ te, int Trows,
+                                    const float* __restrict__ mod, uint32_t thr, float scale, uint64_t seed,
+                                    uint32_t site, float* __restrict__ x, T* __restrict__ xt) {
+  const int bs = blockIdx.x;  // b*S + s
+  const int b = bs / S, s = bs % S;
+  const TimSeqRow r = rows[s];
+  const int E = 2 * d;
+  const float* left = r.kind == 1 ? cls + (size_t)r.src * d
+                                  : (r.kind == 0 ? e0 : e1) + ((size_t)b * n_e_rows + r.src) * d;
+  const float* right = te + ((size_t)b * Trows + r.te_row) * d;
+  const float* mv = r.mod >= 0 ? mod + (size_t)r.mod * E : nullptr;
+  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+    float4 v = c < d ? *reinterpret_cast<const float4*>(left + c) : *reinterpret_cast<const float4*>(right + (c - d));
+    if (mv) { const float4 m4 = *reinterpret_cast<const float4*>(mv + c); v.x += m4.x; v.y += m4.y; v.z += m4.z; v.w += m4.w; }
+    if (thr != 0u) {
+      float k0, k1, k2, k3;
+      drop_mask4(seed, site, ((uint64_t)bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
+      v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
+    }
+    store4<float>(x + (size_t)bs * E + c, v.x, v.y, v.z, v.w);
+    store4<T>(xt + (size_t)bs * E + c, v.x, v.y, v.z, v.w);
+  }
+}
+
+// backward: scatter dx into d_e (features, written), d_te (+= atomics: a time row can feed several
+// token rows), d_cls / d_mod (+= atomics over B*rows).
+__global__ void assemble_bwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
+                                    const float* __restrict__ dx, int n_e_rows, int Trows, uint32_t thr,
+                                    float scale, uint64_t seed, uint32_t site, float* __restrict__ d_e0,
+                                    float* __restrict__ d_e1, float* __restrict__ d_cls, float* __restrict__ d_te,
+                                    float* __restrict__ d_mod) {
+  const int bs = blockIdx.x;
+  const int b = bs / S, s = bs % S;
+  const TimSeqRow r = rows[s];
+  const int E = 2 * d;
+  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+    float4 g = *reinterpret_cast<const float4*>(dx + (size_t)bs * E + c);
+    if (thr != 0u) {
+      float k0, k1, k2, k3;
+      drop_mask4(seed, site, ((uint64_t)bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
+      g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+    }
+    if (r.mod >= 0 && d_mod) {
+      float* p = d_mod + (size_t)r.mod * E + c;
+      atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+    }
+    if (c < d) {
+      if (r.kind != 1) {
+        float* d_e = r.kind == 0 ? d_e0 : d_e1;
+        if (d_e) store4<float>(d_e + ((size_t)b * n_e_rows + r.src) * d + c, g.x, g.y, g.z, g.w);
+      } else if (d_cls) {
+        float* p = d_cls + (size_t)r.src * d + c;
+        atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+      }
+    } else if (d_te) {
+      float* p = d_te + ((size_t)b * Trows + r.te_row) * d + (c - d);
+      atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+    }
+  }
+}
+
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ xt, int B, int S, int E, int s0, int n, T* __restrict__ out) {
+  const int i = blockIdx.x;  // b*n + j
+  const int b = i / n, j = i % n;
+  const T* src = xt + ((size_t)b * S + s0 + j) * E;
+  T* dst = out + (size_t)i * E;
+  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+    float a0, a1, a2, a3;
+    load4<T>(src + c, a0, a1, a2, a3);
+    store4<T>(dst + c, a0, a1, a2, a3);
+  }
+}
+__global__ void scatter_rows_add_kernel(const float* __restrict__ d_rows, int B, int S, int E, int s0, int n,
+                                        float* __restrict__ dx) {
+  const int i = blockIdx.x;
+  const int b = i / n, j = i % n;
+  const float* src = d_rows + (size_t)i * E;
+  float* dst = dx + ((size_t)b * S + s0 + j) * E;
+  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(src + c);
+    float4 o = *reinterpret_cast<float4*>(dst + c);
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    *reinterpret_cast<float4*>(dst + c) = o;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+#define DISPATCH_T(prec, ...)                                    \
+  do {                                                           \
+    if ((prec) == TIMHIP_PREC_FP32) { using T = float; __VA_ARGS__; } \
+    else { using T = bf16_t; __VA_ARGS__; }                      \
+  } while (0)
+
+int tim_transpose(int precision, const void* src, int rows, int cols, int lds_, void* dst, int ld, hipStream_t s) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || ld < rows) return TIMHIP_EINVAL;
+  dim3 grid((cols + 31) / 32, (ld + 31) / 32);
+  DISPATCH_T(precision, hipLaunchKernelGGL((transpose_kernel<T, T>), grid, dim3(256), 0, s, (const T*)src, rows,
+                                           cols, lds_, (T*)dst, ld));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s) {
+  if (!src || !out || rows <= 0 || cols <= 0) return TIMHIP_EINVAL;
+  const int rpb = 64;
+  dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
+  DISPATCH_T(precision, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)src, rows, cols, ld,
+                                           out, rpb));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w,
+                      const float* b, float* xf, int ldx, void* xt, int ldt, float* stats, hipStream_t s) {
+  if (!y || !w || !b || rows <= 0) return TIMHIP_EINVAL;
+  if (cols % 4 || cols > 256 * LN_MAXV || ldy % 4 || (xf && ldx % 4) || (xt && ldt % 4)) return TIMHIP_EUNSUPPORTED;
+  dim3 grid((rows + 3) / 4);
+  DISPATCH_T(precision, hipLaunchKernelGGL(ln_fwd_kernel<T>, grid, dim3(256), 0, s, y, rows, cols, ldy, act, w, b,
+                                           xf, ldx, (T*)xt, ldt, stats));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
+                      int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
+                      float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, hipStream_t s) {
+  if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
+  if (cols % 4 || cols > 256 * LN_MAXV || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
+    return TIMHIP_EUNSUPPORTED;
+  const int rpb = 16;
+  dim3 grid((rows + rpb - 1) / rpb);
+  const size_t shmem = (size_t)4 * 2 * cols * sizeof(float);
+  const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  DISPATCH_T(precision, hipLaunchKernelGGL(ln_bwd_kernel<T>, grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats,
+                                           rows, cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site,
+                                           dgamma, dbeta, rpb));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+extern "C" {
+
+int timhip_cast_weight(int precision, const float* src, int rows, int cols, void* dst, int ld, int transpose,
+                       void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!src || !dst || rows <= 0 || cols <= 0 || ld % 64) return TIMHIP_EINVAL;
+  if (!transpose) {
+    if (ld < cols) return TIMHIP_EINVAL;
+    dim3 grid((ld + 255) / 256, rows);
+    DISPATCH_T(precision, hipLaunchKernelGGL(cast_weight_kernel<T>, grid, dim3(256), 0, s, src, rows, cols, (T*)dst, ld));
+  } else {
+    if (ld < rows) return TIMHIP_EINVAL;
+    dim3 grid((cols + 31) / 32, (ld + 31) / 32);
+    DISPATCH_T(precision, hipLaunchKernelGGL((transpose_kernel<float, T>), grid, dim3(256), 0, s, src, rows, cols,
+                                             cols, (T*)dst, ld));
+  }
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_transpose(int precision, const void* src, int rows, int cols, int lds_, void* dst, int ld, void* stream) {
+  return tim_transpose(precision, src, rows, cols, lds_, dst, ld, (hipStream_t)stream);
+}
+
+int timhip_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, void* stream) {
+  return tim_colsum(precision, src, rows, cols, ld, out, (hipStream_t)stream);
+}
+
+int timhip_cast_rows(int precision, const float* src, int rows, int cols, int lds_, void* dst, int ld, float p_drop,
+                     uint64_t seed, uint32_t site, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || ld < cols || ld % 4) return TIMHIP_EINVAL;
+  const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  dim3 grid((ld / 4 + 255) / 256, rows);
+  DISPATCH_T(precision, hipLaunchKernelGGL(cast_rows_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, rows,
+                                           cols, lds_, (T*)dst, ld, thr, scale, seed, site));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_dropout_rows_bwd(const float* g, int rows, int cols, int ldg, float* dx, int ldx, float p_drop,
+                            uint64_t seed, uint32_t site, void* stream) {
+  if (!g || !dx || rows <= 0 || cols <= 0) return TIMHIP_EINVAL;
+  const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  dim3 grid(((cols + 3) / 4 + 255) / 256, rows);
+  hipLaunchKernelGGL(drop_bwd_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, rows, cols, ldg, dx, ldx, thr,
+                     scale, seed, site);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_dropout_mask(uint64_t seed, uint32_t site, float p, int rows, int cols, uint8_t* out, void* stream) {
+  if (!out || rows <= 0 || cols <= 0) return TIMHIP_EINVAL;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, seed, site,
+                     drop_threshold(p), rows, cols, out);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w,
+                         const float* b, float* x_f32, int ldx, void* x_T, int ldt, float* stats, void* stream) {
+  return tim_layernorm_fwd(precision, y, rows, cols, ldy, act, w, b, x_f32, ldx, x_T, ldt, stats, (hipStream_t)stream);
+}
+
+int timhip_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
+                         int rows, int cols, int act, const float* w, float* dy_f32, int lddy, void* dy_T, int ldt,
+                         float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, void* stream) {
+  return tim_layernorm_bwd(precision, dx, lddx, y, ldy, stats, rows, cols, act, w, dy_f32, lddy, dy_T, ldt, p_drop,
+                           seed, site, dgamma, dbeta, (hipStream_t)stream);
+}
+
+int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const float* w, const float* b, void* h,
+                       int ld, void* stream) {
+  if (!times || !w || !b || !h || rows <= 0 || ld < d) return TIMHIP_EINVAL;
+  dim3 grid((ld + 255) / 256, rows);
+  DISPATCH_T(precision, hipLaunchKernelGGL(time_l1_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, times,
+                                           rows, d, w, b, (T*)h, ld));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const float* w, const void* dh, int ld,
+                       float* dw, float* db, float* dt, void* stream) {
+  if (!times || !w || !dh || !dw || !db || rows <= 0) return TIMHIP_EINVAL;
+  const int rpb = 32;
+  dim3 grid((rows + rpb - 1) / rpb);
+  DISPATCH_T(precision, hipLaunchKernelGGL(time_l1_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, times,
+                                           rows, d, w, (const T*)dh, ld, dw, db, dt, rpb));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_assemble_fwd(int precision, const TimSeqRow* rows, int B, int S, int d, const float* e0, const float* e1,
+                        int n_e_rows, const float* cls, const float* te, int T_, const float* mod, float p_seq_drop,
+                        uint64_t seed, uint32_t site, float* x, void* x_T, void* stream) {
+  if (!rows || !te || !x || !x_T || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
+  const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
+  const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
+  DISPATCH_T(precision, hipLaunchKernelGGL(assemble_fwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
+                                           rows, B, S, d, e0, e1, n_e_rows, cls, te, T_, mod, thr, scale, seed, site, x,
+                                           (T*)x_T));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float* dx, int n_e_rows, int T_,
+                        float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0, float* d_e1, float* d_cls,
+                        float* d_te, float* d_mod, void* stream) {
+  if (!rows || !dx || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
+  const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
+  const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows,
+                     T_, thr, scale, seed, site, d_e0, d_e1, d_cls, d_te, d_mod);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_gather_rows(int precision, const void* x_T, int B, int S, int E, int s0, int n, void* rows_T, void* stream) {
+  if (!x_T || !rows_T || n <= 0 || E % 4) return TIMHIP_EINVAL;
+  DISPATCH_T(precision, hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(B * n), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)x_T, B, S, E, s0, n, (T*)rows_T));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, int n, float* dx, void* stream) {
+  if (!d_rows || !dx || n <= 0 || E % 4) return TIMHIP_EINVAL;
+  hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(B * n), dim3(256), 0, (hipStream_t)stream, d_rows, B, S, E, s0, n, dx);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+}  // extern "C"

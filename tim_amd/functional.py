@@ -1,0 +1,516 @@
+"""Host-side sequencing of the TIM hot path over libtimhip's C ABI.
+
+Two autograd Functions mirror the two entry points the reference loops call
+(rec train.py:198,209-215): `time_mlp` (tim.py:66-74,181-182) and `encoder`
+(tim.py:147-172).  All arithmetic runs in the HIP library; torch supplies device
+buffers, the current stream and autograd bookkeeping only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import call, ptr
+
+
+def _ru(x, m=64):
+    return (x + m - 1) // m * m
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Runtime:
+    """Per-model state that is not a parameter: precision, operand-dtype working copies of
+    the weights (plain and transposed, refreshed when a parameter's version changes),
+    the Philox step counter, and the gradient-bucket hook used by data parallelism."""
+
+    def __init__(self, precision="bf16"):
+        if precision not in L.PRECISIONS:
+            raise ValueError("precision must be one of %s" % list(L.PRECISIONS))
+        if precision == "bf16x3":
+            raise L.TimHipError("precision 'bf16x3' is not implemented yet")
+        self.precision_name = precision
+        self.prec = L.PRECISIONS[precision]
+        self.op_dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self._wcache = {}
+        self.seed = 0x5EED
+        self.step = 0
+        self.bucket_hook = None  # callable(bucket_name, flat_grad_tensor) -> None
+        self.finish_hook = None  # callable() -> None, called at the end of the encoder backward
+
+    # ---- buffers -------------------------------------------------------------------------------
+    def zeros_op(self, rows, cols, dev):
+        return torch.zeros((rows, _ru(cols)), dtype=self.op_dtype, device=dev)
+
+    def empty_op(self, rows, cols, dev):
+        assert cols % 64 == 0
+        return torch.empty((rows, cols), dtype=self.op_dtype, device=dev)
+
+    # ---- weight working copies -----------------------------------------------------------------
+    def weight(self, p, transposed=False):
+        """operand-dtype copy of a [N,K] fp32 weight: [N, ru(K)] or (transposed) [K, ru(N)]"""
+        key = (id(p), transposed)
+        ent = self._wcache.get(key)
+        ver = (p.data_ptr(), p._version)
+        if ent is not None and ent[0] == ver and ent[1].device == p.device:
+            return ent[1]
+        N, K = p.shape
+        src = p.detach()
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        if transposed:
+            buf = ent[1] if ent is not None and ent[1].device == p.device else \
+                torch.empty((K, _ru(N)), dtype=self.op_dtype, device=p.device)
+            call("timhip_cast_weight", self.prec, ptr(src), N, K, ptr(buf), buf.shape[1], 1, _stream())
+        else:
+            buf = ent[1] if ent is not None and ent[1].device == p.device else \
+                torch.empty((N, _ru(K)), dtype=self.op_dtype, device=p.device)
+            call("timhip_cast_weight", self.prec, ptr(src), N, K, ptr(buf), buf.shape[1], 0, _stream())
+        self._wcache[key] = (ver, buf)
+        return buf
+
+    def next_seed(self):
+        self.step += 1
+        return (self.seed * 0x9E3779B97F4A7C15 + self.step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    # ---- thin op wrappers ------------------------------------------------------------------------
+    def gemm(self, epi, A, B, M, N, K, out0, ld0, out1=None, ld1=0, bias=None, res=None, ldres=0, aux=None,
+             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1):
+        if M == 0 or N == 0:
+            return
+        e = L.TimEpi(ptr(out0), ptr(out1), ptr(bias), ptr(res), ptr(aux), ld0, ld1, ldres, ldaux,
+                     float(p_drop), site, seed)
+        call("timhip_gemm_nt", self.prec, epi, ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K,
+             C.byref(e), splitk, _stream())
+
+    def wgrad(self, dY, Nout, X, Kout, M, dW, db):
+        """dW[Nout,Kout] += dY[:M,:Nout]^T X[:M,:Kout]; db += colsum(dY)"""
+        if M == 0:
+            return
+        Mp = _ru(M)
+        tA = torch.empty((Nout, Mp), dtype=self.op_dtype, device=dY.device)
+        tB = torch.empty((Kout, Mp), dtype=self.op_dtype, device=dY.device)
+        call("timhip_wgrad", self.prec, ptr(dY), dY.stride(0), Nout, ptr(X), X.stride(0), Kout, M, ptr(dW),
+             ptr(db), ptr(tA), ptr(tB), _stream())
+
+    def ln_fwd(self, y, rows, cols, act, w, b, xf=None, ldx=0, xt=None, ldt=0, stats=None):
+        call("timhip_layernorm_fwd", self.prec, ptr(y), rows, cols, y.stride(0), act, ptr(w), ptr(b), ptr(xf), ldx,
+             ptr(xt), ldt, ptr(stats), _stream())
+
+    def ln_bwd(self, dx, y, stats, rows, cols, act, w, dyf=None, dyt=None, dgamma=None, dbeta=None):
+        call("timhip_layernorm_bwd", self.prec, ptr(dx), dx.stride(0), ptr(y), y.stride(0), ptr(stats), rows, cols,
+             act, ptr(w), ptr(dyf), 0 if dyf is None else dyf.stride(0), ptr(dyt),
+             0 if dyt is None else dyt.stride(0), 0.0, 0, 0, ptr(dgamma), ptr(dbeta), _stream())
+
+
+def _f32c(t):
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise L.TimHipError("%s: the TIM hot path runs on the MI355X HIP kernels only; got a %s tensor "
+                            "(there is no CPU fallback)" % (what, t.device))
+    L.load()
+
+
+# ==================================================================================================
+# time MLP   (tim.py:66-74)
+# ==================================================================================================
+class TimeMlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rt, times, w0, b0, w2, b2, w4, b4, lnw, lnb):
+        _require_gpu(times, "time_mlp")
+        dev = times.device
+        d = w0.shape[0]
+        t2 = _f32c(times).reshape(-1, 2)
+        R = t2.shape[0]
+        ldd = _ru(d)
+        w0c, b0c, b2c, b4c, lnwc, lnbc = [_f32c(t) for t in (w0, b0, b2, b4, lnw, lnb)]
+        h1 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        call("timhip_time_l1_fwd", rt.prec, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(h1), ldd, _stream())
+        h2 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        rt.gemm(L.EPI_RELU_T, h1, rt.weight(w2), R, d, d, h2, ldd, bias=b2c)
+        u3 = torch.empty((R, d), dtype=torch.float32, device=dev)
+        rt.gemm(L.EPI_STORE_F32, h2, rt.weight(w4), R, d, d, u3, d, bias=b4c)
+        te = torch.empty((R, d), dtype=torch.float32, device=dev)
+        stats = torch.empty((R, 2), dtype=torch.float32, device=dev)
+        rt.ln_fwd(u3, R, d, 1, lnwc, lnbc, xf=te, ldx=d, stats=stats)
+        ctx.rt = rt
+        ctx.shape = tuple(times.shape)
+        ctx.save_for_backward(t2, h1, h2, u3, stats, w0, w2, w4, lnw)
+        return te.view(*times.shape[:-1], d)
+
+    @staticmethod
+    def backward(ctx, d_te):
+        rt = ctx.rt
+        t2, h1, h2, u3, stats, w0, w2, w4, lnw = ctx.saved_tensors
+        dev = t2.device
+        R, d = u3.shape
+        ldd = _ru(d)
+        g = _f32c(d_te).reshape(R, d)
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        dw0, db0, dw2, db2, dw4, db4, dlnw, dlnb = z(d, 2), z(d), z(d, d), z(d), z(d, d), z(d), z(d), z(d)
+        du3 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        rt.ln_bwd(g, u3, stats, R, d, 1, _f32c(lnw), dyt=du3, dgamma=dlnw, dbeta=dlnb)
+        rt.wgrad(du3, d, h2, d, R, dw4, db4)
+        du2 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        rt.gemm(L.EPI_DRELU_T, du3, rt.weight(w4, True), R, d, d, du2, ldd, aux=h2, ldaux=ldd)
+        rt.wgrad(du2, d, h1, d, R, dw2, db2)
+        du1 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        rt.gemm(L.EPI_DRELU_T, du2, rt.weight(w2, True), R, d, d, du1, ldd, aux=h1, ldaux=ldd)
+        d_times = torch.empty((R, 2), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        call("timhip_time_l1_bwd", rt.prec, ptr(t2), R, d, ptr(_f32c(w0)), ptr(du1), ldd, ptr(dw0), ptr(db0),
+             ptr(d_times), _stream())
+        if d_times is not None:
+            d_times = d_times.view(ctx.shape)
+        return None, d_times, dw0, db0, dw2, db2, dw4, db4, dlnw, dlnb
+
+
+# ==================================================================================================
+# encoder: feature encoding + L layers + heads   (tim.py:147-172)
+# ==================================================================================================
+class EncoderPlan:
+    """Token-row table and head slices for one (config, T, Nv, Na).  Mirrors the concatenation
+    order of encodings.py:190-250 and the tail slicing of head.py:17-38 (det head.py:27-46)."""
+
+    def __init__(self, cfg, T, nv, na):
+        nf, F = cfg.num_feats, cfg.F
+        det = cfg.variant == "detection"
+        rows = []  # (kind, src, te_row, mod)
+        self.cls_names = []
+        self.mod_names = []
+        self.embedders = []  # (name, e-slot)
+
+        def cls_idx(name):
+            if name not in self.cls_names:
+                self.cls_names.append(name)
+            return self.cls_names.index(name)
+
+        av = cfg.input_modality == "audio_visual"
+        if av:
+            self.mod_names = ["visual_modality_encoding", "audio_modality_encoding"]
+            self.embedders = [("visual", 0), ("audio", 1)]
+            rows += [(0, s, s, 0) for s in range(nf)]
+            rows += [(2, s, nf + s, 1) for s in range(nf)]
+            nq_te = T - 2 * nf
+            if "visual" in cfg.data_modality and nv > 0:
+                groups = (["visual_verb_cls", "visual_noun_cls"] if (cfg.include_verb_noun and not det) else []) \
+                    + ["visual_action_cls"]
+                for g in groups:
+                    rows += [(1, cls_idx(g), 2 * nf + j, 0) for j in range(nv)]
+            if "audio" in cfg.data_modality and na > 0:
+                rows += [(1, cls_idx("audio_action_cls"), 2 * nf + nq_te - na + j, 1) for j in range(na)]
+        elif cfg.input_modality == "visual":
+            self.embedders = [("visual", 0)]
+            rows += [(0, s, s, -1) for s in range(nf)]
+            nq = T - nf
+            if det:
+                groups = ["visual_action_cls"]
+            else:
+                groups = (["verb_cls", "noun_cls"] if cfg.include_verb_noun else []) + ["action_cls"]
+            for g in groups:
+                rows += [(1, cls_idx(g), nf + j, -1) for j in range(nq)]
+        else:
+            self.embedders = [("audio", 0)]
+            rows += [(0, s, s, -1) for s in range(nf)]
+            nq = T - nf
+            g = "audio_action_cls" if det else "action_cls"
+            rows += [(1, cls_idx(g), nf + j, -1) for j in range(nq)]
+        self.rows = rows
+        self.S = len(rows)
+        self.F = F
+        self.T = T
+        S = self.S
+        # heads: (output slot, parameter prefix, s0, n)
+        heads = []
+        nc = cfg.num_class
+        if cfg.data_modality == "audio_visual":
+            aud_start = S - na if na > 0 else S
+            act_start = aud_start - nv
+            vn = isinstance(nc, list) if det else isinstance(nc[0], list)
+            if vn:
+                if det:
+                    heads += [("verb", "fc_visual_verb", act_start, nv), ("noun", "fc_visual_noun", act_start, nv)]
+                else:
+                    heads += [("verb", "fc_visual_verb", act_start - 2 * nv, nv),
+                              ("noun", "fc_visual_noun", act_start - nv, nv)]
+            heads += [("action", "fc_visual_action", act_start, nv), ("audio", "fc_audio_action", aud_start, S - aud_start)]
+            self.reg = [("reg_visual", "fc_visual_action", act_start, nv),
+                        ("reg_audio", "fc_audio_action", aud_start, S - aud_start)] if det else []
+        elif cfg.data_modality == "visual":
+            act_start = S - nv
+            if isinstance(nc[0], list):
+                if det:
+                    heads += [("verb", "fc_visual_verb", act_start, nv), ("noun", "fc_visual_noun", act_start, nv)]
+                else:
+                    heads += [("verb", "fc_visual_verb", act_start - 2 * nv, nv),
+                              ("noun", "fc_visual_noun", act_start - nv, nv)]
+            heads += [("action", "fc_visual_action", act_start, nv)]
+            self.reg = [("reg_visual", "fc_visual_action", act_start, nv)] if det else []
+        else:
+            heads += [("audio", "fc_audio_action", S - na, na)]
+            self.reg = [("reg_audio", "fc_audio_action", S - na, na)] if det else []
+        for (_, _, s0, n) in heads:
+            if s0 < F or s0 + n > S:
+                raise ValueError("head slice [%d,%d) outside the query rows [%d,%d): num_v_queries/num_a_queries "
+                                 "do not match the time encodings" % (s0, s0 + n, F, S))
+        self.heads = heads
+        self._table = {}
+
+    def table(self, dev):
+        t = self._table.get(dev)
+        if t is None:
+            t = torch.tensor(self.rows, dtype=torch.int32).reshape(-1, 4).to(dev)
+            self._table[dev] = t
+        return t
+
+
+OUT_SLOTS = ("verb", "noun", "action", "audio", "feats", "reg_visual", "reg_audio")
+
+
+class EncoderFn(torch.autograd.Function):
+    """forward(ctx, model, nv, na, visual, audio, te, *params) -> 7 outputs (OUT_SLOTS; None if absent).
+    `params` is `model._encoder_param_list()` so that autograd tracks every parameter."""
+
+    @staticmethod
+    def forward(ctx, model, nv, na, visual, audio, te, *params):
+        rt, cfg = model.rt, model.cfg
+        _require_gpu(te, "encoder")
+        dev = te.device
+        P = dict(zip(model._encoder_param_names, params))
+        B, T, d = te.shape
+        E, FF, H, Lyr, nf = cfg.E, cfg.FF, cfg.nhead, cfg.num_layers, cfg.num_feats
+        if d != cfg.d_model:
+            raise ValueError("time encodings have width %d, model d_model is %d" % (d, cfg.d_model))
+        plan = model._plan(T, nv, na)
+        S, F = plan.S, plan.F
+        M = B * S
+        training = model.training
+        seed = rt.next_seed() if training else 0
+        p_feat = cfg.feat_drop if training else 0.0
+        p_seq = cfg.seq_drop if training else 0.0
+        p_enc = cfg.enc_dropout if training else 0.0
+        te_c = _f32c(te)
+        st = _stream()
+        fe = "feature_encoding."
+
+        # ---- modality embedders: e = LN(GELU(drop(x) W^T + b))  (encodings.py:21-26,140-153)
+        emb_saved = []
+        e_bufs = [None, None]
+        for name, slot in plan.embedders:
+            x = visual if name == "visual" else audio
+            if x.dim() != 3 or x.shape[0] != B or x.shape[1] != nf:
+                raise ValueError("%s input must be [B=%d, num_feats=%d, C], got %s" % (name, B, nf, tuple(x.shape)))
+            Cin = x.shape[2]
+            x2 = _f32c(x).reshape(B * nf, Cin)
+            R = B * nf
+            xT = torch.empty((R, _ru(Cin)), dtype=rt.op_dtype, device=dev)
+            site = L.SITE_FEAT_V if name == "visual" else L.SITE_FEAT_A
+            call("timhip_cast_rows", rt.prec, ptr(x2), R, Cin, Cin, ptr(xT), xT.shape[1], p_feat, seed, site, st)
+            w = P[fe + name + "_embedder.1.weight"]
+            u = torch.empty((R, d), dtype=torch.float32, device=dev)
+            rt.gemm(L.EPI_STORE_F32, xT, rt.weight(w), R, d, Cin, u, d, bias=_f32c(P[fe + name + "_embedder.1.bias"]))
+            e = torch.empty((R, d), dtype=torch.float32, device=dev)
+            stats = torch.empty((R, 2), dtype=torch.float32, device=dev)
+            rt.ln_fwd(u, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), _f32c(P[fe + name + "_embedder.3.bias"]),
+                      xf=e, ldx=d, stats=stats)
+            e_bufs[slot] = e
+            emb_saved.append((name, slot, xT, u, stats, Cin, site))
+
+        # ---- sequence assembly (encodings.py:190-250)
+        cls = torch.cat([_f32c(P[fe + n]).reshape(1, d) for n in plan.cls_names], 0) if plan.cls_names else None
+        mod = torch.cat([_f32c(P[fe + n]).reshape(1, E) for n in plan.mod_names], 0) if plan.mod_names else None
+        xs_f = [torch.empty((M, E), dtype=torch.float32, device=dev) for _ in range(Lyr + 1)]
+        xs_t = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(Lyr + 1)]
+        tab = plan.table(dev)
+        call("timhip_assemble_fwd", rt.prec, ptr(tab), B, S, d, ptr(e_bufs[0]), ptr(e_bufs[1]), nf, ptr(cls),
+             ptr(te_c), T, ptr(mod), p_seq, seed, L.SITE_SEQ, ptr(xs_f[0]), ptr(xs_t[0]), st)
+
+        # ---- L post-norm encoder layers (transformers.py:44-45,92-111)
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, 0)
+        saved_bytes = L.load().timhip_layer_saved_bytes(C.byref(desc))
+        ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
+        ws = model._workspace(ws_bytes, dev)
+        stack = model._stack_prefix
+        layer_saved = []
+        lparams = []
+        for l in range(Lyr):
+            pre = "%s.layers.%d." % (stack, l)
+            lp = model._layer_params(rt, P, pre)
+            lparams.append(lp)
+            sv = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            desc.layer = l
+            call("timhip_layer_fwd", C.byref(desc), C.byref(lp[0]), ptr(xs_f[l]), ptr(xs_t[l]), ptr(xs_f[l + 1]),
+                 ptr(xs_t[l + 1]), ptr(sv), ptr(ws), ws_bytes, st)
+            layer_saved.append(sv)
+            if l > 0:
+                xs_f[l] = None  # the fp32 stream of inner layers is not needed by the backward
+
+        # ---- heads (head.py:17-38)
+        xL_t = xs_t[Lyr]
+        outs = {}
+        head_saved = []
+        for slot, pname, s0, n in plan.heads:
+            w = P["cls_head." + pname + ".weight"]
+            Cn = w.shape[0]
+            rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
+            logits = torch.empty((B * n, Cn), dtype=torch.float32, device=dev)
+            if n > 0:
+                call("timhip_gather_rows", rt.prec, ptr(xL_t), B, S, E, s0, n, ptr(rows), st)
+                rt.gemm(L.EPI_STORE_F32, rows, rt.weight(w), B * n, Cn, E, logits, Cn,
+                        bias=_f32c(P["cls_head." + pname + ".bias"]))
+            outs[slot] = logits
+            head_saved.append((slot, pname, s0, n, rows))
+        reg_saved = []
+        for slot, pname, s0, n in plan.reg:
+            pre = "reg_head." + pname + "."
+            hid = E // 2
+            rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
+            h1 = torch.zeros((B * n, _ru(hid)), dtype=rt.op_dtype, device=dev)
+            h2 = torch.zeros((B * n, _ru(hid)), dtype=rt.op_dtype, device=dev)
+            y = torch.empty((B * n, 2), dtype=torch.float32, device=dev)
+            if n > 0:
+                call("timhip_gather_rows", rt.prec, ptr(xL_t), B, S, E, s0, n, ptr(rows), st)
+                rt.gemm(L.EPI_RELU_T, rows, rt.weight(P[pre + "0.weight"]), B * n, hid, E, h1, h1.shape[1],
+                        bias=_f32c(P[pre + "0.bias"]))
+                rt.gemm(L.EPI_RELU_T, h1, rt.weight(P[pre + "2.weight"]), B * n, hid, hid, h2, h2.shape[1],
+                        bias=_f32c(P[pre + "2.bias"]))
+                rt.gemm(L.EPI_SIGMOID_F32, h2, rt.weight(P[pre + "4.weight"]), B * n, 2, hid, y, 2,
+                        bias=_f32c(P[pre + "4.bias"]))
+            outs[slot] = y
+            reg_saved.append((slot, pname, s0, n, rows, h1, h2, y))
+        feats = xs_f[Lyr].view(B, S, E)[:, :F]
+        outs["feats"] = feats
+
+        ctx.model, ctx.plan, ctx.P_names = model, plan, model._encoder_param_names
+        ctx.dims = (B, T, d, S, F, M, nv, na)
+        ctx.drop = (p_feat, p_seq, p_enc, seed)
+        ctx.emb_saved, ctx.layer_saved, ctx.head_saved, ctx.reg_saved = emb_saved, layer_saved, head_saved, reg_saved
+        ctx.xs_t, ctx.lparams = xs_t, lparams
+        ctx.in_shapes = (tuple(visual.shape), tuple(audio.shape))
+        ctx.save_for_backward(*params)
+        result = tuple(outs.get(k) for k in OUT_SLOTS)
+        ctx.mark_non_differentiable(*[])
+        return result
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        model, plan = ctx.model, ctx.plan
+        rt, cfg = model.rt, model.cfg
+        params = ctx.saved_tensors
+        names = ctx.P_names
+        P = dict(zip(names, params))
+        B, T, d, S, F, M, nv, na = ctx.dims
+        p_feat, p_seq, p_enc, seed = ctx.drop
+        E, FF, H, Lyr, nf = cfg.E, cfg.FF, cfg.nhead, cfg.num_layers, cfg.num_feats
+        dev = params[0].device
+        st = _stream()
+        g = dict(zip(OUT_SLOTS, gouts))
+        fe = "feature_encoding."
+
+        # gradient buckets: one flat fp32 buffer per bucket, parameters are views into it
+        grads = model._alloc_grad_buckets(names, params, dev)
+        G = grads.views
+
+        dx = torch.zeros((M, E), dtype=torch.float32, device=dev)
+        if g["feats"] is not None:
+            dx.view(B, S, E)[:, :F] += g["feats"]  # tiny add of an incoming cotangent (plumbing)
+        xL_t = ctx.xs_t[Lyr]
+
+        # ---- heads
+        for slot, pname, s0, n, rows in ctx.head_saved:
+            go = g[slot]
+            if go is None or n == 0:
+                continue
+            w = P["cls_head." + pname + ".weight"]
+            Cn = w.shape[0]
+            go = _f32c(go)
+            gT = torch.empty((B * n, _ru(Cn)), dtype=rt.op_dtype, device=dev)
+            call("timhip_cast_rows", rt.prec, ptr(go), B * n, Cn, Cn, ptr(gT), gT.shape[1], 0.0, 0, 0, st)
+            rt.wgrad(gT, Cn, rows, E, B * n, G["cls_head." + pname + ".weight"], G["cls_head." + pname + ".bias"])
+            d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
+            rt.gemm(L.EPI_ADD_F32, gT, rt.weight(w, True), B * n, E, Cn, d_rows, E)
+            call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
+        for slot, pname, s0, n, rows, h1, h2, y in ctx.reg_saved:
+            go = g[slot]
+            if go is None or n == 0:
+                continue
+            pre = "reg_head." + pname + "."
+            hid = E // 2
+            # sigmoid backward on the [B*n, 2] outputs (2 columns: not worth a kernel of its own)
+            gz = _f32c(go) * y * (1.0 - y)
+            gzT = torch.empty((B * n, 64), dtype=rt.op_dtype, device=dev)
+            call("timhip_cast_rows", rt.prec, ptr(gz), B * n, 2, 2, ptr(gzT), 64, 0.0, 0, 0, st)
+            rt.wgrad(gzT, 2, h2, hid, B * n, G[pre + "4.weight"], G[pre + "4.bias"])
+            dh2 = torch.zeros_like(h2)
+            rt.gemm(L.EPI_DRELU_T, gzT, rt.weight(P[pre + "4.weight"], True), B * n, hid, 2, dh2, dh2.shape[1],
+                    aux=h2, ldaux=h2.shape[1])
+            rt.wgrad(dh2, hid, h1, hid, B * n, G[pre + "2.weight"], G[pre + "2.bias"])
+            dh1 = torch.zeros_like(h1)
+            rt.gemm(L.EPI_DRELU_T, dh2, rt.weight(P[pre + "2.weight"], True), B * n, hid, hid, dh1, dh1.shape[1],
+                    aux=h1, ldaux=h1.shape[1])
+            rt.wgrad(dh1, hid, rows, E, B * n, G[pre + "0.weight"], G[pre + "0.bias"])
+            d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
+            rt.gemm(L.EPI_ADD_F32, dh1, rt.weight(P[pre + "0.weight"], True), B * n, E, hid, d_rows, E)
+            call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
+        grads.done("heads")
+
+        # ---- layers, last to first; each layer's bucket is handed to the hook as soon as it is complete
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, 0)
+        ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
+        ws = model._workspace(ws_bytes, dev)
+        dx2 = torch.empty_like(dx)
+        stack = model._stack_prefix
+        for l in reversed(range(Lyr)):
+            pre = "%s.layers.%d." % (stack, l)
+            lg = L.TimLayerGrads(*[ptr(G[pre + n]) for n in model._LAYER_GRAD_NAMES])
+            desc.layer = l
+            call("timhip_layer_bwd", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.xs_t[l]),
+                 ptr(ctx.layer_saved[l]), ptr(dx), ptr(dx2), C.byref(lg), ptr(ws), ws_bytes, st)
+            dx, dx2 = dx2, dx
+            ctx.layer_saved[l] = None
+            grads.done("layer%d" % l)
+
+        # ---- sequence assembly backward
+        ncls, nmod = len(plan.cls_names), len(plan.mod_names)
+        d_e = [None, None]
+        for name, slot, *_ in ctx.emb_saved:
+            d_e[slot] = torch.empty((B * nf, d), dtype=torch.float32, device=dev)
+        d_cls = torch.zeros((max(ncls, 1), d), dtype=torch.float32, device=dev)
+        d_mod = torch.zeros((max(nmod, 1), E), dtype=torch.float32, device=dev)
+        d_te = torch.zeros((B, T, d), dtype=torch.float32, device=dev)
+        call("timhip_assemble_bwd", ptr(plan.table(dev)), B, S, d, ptr(dx), nf, T, p_seq, seed, L.SITE_SEQ,
+             ptr(d_e[0]), ptr(d_e[1]), ptr(d_cls), ptr(d_te), ptr(d_mod), st)
+        for i, n in enumerate(plan.cls_names):
+            G[fe + n].copy_(d_cls[i].view_as(G[fe + n]))
+        for i, n in enumerate(plan.mod_names):
+            G[fe + n].copy_(d_mod[i].view_as(G[fe + n]))
+
+        # ---- embedders backward
+        d_inputs = {"visual": None, "audio": None}
+        need_in = {"visual": ctx.needs_input_grad[3], "audio": ctx.needs_input_grad[4]}
+        for name, slot, xT, u, stats, Cin, site in ctx.emb_saved:
+            R = B * nf
+            w = P[fe + name + "_embedder.1.weight"]
+            duT = torch.zeros((R, _ru(d)), dtype=rt.op_dtype, device=dev)
+            rt.ln_bwd(d_e[slot], u, stats, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), dyt=duT,
+                      dgamma=G[fe + name + "_embedder.3.weight"], dbeta=G[fe + name + "_embedder.3.bias"])
+            rt.wgrad(duT, d, xT, Cin, R, G[fe + name + "_embedder.1.weight"], G[fe + name + "_embedder.1.bias"])
+            if need_in[name]:
+                gx = torch.empty((R, Cin), dtype=torch.float32, device=dev)
+                rt.gemm(L.EPI_ADD_F32, duT, rt.weight(w, True), R, Cin, d, gx, Cin)
+                dxin = torch.empty((R, Cin), dtype=torch.float32, device=dev)
+                call("timhip_dropout_rows_bwd", ptr(gx), R, Cin, Cin, ptr(dxin), Cin, p_feat, seed, site, st)
+                d_inputs[name] = dxin.view(B, nf, Cin)
+        grads.done("front")
+        if rt.finish_hook is not None:
+            rt.finish_hook()
+        out = [None, None, None, d_inputs["visual"], d_inputs["audio"], d_te if ctx.needs_input_grad[5] else None]
+        out += [G[n] if ctx.needs_input_grad[6 + i] else None for i, n in enumerate(names)]
+        return tuple(out)

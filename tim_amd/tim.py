@@ -1,0 +1,300 @@
+"""`TIM`: drop-in for the reference's `time_interval_machine.models.tim.TIM`
+(recognition/time_interval_machine/models/tim.py:17-191 and the detection variant
+detection/time_interval_machine/models/tim.py:17-430).
+
+Same constructor arguments, same `forward(inputs, forward_type, ...)` dispatch, same
+parameter names and shapes (state_dict round-trips with reference checkpoints), same
+output tuple.  The arithmetic of `"time_mlp"` and `"encoder"` runs in the HIP library
+(`tim_amd.functional`); the torch.nn modules below are parameter containers only and
+their own `forward` is never called on that path.
+"""
+import copy
+import math
+
+import torch
+from torch import nn
+from torch.nn.init import normal_
+
+from . import _lib as L
+from .config import TimConfig
+from .functional import EncoderFn, EncoderPlan, Runtime, TimeMlpFn, OUT_SLOTS
+
+
+# ---- parameter containers, registered in the reference's order so that state_dict() key order matches ----
+class _FeatureEncodingParams(nn.Module):
+    """encodings.py:7-39, 77-100, 123-179 (rec) / 7-33, 55-81, 102-150 (det)."""
+
+    def __init__(self, cfg: TimConfig):
+        super().__init__()
+        d = cfg.d_model
+        det = cfg.variant == "detection"
+
+        def embedder(cin):
+            return nn.Sequential(nn.Dropout(p=cfg.feat_drop), nn.Linear(cin, d), nn.GELU(), nn.LayerNorm(d))
+
+        def cls():
+            p = nn.Parameter(torch.empty((1, 1, d)))
+            normal_(p, std=0.01)
+            return p
+
+        if cfg.input_modality == "audio_visual":
+            self.visual_embedder = embedder(cfg.visual_input_dim)
+            self.audio_embedder = embedder(cfg.audio_input_dim)
+            self.visual_modality_encoding = nn.Parameter(torch.empty((1, 1, 2 * d)))
+            self.audio_modality_encoding = nn.Parameter(torch.empty((1, 1, 2 * d)))
+            normal_(self.visual_modality_encoding, std=0.01)
+            normal_(self.audio_modality_encoding, std=0.01)
+            if "visual" in cfg.data_modality:
+                self.visual_action_cls = cls()
+                if cfg.include_verb_noun and not det:
+                    self.visual_verb_cls = cls()
+                    self.visual_noun_cls = cls()
+            if "audio" in cfg.data_modality:
+                self.audio_action_cls = cls()
+        elif cfg.input_modality == "visual":
+            self.visual_embedder = embedder(cfg.visual_input_dim)
+            if det:
+                self.visual_action_cls = cls()
+            else:
+                self.action_cls = cls()
+                if cfg.include_verb_noun:
+                    self.verb_cls = cls()
+                    self.noun_cls = cls()
+        else:
+            self.audio_embedder = embedder(cfg.audio_input_dim)
+            if det:
+                self.audio_action_cls = cls()
+            else:
+                self.action_cls = cls()
+        self.dropout = nn.Dropout(p=cfg.seq_drop)
+
+
+class _ClsHeadParams(nn.Module):
+    """head.py:4-15,40-51,71-74 (rec) / 7-25,48-63,81-87 (det, with the focal prior bias)."""
+
+    def __init__(self, cfg: TimConfig):
+        super().__init__()
+        E = cfg.E
+        det = cfg.variant == "detection"
+        nc = cfg.num_class
+        bias_value = -(math.log((1 - 0.01) / 0.01))
+        made = []
+
+        def fc(name, n):
+            setattr(self, name, nn.Linear(E, n))
+            made.append(name)
+
+        if cfg.data_modality == "audio_visual":
+            vn = isinstance(nc, list) if det else isinstance(nc[0], list)
+            if vn:
+                fc("fc_visual_verb", nc[0][0]); fc("fc_visual_noun", nc[0][1]); fc("fc_visual_action", nc[0][2])
+            else:
+                fc("fc_visual_action", nc[0])
+            fc("fc_audio_action", nc[1])
+        elif cfg.data_modality == "visual":
+            v = nc[0]
+            if isinstance(v, list):
+                fc("fc_visual_verb", v[0]); fc("fc_visual_noun", v[1]); fc("fc_visual_action", v[2])
+            else:
+                fc("fc_visual_action", v)
+        else:
+            fc("fc_audio_action", nc[1])
+        if det:
+            for n in made:
+                nn.init.constant_(getattr(self, n).bias, bias_value)
+
+
+class _RegHeadParams(nn.Module):
+    """det head.py:95-163."""
+
+    def __init__(self, cfg: TimConfig):
+        super().__init__()
+        E = cfg.E
+
+        def mlp():
+            return nn.Sequential(nn.Linear(E, E // 2), nn.ReLU(), nn.Linear(E // 2, E // 2), nn.ReLU(),
+                                 nn.Linear(E // 2, 2), nn.Sigmoid())
+
+        if cfg.data_modality in ("audio_visual", "visual"):
+            self.fc_visual_action = mlp()
+        if cfg.data_modality in ("audio_visual", "audio"):
+            self.fc_audio_action = mlp()
+
+
+class _EncoderLayerParams(nn.Module):
+    """transformers.py:71-87."""
+
+    def __init__(self, E, H, FF, p):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(E, H, dropout=p)
+        self.dropout1 = nn.Dropout(p)
+        self.norm1 = nn.LayerNorm(E)
+        self.linear1 = nn.Linear(E, FF)
+        self.dropout = nn.Dropout(p)
+        self.linear2 = nn.Linear(FF, E)
+        self.dropout2 = nn.Dropout(p)
+        self.norm2 = nn.LayerNorm(E)
+
+
+class _EncoderStackParams(nn.Module):
+    """transformers.py:27-30: `_get_clones` deep-copies one layer, so a freshly built model
+    starts with identical layers, exactly as the reference does."""
+
+    def __init__(self, layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+
+class _GradBuckets:
+    def __init__(self, rt, names, params, dev, bucket_of):
+        self.rt = rt
+        self.views = {}
+        self.flat = {}
+        sizes = {}
+        for n, p in zip(names, params):
+            b = bucket_of(n)
+            sizes[b] = sizes.get(b, 0) + (p.numel() + 3) // 4 * 4
+        for b, sz in sizes.items():
+            self.flat[b] = torch.zeros(sz, dtype=torch.float32, device=dev)
+        off = {b: 0 for b in sizes}
+        for n, p in zip(names, params):
+            b = bucket_of(n)
+            self.views[n] = self.flat[b][off[b]:off[b] + p.numel()].view(p.shape)
+            off[b] += (p.numel() + 3) // 4 * 4
+
+    def done(self, bucket):
+        if self.rt.bucket_hook is not None and bucket in self.flat:
+            self.rt.bucket_hook(bucket, self.flat[bucket])
+
+
+class TIM(nn.Module):
+    _LAYER_GRAD_NAMES = ["self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                         "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
+                         "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"]
+
+    def __init__(self,
+                 num_class,
+                 visual_input_dim=1024,
+                 audio_input_dim=2304,
+                 feat_drop=0.5,
+                 seq_drop=0.5,
+                 d_model=512,
+                 feedforward_scale=4,
+                 nhead=8,
+                 num_layers=6,
+                 enc_dropout=0.1,
+                 input_modality="audio_visual",
+                 data_modality="audio_visual",
+                 num_feats=50,
+                 include_verb_noun=True,
+                 pool_features=False,
+                 precision="bf16",
+                 _variant="recognition"):
+        super().__init__()
+        if pool_features:
+            # AVGA pooling (pool.py:6-43) is an AVE-only pre-step outside the hot path
+            raise NotImplementedError("pool_features=True (AVGA, AVE dataset only) is outside the MI355X hot path")
+        if d_model % 32 != 0:
+            raise ValueError("d_model must be a multiple of 32 for the gfx950 kernels")
+        self.cfg = TimConfig(num_class=num_class, visual_input_dim=visual_input_dim, audio_input_dim=audio_input_dim,
+                             feat_drop=feat_drop, seq_drop=seq_drop, d_model=d_model,
+                             feedforward_scale=feedforward_scale, nhead=nhead, num_layers=num_layers,
+                             enc_dropout=enc_dropout, input_modality=input_modality, data_modality=data_modality,
+                             num_feats=num_feats, include_verb_noun=include_verb_noun, variant=_variant)
+        cfg = self.cfg
+        # attributes the reference exposes (tim.py:37-53)
+        self.input_modality, self.data_modality = input_modality, data_modality
+        self.visual_input_dim, self.audio_input_dim = visual_input_dim, audio_input_dim
+        self.feat_drop, self.seq_drop = feat_drop, seq_drop
+        self.d_model, self.dim_feedforward = d_model, d_model * feedforward_scale
+        self.nhead, self.num_layers, self.enc_dropout = nhead, num_layers, enc_dropout
+        self.num_feats = cfg.F  # the reference doubles num_feats for audio_visual (tim.py:88)
+        self.num_class, self.include_verb_noun, self.pool_features = num_class, include_verb_noun, pool_features
+
+        d, E = d_model, cfg.E
+        self.time_mlp = nn.Sequential(nn.Linear(2, d), nn.ReLU(), nn.Linear(d, d), nn.ReLU(), nn.Linear(d, d),
+                                      nn.ReLU(), nn.LayerNorm(d))
+        self.feature_encoding = _FeatureEncodingParams(cfg)
+        self.cls_head = _ClsHeadParams(cfg)
+        if _variant == "detection":
+            self.reg_head = _RegHeadParams(cfg)
+        stack = _EncoderStackParams(_EncoderLayerParams(E, nhead, cfg.FF, enc_dropout), num_layers)
+        if _variant == "detection":
+            self.backbone = stack
+        else:
+            self.transformer_encoder = stack
+        self._stack_prefix = "backbone" if _variant == "detection" else "transformer_encoder"
+        self.drloc_mlp = nn.Sequential(nn.Linear(4 * d, d), nn.ReLU(), nn.Linear(d, d), nn.ReLU(), nn.Linear(d, 1))
+        self.pool = None
+
+        self.rt = Runtime(precision)
+        self._plans = {}
+        self._ws = {}
+        self._encoder_param_names = [n for n, _ in self.named_parameters()
+                                     if not (n.startswith("time_mlp.") or n.startswith("drloc_mlp."))]
+
+    # ---- helpers used by tim_amd.functional --------------------------------------------------------
+    def _encoder_param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[n] for n in self._encoder_param_names]
+
+    def _plan(self, T, nv, na):
+        key = (T, nv, na)
+        p = self._plans.get(key)
+        if p is None:
+            p = EncoderPlan(self.cfg, T, nv, na)
+            self._plans[key] = p
+        return p
+
+    def _workspace(self, nbytes, dev):
+        w = self._ws.get(dev)
+        if w is None or w.numel() < nbytes:
+            w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws[dev] = w
+        return w
+
+    @staticmethod
+    def _layer_params(rt, P, pre):
+        from .functional import _f32c
+        keep = [rt.weight(P[pre + "self_attn.in_proj_weight"]), rt.weight(P[pre + "self_attn.in_proj_weight"], True),
+                rt.weight(P[pre + "self_attn.out_proj.weight"]), rt.weight(P[pre + "self_attn.out_proj.weight"], True),
+                rt.weight(P[pre + "linear1.weight"]), rt.weight(P[pre + "linear1.weight"], True),
+                rt.weight(P[pre + "linear2.weight"]), rt.weight(P[pre + "linear2.weight"], True)]
+        keep += [_f32c(P[pre + n]) for n in ("self_attn.in_proj_bias", "self_attn.out_proj.bias", "linear1.bias",
+                                             "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight",
+                                             "norm2.bias")]
+        return L.TimLayerParams(*[t.data_ptr() for t in keep]), keep
+
+    def _bucket_of(self, name):
+        pre = self._stack_prefix + ".layers."
+        if name.startswith(pre):
+            return "layer" + name[len(pre):].split(".")[0]
+        if name.startswith("feature_encoding."):
+            return "front"
+        return "heads"
+
+    def _alloc_grad_buckets(self, names, params, dev):
+        return _GradBuckets(self.rt, names, params, dev, self._bucket_of)
+
+    # ---- the reference's public interface ------------------------------------------------------------
+    def forward_encoder(self, inputs, time_encodings, num_v_queries, num_a_queries):
+        outs = EncoderFn.apply(self, int(num_v_queries or 0), int(num_a_queries or 0), inputs[0], inputs[1],
+                               time_encodings, *self._encoder_param_list())
+        o = dict(zip(OUT_SLOTS, outs))
+        return (o["verb"], o["noun"], o["action"], o["audio"]), o["feats"]
+
+    def _time_mlp(self, times):
+        m = self.time_mlp
+        return TimeMlpFn.apply(self.rt, times, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight,
+                               m[4].bias, m[6].weight, m[6].bias)
+
+    def forward(self, inputs, forward_type, time_encodings=None, num_v_queries=None, num_a_queries=None):
+        if forward_type == "time_mlp":
+            return self._time_mlp(inputs)
+        elif forward_type == "encoder":
+            return self.forward_encoder(inputs, time_encodings, num_v_queries, num_a_queries)
+        elif forward_type == "drloc_mlp":
+            # DRLoc auxiliary MLP (tim.py:129-135,190-191): adjacent to the hot path,
+            # stays stock PyTorch like the losses that call it.
+            return self.drloc_mlp(inputs).squeeze(2)
