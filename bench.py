@@ -77,8 +77,8 @@ def gemm_roofline(model, cfg, B, nv, na, precision, reps=20):
         ("ffn1 fwd", M, FF, E, L.EPI_GELU_DROP_T2, 1), ("ffn2 fwd", M, E, FF, L.EPI_DROP_RES_F32, 1),
         ("ffn2 dgrad", M, FF, E, L.EPI_DGELU_T, 1), ("ffn1 dgrad", M, E, FF, L.EPI_ADD_F32, 1),
         ("out_proj dgrad", M, E, E, L.EPI_STORE_T, 1), ("in_proj dgrad", M, E, 3 * E, L.EPI_ADD_F32, 1),
-        ("in_proj wgrad", 3 * E, E, Mp, L.EPI_ATOMIC_F32, 1), ("out_proj wgrad", E, E, Mp, L.EPI_ATOMIC_F32, 1),
-        ("ffn1 wgrad", FF, E, Mp, L.EPI_ATOMIC_F32, 1), ("ffn2 wgrad", E, FF, Mp, L.EPI_ATOMIC_F32, 1),
+        ("in_proj wgrad", 3 * E, E, Mp, "slab", 1), ("out_proj wgrad", E, E, Mp, "slab", 1),
+        ("ffn1 wgrad", FF, E, Mp, "slab", 1), ("ffn2 wgrad", E, FF, Mp, "slab", 1),
     ]
     g = torch.Generator().manual_seed(3)
     out = []
@@ -91,11 +91,15 @@ def gemm_roofline(model, cfg, B, nv, na, precision, reps=20):
         res = torch.zeros((m_, n_), dtype=torch.float32, device=dev)
         bias = torch.zeros(n_, device=dev)
         sk = 1
-        if epi == L.EPI_ATOMIC_F32:
+        if epi == "slab":  # weight gradients: split-K into fp32 slabs exactly as timhip_wgrad launches it
             tiles = ((m_ + 127) // 128) * ((n_ + 127) // 128)
-            sk = max(1, min((768 + tiles - 1) // tiles, k_ // 256, 32))
-        kw = dict(out1=o1, ld1=n_, bias=None if epi in (L.EPI_ATOMIC_F32, L.EPI_ADD_F32, L.EPI_DGELU_T) else bias,
-                  res=res, ldres=n_, aux=o1, ldaux=n_, p_drop=cfg.enc_dropout, seed=7, site=5, splitk=sk)
+            sk = max(1, min((512 + tiles - 1) // tiles, k_ // 256, 8))
+            epi = L.EPI_STORE_F32
+            o0 = torch.zeros((sk * m_, n_), dtype=torch.float32, device=dev)
+            kw = dict(splitk=sk)
+        else:
+            kw = dict(out1=o1, ld1=n_, bias=None if epi in (L.EPI_ADD_F32, L.EPI_DGELU_T) else bias,
+                      res=res, ldres=n_, aux=o1, ldaux=n_, p_drop=cfg.enc_dropout, seed=7, site=5, splitk=sk)
         for _ in range(3):
             rt.gemm(epi, A, Bm, m_, n_, k_, o0, n_, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

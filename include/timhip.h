@@ -170,10 +170,11 @@ int timhip_attention_bwd(const TimDesc* d, const void* qkv, const void* o, const
 size_t timhip_attention_bwd_workspace_bytes(const TimDesc* d);
 
 /* dW[Nout,Kout] += dY[M,Nout]^T X[M,Kout] and (db != NULL) db[Nout] += colsum(dY): weight/bias
- * gradients of one nn.Linear.  tA / tB: scratch for the transposed operand copies,
- * >= Nout*round_up(M,64) and Kout*round_up(M,64) elements of T. */
+ * gradients of one nn.Linear.  workspace (timhip_wgrad_workspace_bytes) holds the transposed
+ * operand copies and the split-K fp32 partial slabs. */
+size_t timhip_wgrad_workspace_bytes(int precision, int Nout, int Kout, int M);
 int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout,
-                 int M, float* dW, float* db, void* tA, void* tB, void* stream);
+                 int M, float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
 /* dx[r,c] = g[r,c] * keep-mask/(1-p): backward of the feature dropout applied by timhip_cast_rows */
 int timhip_dropout_rows_bwd(const float* g, int rows, int cols, int ldg, float* dx, int ldx,

@@ -130,9 +130,11 @@ def feature_encoding(sd, cfg, visual, audio, te, nv, na, masks=None, rd=None):
 # (transformers.py:92-111 over nn.MultiheadAttention; mask rec tim.py:161-166;
 #  exact structured form: SURVEY.md Appendix B)
 # ----------------------------------------------------------------------------
-def attention_structured(q, k, v, nfeat, drop_mask=None, p=0.0):
+def attention_structured(q, k, v, nfeat, drop_mask=None, p=0.0, rd=None):
     """q,k,v: [B,H,S,Dh] (q NOT yet scaled).  Token i may attend to the `nfeat`
-    feature tokens and to itself: M[i,j] blocked iff j >= nfeat and j != i."""
+    feature tokens and to itself: M[i,j] blocked iff j >= nfeat and j != i.
+    `rd`: round the probabilities to that dtype before P.V (what an MFMA kernel with
+    `rd` operands does); the self term stays in working precision."""
     Dh = q.shape[-1]
     q = q * (Dh ** -0.5)  # F.multi_head_attention_forward scales q
     kf, vf = k[:, :, :nfeat], v[:, :, :nfeat]
@@ -144,6 +146,9 @@ def attention_structured(q, k, v, nfeat, drop_mask=None, p=0.0):
         # drop_mask: [B,H,S,F+1]; column F is the self column (unused for feature rows)
         pf = _drop(pf, drop_mask[:, :, :nfeat, :nfeat], p)
         pq = _drop(pq, drop_mask[:, :, nfeat:], p)
+    if rd is not None:
+        pf = pf.to(rd).to(v.dtype)
+        pq = torch.cat([pq[..., :nfeat].to(rd).to(v.dtype), pq[..., nfeat:]], -1)
     of = pf @ vf
     oq = pq[..., :nfeat] @ vf + pq[..., nfeat:] * v[:, :, nfeat:]
     return torch.cat([of, oq], 2)
@@ -157,7 +162,7 @@ def encoder_layer(sd, prefix, x, nhead, nfeat, masks=None, p=0.0, rd=None, li=0)
     q, k, v = [t.reshape(B, S, nhead, Dh).transpose(1, 2) for t in qkv.split(E, -1)]
     if rd is not None:
         q, k, v = [t.to(rd).to(x.dtype) for t in (q, k, v)]
-    o = attention_structured(q, k, v, nfeat, m("attn"), p).transpose(1, 2).reshape(B, S, E)
+    o = attention_structured(q, k, v, nfeat, m("attn"), p, rd).transpose(1, 2).reshape(B, S, E)
     a = _lin(o, sd[prefix + "self_attn.out_proj.weight"], sd[prefix + "self_attn.out_proj.bias"], rd)
     x = _ln(x + _drop(a, m("drop1"), p), sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"])
     h = _drop(_gelu(_lin(x, sd[prefix + "linear1.weight"], sd[prefix + "linear1.bias"], rd)), m("ffn"), p)

@@ -52,7 +52,8 @@ _SIGS = {
     "timhip_layer_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_cast_weight": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, vp]),
     "timhip_gemm_nt": (C.c_int, [i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(TimEpi), i32, vp]),
-    "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "timhip_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
     "timhip_transpose": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, vp]),
     "timhip_colsum": (C.c_int, [i32, vp, i32, i32, i32, vp, vp]),
     "timhip_cast_rows": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, f32, u64, u32, vp]),

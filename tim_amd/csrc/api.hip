@@ -28,8 +28,32 @@ SavedLayout saved_layout(const TimDesc& d) {
   return L;
 }
 
+int splitk_for(int Mout, int Nout, int Kp) {
+  const int tiles = ((Mout + 127) / 128) * ((Nout + 127) / 128);
+  int sk = (512 + tiles - 1) / tiles;
+  const int maxk = Kp / 256 > 0 ? Kp / 256 : 1;
+  if (sk > maxk) sk = maxk;
+  if (sk > 8) sk = 8;
+  if (sk < 1) sk = 1;
+  return sk;
+}
+
+struct WgradWs { size_t tA, tB, slab, total; };
+WgradWs wgrad_ws(int prec, int Nout, int Kout, int M) {
+  const size_t Mp = round_up(M, 64), ts = opsize(prec);
+  WgradWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  w.tA = take((size_t)Nout * Mp * ts);
+  w.tB = take((size_t)Kout * Mp * ts);
+  const int sk = splitk_for(Nout, Kout, (int)Mp);
+  w.slab = take(sk > 1 ? (size_t)sk * Nout * Kout * 4 : 0);
+  w.total = off;
+  return w;
+}
+
 struct WsLayout {
-  size_t f32a, f32b, Ta, Tb, Tc, tA, tB, attn, total;
+  size_t f32a, f32b, Ta, Tb, Tc, tA, tB, attn, total, wg_bytes;
 };
 
 WsLayout ws_layout(const TimDesc& d) {
@@ -45,8 +69,17 @@ WsLayout ws_layout(const TimDesc& d) {
   L.Ta = take(M * wide * ts);
   L.Tb = take(M * d.E * ts);
   L.Tc = take(M * d.E * ts);
-  L.tA = take(wide * Mp * ts);
-  L.tB = take(mid * Mp * ts);
+  {
+    size_t wg = wgrad_ws(d.precision, 3 * d.E, d.E, (int)M).total;
+    size_t w2 = wgrad_ws(d.precision, d.E, d.FF, (int)M).total;
+    size_t w3 = wgrad_ws(d.precision, d.FF, d.E, (int)M).total;
+    if (w2 > wg) wg = w2;
+    if (w3 > wg) wg = w3;
+    L.tA = take(wg);
+    L.tB = L.tA;
+    L.wg_bytes = wg;
+  }
+  (void)Mp; (void)wide; (void)mid;
   L.attn = take(tim_attention_bwd_ws(d));
   L.total = off;
   return L;
@@ -67,27 +100,28 @@ TimEpi epi0() {
   return e;
 }
 
-int splitk_for(int Mout, int Nout, int Kp) {
-  const int tiles = ((Mout + 127) / 128) * ((Nout + 127) / 128);
-  int sk = (768 + tiles - 1) / tiles;
-  const int maxk = Kp / 256 > 0 ? Kp / 256 : 1;
-  if (sk > maxk) sk = maxk;
-  if (sk < 1) sk = 1;
-  if (sk > 32) sk = 32;
-  return sk;
-}
-
 // dW[Nout, Kout] += dY[M, Nout]^T X[M, Kout]   (+ db[Nout] += colsum dY)
+// Both operands are transposed into K(=M)-contiguous copies, the product runs split-K into fp32
+// slabs (plain coalesced stores, no atomics) and one reduce kernel adds the slabs into dW.
 int wgrad(int prec, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
-          void* tA, void* tB, hipStream_t s) {
+          void* ws, size_t ws_bytes, hipStream_t s) {
   const int Mp = round_up(M, 64);
+  const WgradWs W = wgrad_ws(prec, Nout, Kout, M);
+  if (ws_bytes < W.total) return TIMHIP_EWORKSPACE;
+  char* w = (char*)ws;
+  void* tA = w + W.tA; void* tB = w + W.tB; float* slab = (float*)(w + W.slab);
   int rc;
-  if (db && (rc = tim_colsum(prec, dY, M, Nout, ldy, db, s))) return rc;
-  if ((rc = tim_transpose(prec, dY, M, Nout, ldy, tA, Mp, s))) return rc;
-  if ((rc = tim_transpose(prec, X, M, Kout, ldx, tB, Mp, s))) return rc;
+  if ((rc = tim_transpose(prec, dY, M, Nout, ldy, tA, Mp, db, s))) return rc;
+  if ((rc = tim_transpose(prec, X, M, Kout, ldx, tB, Mp, nullptr, s))) return rc;
+  const int sk = splitk_for(Nout, Kout, Mp);
   TimEpi e = epi0();
-  e.out0 = dW; e.ld0 = Kout;
-  return tim_gemm_nt(prec, TIMHIP_EPI_ATOMIC_F32, tA, Mp, tB, Mp, Nout, Kout, Mp, e, splitk_for(Nout, Kout, Mp), s);
+  if (sk == 1 || (Kout % 4) != 0) {
+    e.out0 = dW; e.ld0 = Kout;
+    return tim_gemm_nt(prec, TIMHIP_EPI_ATOMIC_F32, tA, Mp, tB, Mp, Nout, Kout, Mp, e, sk, s);
+  }
+  e.out0 = slab; e.ld0 = Kout;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_F32, tA, Mp, tB, Mp, Nout, Kout, Mp, e, sk, s))) return rc;
+  return tim_slab_reduce(slab, (long long)Nout * Kout, sk, dW, s);
 }
 
 }  // namespace
@@ -117,10 +151,14 @@ int timhip_gemm_nt(int precision, int epi, const void* A, int lda, const void* B
   return tim_gemm_nt(precision, epi, A, lda, B, ldb, M, N, K, *e, splitk, (hipStream_t)stream);
 }
 
+size_t timhip_wgrad_workspace_bytes(int precision, int Nout, int Kout, int M) {
+  return wgrad_ws(precision, Nout, Kout, M).total;
+}
+
 int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M,
-                 float* dW, float* db, void* tA, void* tB, void* stream) {
-  if (!dY || !X || !dW || !tA || !tB) return TIMHIP_EINVAL;
-  return wgrad(precision, dY, ldy, Nout, X, ldx, Kout, M, dW, db, tA, tB, (hipStream_t)stream);
+                 float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dY || !X || !dW || !workspace) return TIMHIP_EINVAL;
+  return wgrad(precision, dY, ldy, Nout, X, ldx, Kout, M, dW, db, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_in, const void* x_in_T, float* x_out,
@@ -184,20 +222,20 @@ int timhip_layer_bwd(const TimDesc* dp, const TimLayerParams* w, const void* x_i
   const float* y2 = (const float*)(sv + L.y2); const float* st2 = (const float*)(sv + L.st2);
   char* ws = (char*)workspace;
   float* f32a = (float*)(ws + W.f32a); float* f32b = (float*)(ws + W.f32b);
-  void* Ta = ws + W.Ta; void* Tb = ws + W.Tb; void* Tc = ws + W.Tc; void* tA = ws + W.tA; void* tB = ws + W.tB;
+  void* Ta = ws + W.Ta; void* Tb = ws + W.Tb; void* Tc = ws + W.Tc; void* wg = ws + W.tA;
 
   // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
   if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, Tb, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b, s))) return rc;
   // linear2: dW2 += df^T h, db2 += colsum df
-  if ((rc = wgrad(prec, Tb, E, E, h, FF, FF, M, g->l2_w, g->l2_b, tA, tB, s))) return rc;
+  if ((rc = wgrad(prec, Tb, E, E, h, FF, FF, M, g->l2_w, g->l2_b, wg, W.wg_bytes, s))) return rc;
   // du = (df W2) * dropout-mask * gelu'(u)
   TimEpi e = epi0();
   e.out0 = Ta; e.ld0 = FF; e.aux = u; e.ldaux = FF;
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DGELU_T, Tb, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
   // linear1: dW1 += du^T x1, db1 += colsum du
-  if ((rc = wgrad(prec, Ta, FF, FF, x1t, E, E, M, g->l1_w, g->l1_b, tA, tB, s))) return rc;
+  if ((rc = wgrad(prec, Ta, FF, FF, x1t, E, E, M, g->l1_w, g->l1_b, wg, W.wg_bytes, s))) return rc;
   // dx1 = du W1 + dy2   (residual branch)
   e = epi0();
   e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E;
@@ -206,14 +244,14 @@ int timhip_layer_bwd(const TimDesc* dp, const TimLayerParams* w, const void* x_i
   if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, Tb, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b, s))) return rc;
   // out-projection: dWo += da^T o, dbo += colsum da ; do = da Wo
-  if ((rc = wgrad(prec, Tb, E, E, o, E, E, M, g->out_w, g->out_b, tA, tB, s))) return rc;
+  if ((rc = wgrad(prec, Tb, E, E, o, E, E, M, g->out_w, g->out_b, wg, W.wg_bytes, s))) return rc;
   e = epi0();
   e.out0 = Tc; e.ld0 = E;
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, Tb, E, w->out_wt, E, M, E, E, e, 1, s))) return rc;
   // attention backward -> dqkv
   if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, Ta, ws + W.attn, W.total - W.attn, s))) return rc;
   // in-projection: dWin += dqkv^T x_in, dbin += colsum dqkv ; dx_in = dqkv Win + dy1
-  if ((rc = wgrad(prec, Ta, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, tA, tB, s))) return rc;
+  if ((rc = wgrad(prec, Ta, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, wg, W.wg_bytes, s))) return rc;
   e = epi0();
   e.out0 = dx_in; e.ld0 = E; e.res = f32a; e.ldres = E;
   return tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, Ta, 3 * E, w->in_wt, 3 * E, M, E, 3 * E, e, 1, s);

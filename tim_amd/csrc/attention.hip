@@ -238,10 +238,18 @@ int check_desc(const TimDesc& d) {
 
 }  // namespace
 
+int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
+int tim_attention_bwd_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
+                           void* dqkv, hipStream_t s);
+
 int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse) return TIMHIP_EINVAL;
+  if (d.precision == TIMHIP_PREC_BF16 && !(d.reserved & 1)) {  // reserved bit 0: force the fp32-arithmetic kernels
+    rc = tim_attention_fwd_mfma(d, qkv, o, lse, s);
+    if (rc != TIMHIP_EUNSUPPORTED) return rc;
+  }
   const size_t lds = simple_lds(d, 1);
   if (lds > 160 * 1024) return TIMHIP_EUNSUPPORTED;
   AttnArgs a = make_args(d);
@@ -265,6 +273,10 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse || !d_o || !dqkv || !ws) return TIMHIP_EINVAL;
+  if (d.precision == TIMHIP_PREC_BF16 && !(d.reserved & 1)) {
+    rc = tim_attention_bwd_mfma(d, qkv, o, lse, d_o, dqkv, s);
+    if (rc != TIMHIP_EUNSUPPORTED) return rc;
+  }
   if (ws_bytes < tim_attention_bwd_ws(d)) return TIMHIP_EWORKSPACE;
   const size_t lds = simple_lds(d, 2);
   if (lds > 160 * 1024) return TIMHIP_EUNSUPPORTED;

@@ -1,0 +1,536 @@
+// MFMA (bf16) structured attention for the TIM encoder, forward and backward.
+//
+// Math: see attention.hip (token i attends to the F feature tokens + itself; reference
+// tim.py:161-166 mask over nn.MultiheadAttention, transformers.py:102).
+//
+// One workgroup (4 waves) per (window, head).  The F feature keys/values of the head
+// (F <= 192, padded to NJB*32) live in LDS for the whole kernel; query rows are processed
+// in blocks of 32 with the MFMA issued "swapped" (D = K_frag x Q_frag = S^T) so that a
+// LANE OWNS ONE QUERY ROW: the softmax reduction is over that lane's registers plus one
+// cross-half shuffle, the probabilities feed the P.V MFMA straight from registers (the MFMA
+// contraction order is a free permutation, so P's accumulator registers 8a..8a+7 ARE a valid
+// B operand), and V^T fragments come from LDS through ds_read_b64_tr_b16.
+//
+// LDS image of a [rows][DH] bf16 tile: row stride DH*2 bytes, 16-byte chunk index XOR g(row)
+// with g chosen so that BOTH access patterns are bank-conflict free:
+//   ds_read_b128 fragment reads (16 different rows, same chunk)   -> rows map to 16 distinct slots
+//   ds_read_b64_tr_b16 reads (4 rows x 64 B)                      -> 16 distinct slots
+#include "common.h"
+
+namespace {
+
+struct AttnArgsM {
+  int S, F, E, H, LP;
+  float scale;
+  uint32_t thr; float dscale; uint64_t seed; uint32_t site;
+};
+
+template <int DH> __device__ __forceinline__ int swz(int row);
+template <> __device__ __forceinline__ int swz<128>(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+template <> __device__ __forceinline__ int swz<64>(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+template <> __device__ __forceinline__ int swz<32>(int row) { return (row >> 2) & 3; }
+
+// byte offset of (row, 16-B chunk c) in a tile
+template <int DH> __device__ __forceinline__ int tile_off(int row, int c) {
+  return row * (DH * 2) + ((c ^ swz<DH>(row)) << 4);
+}
+
+typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+
+__device__ __forceinline__ bf16x4_t tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_ptr)(p));
+}
+
+__device__ __forceinline__ bf16x8_t cat8(bf16x4_t a, bf16x4_t b) {
+  bf16x8_t r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& v, int a) {
+  bf16x8_t r;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) r[u] = (bf16_t)v[8 * a + u];
+  return r;
+}
+
+__device__ __forceinline__ float dot8(bf16x8_t a, bf16x8_t b) {
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s = fmaf((float)a[u], (float)b[u], s);
+  return s;
+}
+
+// stage `nrows` rows (row r -> src + r*ld, DH bf16 each; rows >= nvalid are zero) into a tile
+template <int DH>
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, size_t ld, int nrows, int nvalid, int tid,
+                                           int nthreads) {
+  constexpr int NC = DH / 8;
+  for (int idx = tid; idx < nrows * NC; idx += nthreads) {
+    const int row = idx / NC, c = idx % NC;
+    bf16x8_t v;
+    if (row < nvalid) {
+      v = *reinterpret_cast<const bf16x8_t*>(src + (size_t)row * ld + c * 8);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (bf16_t)0.f;
+    }
+    *reinterpret_cast<bf16x8_t*>(tile + tile_off<DH>(row, c)) = v;
+  }
+}
+
+// V^T / K^T fragment for the PV-style MFMA: lane (i = lane & 31 -> dh 32*db + i, g = lane >> 5)
+// gets the 8 values tile[key(u)][dh], key(u) = kb + 8*(u>>2) + 4*g + (u&3)   (kb = 32*jb + 16*a)
+template <int DH>
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int kb, int db, int lane) {
+  const int gid = lane >> 4, p = lane & 15, g = gid >> 1;
+  const int row0 = kb + 4 * g + (p >> 2);
+  const int c = 4 * db + 2 * (gid & 1) + ((p & 3) >> 1);
+  const int sub = (p & 1) * 8;
+  bf16x4_t lo = tr_read(tile + tile_off<DH>(row0, c) + sub);
+  bf16x4_t hi = tr_read(tile + tile_off<DH>(row0 + 8, c) + sub);
+  return cat8(lo, hi);
+}
+
+__device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
+                                      float& k3) {
+  drop_mask4(a.seed, a.site, (rowbase + (uint64_t)key) >> 2, a.thr, a.dscale, k0, k1, k2, k3);
+}
+__device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int key) {
+  float k[4];
+  drop_mask4(a.seed, a.site, (rowbase + (uint64_t)key) >> 2, a.thr, a.dscale, k[0], k[1], k[2], k[3]);
+  const int c = (int)((rowbase + (uint64_t)key) & 3);
+  return c == 0 ? k[0] : (c == 1 ? k[1] : (c == 2 ? k[2] : k[3]));
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <int DH, int NJB>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                     float* __restrict__ lse, AttnArgsM a) {
+  constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + FP * DH * 2;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int S = a.S, F = a.F, E = a.E;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t ld = (size_t)3 * E;
+  const bf16_t* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
+  stage_tile<DH>(sK, base + E, ld, FP, F, tid, 256);
+  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, 256);
+  __syncthreads();
+
+  const int li = lane & 31, g = lane >> 5;
+  const int nrb = (S + 31) >> 5;
+  for (int rb = wave; rb < nrb; rb += 4) {
+    const int row = rb * 32 + li;
+    const bool valid = row < S;
+    const int rowc = valid ? row : S - 1;
+    const bool isq = rowc >= F;
+    const bf16_t* qp = base + (size_t)rowc * ld;
+    bf16x8_t qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 16 + g * 8);
+
+    // S^T = K Q^T : lane owns query row `row`, registers hold keys 32jb + (r&3) + 8(r>>2) + 4g
+    f32x16_t sc[NJB];
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[jb][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        sc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sc[jb], 0, 0, 0);
+      }
+    }
+    // self score of query tokens
+    float sself = -INFINITY;
+    if (isq) {
+      float t = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk)
+        t += dot8(qf[kk], *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8));
+      sself = t;
+    }
+    {
+      const float other = __shfl_xor(isq ? sself : 0.f, 32, 64);
+      if (isq) sself = (sself + other) * a.scale;
+    }
+    float mx = sself;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float s = key < F ? sc[jb][r] * a.scale : -INFINITY;
+        sc[jb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(sc[jb][r] - mx);
+        sc[jb][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float pself_un = isq ? __expf(sself - mx) : 0.f;
+    sum += pself_un;
+    const float inv = 1.f / sum;
+    if (valid && g == 0) lse[((size_t)b * a.H + h) * S + row] = mx + __logf(sum);
+    const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
+        if (a.thr != 0u) keep4(a, rowbase, jb * 32 + 8 * q + 4 * g, k0, k1, k2, k3);
+        sc[jb][4 * q] *= inv * k0; sc[jb][4 * q + 1] *= inv * k1;
+        sc[jb][4 * q + 2] *= inv * k2; sc[jb][4 * q + 3] *= inv * k3;
+      }
+    float pself = pself_un * inv;
+    if (isq && a.thr != 0u) pself *= keep1(a, rowbase, F);
+
+    // O^T = V^T P^T
+    f32x16_t oa[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oa[db][r] = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NJB; ++jb)
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const bf16x8_t pf = pack8(sc[jb], aa);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const bf16x8_t vf = tr_frag<DH>(sV, jb * 32 + 16 * aa, db, lane);
+          oa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oa[db], 0, 0, 0);
+        }
+      }
+    if (valid) {
+      bf16_t* op = o + ((size_t)b * S + row) * E + (size_t)h * DH;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dh = 32 * db + 8 * q + 4 * g;
+          float v0 = oa[db][4 * q], v1 = oa[db][4 * q + 1], v2 = oa[db][4 * q + 2], v3 = oa[db][4 * q + 3];
+          if (isq) {
+            float s0, s1, s2, s3;
+            load4<bf16_t>(qp + 2 * E + dh, s0, s1, s2, s3);
+            v0 = fmaf(pself, s0, v0); v1 = fmaf(pself, s1, v1); v2 = fmaf(pself, s2, v2); v3 = fmaf(pself, s3, v3);
+          }
+          store4<bf16_t>(op + dh, v0, v1, v2, v3);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward
+//   phase 1 (lane = query row): S^T, dP^T = V dO^T, dS -> dQ^T = K^T dS^T ; self terms of query tokens
+//   phase 2 (lane = key):       S = Q K^T, dP = dO V^T recomputed in the transposed orientation so
+//                               that dS / P~ land in registers as B operands of
+//                               dK^T = Q^T dS and dV^T = dO^T P~ (contraction over the 32 rows of a block).
+// ---------------------------------------------------------------------------
+template <int DH, int NJB>
+__global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                     const float* __restrict__ lse, const bf16_t* __restrict__ d_o,
+                                                     bf16_t* __restrict__ dqkv, AttnArgsM a) {
+  constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = sK + FP * DH * 2;
+  char* sQ = sV + FP * DH * 2;        // 32-row block of Q
+  char* sD = sQ + 32 * DH * 2;        // 32-row block of dO
+  float* sL = reinterpret_cast<float*>(sD + 32 * DH * 2);  // [32] lse, [32] delta
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int S = a.S, F = a.F, E = a.E;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t ld = (size_t)3 * E;
+  const bf16_t* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
+  bf16_t* dbase = dqkv + (size_t)b * S * ld + (size_t)h * DH;
+  const bf16_t* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
+  const bf16_t* obase = o + (size_t)b * S * E + (size_t)h * DH;
+  const float* lsebase = lse + ((size_t)b * a.H + h) * S;
+  stage_tile<DH>(sK, base + E, ld, FP, F, tid, 256);
+  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, 256);
+  __syncthreads();
+
+  const int li = lane & 31, g = lane >> 5;
+  const int nrb = (S + 31) >> 5;
+
+  // ---------------- phase 1 ----------------
+  for (int rb = wave; rb < nrb; rb += 4) {
+    const int row = rb * 32 + li;
+    const bool valid = row < S;
+    const int rowc = valid ? row : S - 1;
+    const bool isq = rowc >= F;
+    const bf16_t* qp = base + (size_t)rowc * ld;
+    const bf16_t* dop = dobase + (size_t)rowc * E;
+    const bf16_t* op = obase + (size_t)rowc * E;
+    bf16x8_t qf[NKK], df[NKK];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 16 + g * 8);
+      df[kk] = *reinterpret_cast<const bf16x8_t*>(dop + kk * 16 + g * 8);
+      delta += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(op + kk * 16 + g * 8));
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float l = lsebase[rowc];
+    const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
+
+    // self terms (scalar per row)
+    float ds_self = 0.f, pt_self = 0.f;
+    if (isq) {
+      float t = 0.f, u = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        t += dot8(qf[kk], *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8));
+        u += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(qp + 2 * E + kk * 16 + g * 8));
+      }
+      ds_self = t; pt_self = u;
+    }
+    {
+      const float t2 = __shfl_xor(ds_self, 32, 64), u2 = __shfl_xor(pt_self, 32, 64);
+      if (isq) {
+        const float t = (ds_self + t2) * a.scale, u = pt_self + u2;
+        const float p = __expf(t - l);
+        const float keep = a.thr != 0u ? keep1(a, rowbase, F) : 1.f;
+        ds_self = p * (u * keep - delta) * a.scale;
+        pt_self = p * keep;
+      }
+    }
+    // per key block: S^T, dP^T -> dS^T (registers) -> dQ^T += K^T dS^T
+    f32x16_t qa[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qa[db][r] = 0.f;
+#pragma unroll 1
+    for (int jb = 0; jb < NJB; ++jb) {
+      f32x16_t sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[kk], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float k[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.thr != 0u) keep4(a, rowbase, jb * 32 + 8 * q + 4 * g, k[0], k[1], k[2], k[3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = 4 * q + t;
+          const int key = jb * 32 + 8 * q + 4 * g + t;
+          const float p = key < F ? __expf(sc[r] * a.scale - l) : 0.f;
+          sc[r] = p * (dp[r] * k[t] - delta) * a.scale;
+        }
+      }
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const bf16x8_t sf = pack8(sc, aa);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const bf16x8_t kf = tr_frag<DH>(sK, jb * 32 + 16 * aa, db, lane);
+          qa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, qa[db], 0, 0, 0);
+        }
+      }
+    }
+    if (valid) {
+      bf16_t* dq = dbase + (size_t)row * ld;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dh = 32 * db + 8 * q + 4 * g;
+          float v0 = qa[db][4 * q], v1 = qa[db][4 * q + 1], v2 = qa[db][4 * q + 2], v3 = qa[db][4 * q + 3];
+          if (isq) {
+            float k0, k1, k2, k3, q0, q1, q2, q3, d0, d1, d2, d3;
+            load4<bf16_t>(qp + E + dh, k0, k1, k2, k3);
+            load4<bf16_t>(qp + dh, q0, q1, q2, q3);
+            load4<bf16_t>(dop + dh, d0, d1, d2, d3);
+            v0 = fmaf(ds_self, k0, v0); v1 = fmaf(ds_self, k1, v1); v2 = fmaf(ds_self, k2, v2); v3 = fmaf(ds_self, k3, v3);
+            // a query token's own key / value receive the self term only
+            store4<bf16_t>(dq + E + dh, ds_self * q0, ds_self * q1, ds_self * q2, ds_self * q3);
+            store4<bf16_t>(dq + 2 * E + dh, pt_self * d0, pt_self * d1, pt_self * d2, pt_self * d3);
+          }
+          store4<bf16_t>(dq + dh, v0, v1, v2, v3);
+        }
+    }
+  }
+
+  // ---------------- phase 2 ----------------
+  // wave w owns key blocks w, w+4; accumulators dK^T, dV^T [dh][key] over all row blocks
+  for (int jb0 = 0; jb0 < NJB; jb0 += 4) {
+    const int jb = jb0 + wave;
+    const bool active = jb < NJB;
+    f32x16_t ka[NDB], va[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ka[db][r] = 0.f; va[db][r] = 0.f; }
+    const int key = jb * 32 + li;
+    const int jbc = active ? jb : 0;
+    for (int rb = 0; rb < nrb; ++rb) {
+      __syncthreads();  // previous block's sQ/sD fully consumed
+      const int r0 = rb * 32;
+      const int nvalid = min(32, S - r0);
+      stage_tile<DH>(sQ, base + (size_t)r0 * ld, ld, 32, nvalid, tid, 256);
+      stage_tile<DH>(sD, dobase + (size_t)r0 * E, E, 32, nvalid, tid, 256);
+      if (tid < 32) {
+        const int rr = r0 + tid;
+        float lv = 0.f, dv = 0.f;
+        if (rr < S) {
+          lv = lsebase[rr];
+          // delta = dO . O
+          const bf16_t* dop = dobase + (size_t)rr * E;
+          const bf16_t* op = obase + (size_t)rr * E;
+          for (int c = 0; c < DH; c += 8)
+            dv += dot8(*reinterpret_cast<const bf16x8_t*>(dop + c), *reinterpret_cast<const bf16x8_t*>(op + c));
+        }
+        sL[tid] = lv; sL[32 + tid] = dv;
+      }
+      __syncthreads();
+      if (!active) continue;
+      // S = Q K^T, dP = dO V^T : lane owns key `key`, registers hold rows (r&3) + 8(r>>2) + 4g
+      f32x16_t sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(sQ + tile_off<DH>(li, kk * 2 + g));
+        const bf16x8_t df = *reinterpret_cast<const bf16x8_t*>(sD + tile_off<DH>(li, kk * 2 + g));
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jbc * 32 + li, kk * 2 + g));
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + tile_off<DH>(jbc * 32 + li, kk * 2 + g));
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf, dp, 0, 0, 0);
+      }
+      f32x16_t dsr, ptr_;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
+        const int rr = r0 + rl;
+        float keep = 1.f;
+        if (a.thr != 0u && rr < S && key < F) {
+          const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rr) * (uint64_t)a.LP;
+          keep = keep1(a, rowbase, key);
+        }
+        const float p = (rr < S && key < F) ? __expf(sc[r] * a.scale - sL[rl]) : 0.f;
+        dsr[r] = p * (dp[r] * keep - sL[32 + rl]) * a.scale;
+        ptr_[r] = p * keep;
+      }
+      // dK^T += Q^T dS ; dV^T += dO^T P~   (contraction over the 32 rows: two K=16 MFMAs)
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const bf16x8_t sf = pack8(dsr, aa), pf = pack8(ptr_, aa);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const bf16x8_t qt = tr_frag<DH>(sQ, 16 * aa, db, lane);
+          const bf16x8_t dt = tr_frag<DH>(sD, 16 * aa, db, lane);
+          ka[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, ka[db], 0, 0, 0);
+          va[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, va[db], 0, 0, 0);
+        }
+      }
+    }
+    if (active && key < F) {
+      bf16_t* dk = dbase + (size_t)key * ld + E;
+      bf16_t* dv = dbase + (size_t)key * ld + 2 * E;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dh = 32 * db + 8 * q + 4 * g;
+          store4<bf16_t>(dk + dh, ka[db][4 * q], ka[db][4 * q + 1], ka[db][4 * q + 2], ka[db][4 * q + 3]);
+          store4<bf16_t>(dv + dh, va[db][4 * q], va[db][4 * q + 1], va[db][4 * q + 2], va[db][4 * q + 3]);
+        }
+    }
+  }
+}
+
+AttnArgsM make_args(const TimDesc& d) {
+  AttnArgsM a;
+  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 4);
+  a.scale = 1.f / sqrtf((float)(d.E / d.H));
+  a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
+  a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
+  a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
+  return a;
+}
+
+template <int DH, int NJB>
+int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
+  const size_t lds = (size_t)2 * NJB * 32 * DH * 2;
+  (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_fwd_mfma<DH, NJB>), dim3(d.B * d.H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse,
+                     make_args(d));
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
+template <int DH, int NJB>
+int launch_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
+               hipStream_t s) {
+  const size_t lds = (size_t)2 * NJB * 32 * DH * 2 + (size_t)2 * 32 * DH * 2 + 64 * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_mfma<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_mfma<DH, NJB>), dim3(d.B * d.H), dim3(256), lds, s, (const bf16_t*)qkv,
+                     (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dqkv, make_args(d));
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
+
+}  // namespace
+
+// returns TIMHIP_EUNSUPPORTED when the (head_dim, F) combination has no MFMA instantiation;
+// the caller then uses the fp32-arithmetic kernels of attention.hip
+#define ATTN_DISPATCH(FN, ...)                                                   \
+  do {                                                                           \
+    const int DHv = d.E / d.H, NJBv = (d.F + 31) / 32;                           \
+    if (DHv == 128) {                                                            \
+      switch (NJBv) {                                                            \
+        case 1: return FN<128, 1>(__VA_ARGS__);                                  \
+        case 2: return FN<128, 2>(__VA_ARGS__);                                  \
+        case 3: return FN<128, 3>(__VA_ARGS__);                                  \
+        case 4: return FN<128, 4>(__VA_ARGS__);                                  \
+        case 5: return FN<128, 5>(__VA_ARGS__);                                  \
+        default: return TIMHIP_EUNSUPPORTED;                                     \
+      }                                                                          \
+    } else if (DHv == 64) {                                                      \
+      switch (NJBv) {                                                            \
+        case 1: return FN<64, 1>(__VA_ARGS__);                                   \
+        case 2: return FN<64, 2>(__VA_ARGS__);                                   \
+        case 4: return FN<64, 4>(__VA_ARGS__);                                   \
+        default: return TIMHIP_EUNSUPPORTED;                                     \
+      }                                                                          \
+    } else if (DHv == 32) {                                                      \
+      switch (NJBv) {                                                            \
+        case 1: return FN<32, 1>(__VA_ARGS__);                                   \
+        case 2: return FN<32, 2>(__VA_ARGS__);                                   \
+        default: return TIMHIP_EUNSUPPORTED;                                     \
+      }                                                                          \
+    }                                                                            \
+    return TIMHIP_EUNSUPPORTED;                                                  \
+  } while (0)
+
+int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
+  if (d.precision != TIMHIP_PREC_BF16 || (d.E % 8) != 0) return TIMHIP_EUNSUPPORTED;
+  ATTN_DISPATCH(launch_fwd, d, qkv, o, lse, s);
+}
+
+int tim_attention_bwd_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
+                           void* dqkv, hipStream_t s) {
+  if (d.precision != TIMHIP_PREC_BF16 || (d.E % 8) != 0) return TIMHIP_EUNSUPPORTED;
+  ATTN_DISPATCH(launch_bwd, d, qkv, o, lse, d_o, dqkv, s);
+}

@@ -141,7 +141,8 @@ __device__ __forceinline__ float wave_max(float v) {
 int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
                 int K, const TimEpi& e, int splitk, hipStream_t s);
 int tim_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,
-                  hipStream_t s);
+                  float* colsum, hipStream_t s);
+int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStream_t s);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,

@@ -29,6 +29,7 @@ struct EpiDev {
   int ld0, ld1, ldres, ldaux;
   uint32_t thr; float scale; uint32_t site; uint64_t seed;
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
+  long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)
 };
 
 template <int EPI, typename T>
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   const int nk_total = K / BK;
   const int kt0 = blockIdx.z * ksteps_per_split;
   const int kt1 = min(nk_total, kt0 + ksteps_per_split);
-  if (kt0 >= kt1) return;
+  if (EPI == TIMHIP_EPI_STORE_F32) e.out0 = (float*)e.out0 + (long long)blockIdx.z * e.slab_stride;
 
   // ---- staging: each wave-instruction moves 8 rows x 128 B ----
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
     b_swz[i] = (row >> 1) & 7;
   }
 
-  stage(kt0, 0);
+  if (kt0 < kt1) stage(kt0, 0);
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) & 1;
     __syncthreads();  // stage(kt) landed (vmcnt(0)) and every wave is done reading buf^1
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   const int nk_total = K / FBK;
   const int kt0 = blockIdx.z * ksteps_per_split;
   const int kt1 = min(nk_total, kt0 + ksteps_per_split);
-  if (kt0 >= kt1) return;
+  if (EPI == TIMHIP_EPI_STORE_F32) e.out0 = (float*)e.out0 + (long long)blockIdx.z * e.slab_stride;
 
   f32x16_t acc[2][2];
 #pragma unroll
@@ -381,13 +382,14 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   if (lda % 64 || ldb % 64 || lda < Kp || ldb < Kp) return TIMHIP_EALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return TIMHIP_EALIGN;
   if (splitk < 1) splitk = 1;
-  if (splitk > 1 && epi != TIMHIP_EPI_ATOMIC_F32) return TIMHIP_EINVAL;
+  if (splitk > 1 && epi != TIMHIP_EPI_ATOMIC_F32 && epi != TIMHIP_EPI_STORE_F32) return TIMHIP_EINVAL;
   EpiDev e;
   e.out0 = te.out0; e.out1 = te.out1; e.bias = te.bias; e.res = te.res; e.aux = te.aux;
   e.ld0 = te.ld0; e.ld1 = te.ld1; e.ldres = te.ldres; e.ldaux = te.ldaux;
   e.thr = te.p_drop > 0.f ? drop_threshold(te.p_drop) : 0u;
   e.scale = te.p_drop > 0.f ? 1.f / (1.f - te.p_drop) : 1.f;
   e.site = te.site; e.seed = te.seed;
+  e.slab_stride = splitk > 1 ? (long long)M * te.ld0 : 0;
   bool vec = (e.ld0 % 4 == 0) && (((uintptr_t)e.out0 & 15) == 0);
   if (e.out1) vec = vec && (e.ld1 % 4 == 0) && (((uintptr_t)e.out1 & 15) == 0);
   if (e.res) vec = vec && (e.ldres % 4 == 0) && (((uintptr_t)e.res & 15) == 0);

@@ -17,21 +17,53 @@ __global__ void cast_weight_kernel(const float* __restrict__ src, int rows, int 
     dst[(size_t)r * ld + c] = OpT<T>::from_f(c < cols ? src[(size_t)r * cols + c] : 0.f);
 }
 
-// dst[c, r] = src[r, c] through a 32x33 LDS tile; dst has ld >= rows, zero padded
+// dst[c, r] = src[r, c] through a 32x33 LDS tile; dst has ld >= rows, zero padded.  A block walks a
+// panel of TP_ROWS rows x 32 columns; with colsum != nullptr it also accumulates
+// colsum[c] += sum_r src[r, c] (bias gradients) with one atomic per column per panel.
+constexpr int TP_ROWS = 256;
 template <typename TS, typename TD>
-__global__ void transpose_kernel(const TS* __restrict__ src, int rows, int cols, int lds_, TD* __restrict__ dst,
-                                 int ld) {
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, int rows, int cols, int lds_,
+                                                        TD* __restrict__ dst, int ld, float* __restrict__ colsum) {
   __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  __shared__ float part[8][32];
+  const int c0 = blockIdx.x * 32, rp0 = blockIdx.y * TP_ROWS;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < rows && c < cols) ? OpT<TS>::to_f(src[(size_t)r * lds_ + c]) : 0.f;
+  float acc = 0.f;
+  for (int r0 = rp0; r0 < rp0 + TP_ROWS && r0 < ld; r0 += 32) {
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      const float v = (r < rows && c < cols) ? OpT<TS>::to_f(src[(size_t)r * lds_ + c]) : 0.f;
+      tile[i][tx] = v;
+      acc += v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;  // dst row = c, dst col = r
+      if (c < cols && r < ld) dst[(size_t)c * ld + r] = OpT<TD>::from_f(tile[tx][i]);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;  // dst row = c, dst col = r
-    if (c < cols && r < ld) dst[(size_t)c * ld + r] = OpT<TD>::from_f(tile[tx][i]);
+  if (colsum) {
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c0 + tx < cols) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += part[k][tx];
+      atomicAdd(colsum + c0 + tx, t);
+    }
+  }
+}
+
+// dW[i] += sum_z slab[z][i]   (split-K weight-gradient partials)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, long long n, int nslab, float* __restrict__ dW) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    float4 a = *reinterpret_cast<const float4*>(dW + i);
+    for (int z = 0; z < nslab; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (long long)z * n + i);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dW + i) = a;
   }
 }
 
@@ -313,40 +345,65 @@ __global__ void assemble_fwd_kernel(const TimSeqRow* __restrict__ rows, int B, i
   }
 }
 
-// backward: scatter dx into d_e (features, written), d_te (+= atomics: a time row can feed several
-// token rows), d_cls / d_mod (+= atomics over B*rows).
-__global__ void assemble_bwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
-                                    const float* __restrict__ dx, int n_e_rows, int Trows, uint32_t thr,
-                                    float scale, uint64_t seed, uint32_t site, float* __restrict__ d_e0,
-                                    float* __restrict__ d_e1, float* __restrict__ d_cls, float* __restrict__ d_te,
-                                    float* __restrict__ d_mod) {
-  const int bs = blockIdx.x;
-  const int b = bs / S, s = bs % S;
+// backward.  Kernel 1: one block per token row s walks all windows: writes d_e (feature rows), and
+// reduces the cls / modality gradients over the batch in registers before ONE atomic per column.
+// Kernel 2: d_te[b, t, :] = sum over the token rows that read time row t (fixed order, no atomics).
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
+                                                           const float* __restrict__ dx, int n_e_rows, uint32_t thr,
+                                                           float scale, uint64_t seed, uint32_t site,
+                                                           float* __restrict__ d_e0, float* __restrict__ d_e1,
+                                                           float* __restrict__ d_cls, float* __restrict__ d_mod) {
+  const int s = blockIdx.x;
   const TimSeqRow r = rows[s];
   const int E = 2 * d;
   for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
-    float4 g = *reinterpret_cast<const float4*>(dx + (size_t)bs * E + c);
-    if (thr != 0u) {
-      float k0, k1, k2, k3;
-      drop_mask4(seed, site, ((uint64_t)bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
-      g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < B; ++b) {
+      const size_t bs = (size_t)b * S + s;
+      float4 g = *reinterpret_cast<const float4*>(dx + bs * E + c);
+      if (thr != 0u) {
+        float k0, k1, k2, k3;
+        drop_mask4(seed, site, (bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
+        g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+      }
+      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      if (c < d && r.kind != 1) {
+        float* d_e = r.kind == 0 ? d_e0 : d_e1;
+        if (d_e) store4<float>(d_e + ((size_t)b * n_e_rows + r.src) * d + c, g.x, g.y, g.z, g.w);
+      }
     }
     if (r.mod >= 0 && d_mod) {
       float* p = d_mod + (size_t)r.mod * E + c;
-      atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+      atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
     }
-    if (c < d) {
-      if (r.kind != 1) {
-        float* d_e = r.kind == 0 ? d_e0 : d_e1;
-        if (d_e) store4<float>(d_e + ((size_t)b * n_e_rows + r.src) * d + c, g.x, g.y, g.z, g.w);
-      } else if (d_cls) {
-        float* p = d_cls + (size_t)r.src * d + c;
-        atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+    if (c < d && r.kind == 1 && d_cls) {
+      float* p = d_cls + (size_t)r.src * d + c;
+      atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void assemble_bwd_te_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
+                                                              const float* __restrict__ dx, int Trows, uint32_t thr,
+                                                              float scale, uint64_t seed, uint32_t site,
+                                                              float* __restrict__ d_te) {
+  const int bt = blockIdx.x;
+  const int b = bt / Trows, t = bt % Trows;
+  const int E = 2 * d;
+  for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      if (rows[s].te_row != t) continue;
+      const size_t bs = (size_t)b * S + s;
+      float4 g = *reinterpret_cast<const float4*>(dx + bs * E + d + c);
+      if (thr != 0u) {
+        float k0, k1, k2, k3;
+        drop_mask4(seed, site, (bs * E + d + c) >> 2, thr, scale, k0, k1, k2, k3);
+        g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
       }
-    } else if (d_te) {
-      float* p = d_te + ((size_t)b * Trows + r.te_row) * d + (c - d);
-      atomicAdd(p, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
     }
+    store4<float>(d_te + ((size_t)b * Trows + t) * d + c, acc.x, acc.y, acc.z, acc.w);
   }
 }
 
@@ -387,11 +444,21 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ d_rows, int B,
     else { using T = bf16_t; __VA_ARGS__; }                      \
   } while (0)
 
-int tim_transpose(int precision, const void* src, int rows, int cols, int lds_, void* dst, int ld, hipStream_t s) {
+int tim_transpose(int precision, const void* src, int rows, int cols, int lds_, void* dst, int ld, float* colsum,
+                  hipStream_t s) {
   if (!src || !dst || rows <= 0 || cols <= 0 || ld < rows) return TIMHIP_EINVAL;
-  dim3 grid((cols + 31) / 32, (ld + 31) / 32);
+  dim3 grid((cols + 31) / 32, (ld + TP_ROWS - 1) / TP_ROWS);
   DISPATCH_T(precision, hipLaunchKernelGGL((transpose_kernel<T, T>), grid, dim3(256), 0, s, (const T*)src, rows,
-                                           cols, lds_, (T*)dst, ld));
+                                           cols, lds_, (T*)dst, ld, colsum));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStream_t s) {
+  if (!slab || !dW || n <= 0 || (n & 3)) return TIMHIP_EINVAL;
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, n, nslab, dW);
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
@@ -447,16 +514,16 @@ int timhip_cast_weight(int precision, const float* src, int rows, int cols, void
     DISPATCH_T(precision, hipLaunchKernelGGL(cast_weight_kernel<T>, grid, dim3(256), 0, s, src, rows, cols, (T*)dst, ld));
   } else {
     if (ld < rows) return TIMHIP_EINVAL;
-    dim3 grid((cols + 31) / 32, (ld + 31) / 32);
+    dim3 grid((cols + 31) / 32, (ld + TP_ROWS - 1) / TP_ROWS);
     DISPATCH_T(precision, hipLaunchKernelGGL((transpose_kernel<float, T>), grid, dim3(256), 0, s, src, rows, cols,
-                                             cols, (T*)dst, ld));
+                                             cols, (T*)dst, ld, (float*)nullptr));
   }
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
 
 int timhip_transpose(int precision, const void* src, int rows, int cols, int lds_, void* dst, int ld, void* stream) {
-  return tim_transpose(precision, src, rows, cols, lds_, dst, ld, (hipStream_t)stream);
+  return tim_transpose(precision, src, rows, cols, lds_, dst, ld, nullptr, (hipStream_t)stream);
 }
 
 int timhip_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, void* stream) {
@@ -547,9 +614,14 @@ int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float*
   if (!rows || !dx || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
   const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
   const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(B * S), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows,
-                     T_, thr, scale, seed, site, d_e0, d_e1, d_cls, d_te, d_mod);
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows, thr,
+                     scale, seed, site, d_e0, d_e1, d_cls, d_mod);
   TIM_CHECK_LAUNCH();
+  if (d_te) {
+    hipLaunchKernelGGL(assemble_bwd_te_kernel, dim3(B * T_), dim3(128), 0, (hipStream_t)stream, rows, B, S, d, dx, T_,
+                       thr, scale, seed, site, d_te);
+    TIM_CHECK_LAUNCH();
+  }
   return TIMHIP_OK;
 }
 

@@ -89,11 +89,10 @@ class Runtime:
         """dW[Nout,Kout] += dY[:M,:Nout]^T X[:M,:Kout]; db += colsum(dY)"""
         if M == 0:
             return
-        Mp = _ru(M)
-        tA = torch.empty((Nout, Mp), dtype=self.op_dtype, device=dY.device)
-        tB = torch.empty((Kout, Mp), dtype=self.op_dtype, device=dY.device)
+        nbytes = L.load().timhip_wgrad_workspace_bytes(self.prec, Nout, Kout, M)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dY.device)
         call("timhip_wgrad", self.prec, ptr(dY), dY.stride(0), Nout, ptr(X), X.stride(0), Kout, M, ptr(dW),
-             ptr(db), ptr(tA), ptr(tB), _stream())
+             ptr(db), ptr(ws), nbytes, _stream())
 
     def ln_fwd(self, y, rows, cols, act, w, b, xf=None, ldx=0, xt=None, ldt=0, stats=None):
         call("timhip_layernorm_fwd", self.prec, ptr(y), rows, cols, y.stride(0), act, ptr(w), ptr(b), ptr(xf), ldx,
