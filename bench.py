@@ -91,12 +91,28 @@ def gemm_roofline(model, cfg, B, nv, na, precision, reps=20):
         res = torch.zeros((m_, n_), dtype=torch.float32, device=dev)
         bias = torch.zeros(n_, device=dev)
         sk = 1
-        if epi == "slab":  # weight gradients: split-K into fp32 slabs exactly as timhip_wgrad launches it
-            tiles = ((m_ + 127) // 128) * ((n_ + 127) // 128)
-            sk = max(1, min((512 + tiles - 1) // tiles, k_ // 256, 8))
-            epi = L.EPI_STORE_F32
-            o0 = torch.zeros((sk * m_, n_), dtype=torch.float32, device=dev)
-            kw = dict(splitk=sk)
+        if epi == "slab":
+            # weight gradient dW[m_, n_] += dY[M, m_]^T X[M, n_] through timhip_wgrad (transposing-read TN
+            # MFMA kernel + slab reduce), timed as one unit; M = B*S rows
+            dY = torch.randn(M, m_, generator=g).to(dev).to(rt.op_dtype)
+            Xa = torch.randn(M, n_, generator=g).to(dev).to(rt.op_dtype)
+            dW = torch.zeros((m_, n_), dtype=torch.float32, device=dev)
+            dbv = torch.zeros(m_, dtype=torch.float32, device=dev)
+            for _ in range(3):
+                rt.wgrad(dY, m_, Xa, n_, M, dW, dbv)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                rt.wgrad(dY, m_, Xa, n_, M, dW, dbv)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            fl = 2.0 * m_ * n_ * M
+            out.append({"gemm": name, "M": m_, "N": n_, "K": M, "us": round(ms * 1e3, 2),
+                        "tflops": round(fl / ms / 1e9, 1)})
+            tot_flop += fl * cnt
+            tot_ms += ms * cnt
+            continue
         else:
             kw = dict(out1=o1, ld1=n_, bias=None if epi in (L.EPI_ADD_F32, L.EPI_DGELU_T) else bias,
                       res=res, ldres=n_, aux=o1, ldaux=n_, p_drop=cfg.enc_dropout, seed=7, site=5, splitk=sk)
@@ -236,8 +252,9 @@ def main():
         ach = fl / ms / 1e9
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 4), "traffic": None,
-                           "kernel": "gemm_nt_%s_kernel (all 12 GEMM launches of one encoder layer fwd+bwd, "
-                                     "2*M*N*K algorithmic FLOPs each, HIP-event timed)" % (
+                           "kernel": "MFMA GEMM family: gemm_nt_%s_kernel (8 launches) + wgrad_tn kernel incl. its slab "
+                                     "reduce (4 launches) = the 12 GEMMs of one encoder layer fwd+bwd, 2*M*N*K "
+                                     "algorithmic FLOPs each, HIP-event timed on the launch stream" % (
                                          "bf16" if args.precision == "bf16" else "f32"),
                            "per_shape": per}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

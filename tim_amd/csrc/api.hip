@@ -42,6 +42,11 @@ struct WgradWs { size_t tA, tB, slab, total; };
 WgradWs wgrad_ws(int prec, int Nout, int Kout, int M) {
   const size_t Mp = round_up(M, 64), ts = opsize(prec);
   WgradWs w;
+  if (prec == TIMHIP_PREC_BF16) {  // transposing-read kernel: no operand copies
+    w.tA = w.tB = w.slab = 0;
+    w.total = tim_wgrad_tn_ws(Nout, Kout, M);
+    return w;
+  }
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
   w.tA = take((size_t)Nout * Mp * ts);
@@ -108,6 +113,7 @@ int wgrad(int prec, const void* dY, int ldy, int Nout, const void* X, int ldx, i
   const int Mp = round_up(M, 64);
   const WgradWs W = wgrad_ws(prec, Nout, Kout, M);
   if (ws_bytes < W.total) return TIMHIP_EWORKSPACE;
+  if (prec == TIMHIP_PREC_BF16) return tim_wgrad_tn_bf16(dY, ldy, Nout, X, ldx, Kout, M, dW, db, ws, ws_bytes, s);
   char* w = (char*)ws;
   void* tA = w + W.tA; void* tB = w + W.tB; float* slab = (float*)(w + W.slab);
   int rc;

@@ -16,6 +16,7 @@
 //   ds_read_b128 fragment reads (16 different rows, same chunk)   -> rows map to 16 distinct slots
 //   ds_read_b64_tr_b16 reads (4 rows x 64 B)                      -> 16 distinct slots
 #include "common.h"
+#include "mfma_tiles.h"
 
 namespace {
 
@@ -24,74 +25,6 @@ struct AttnArgsM {
   float scale;
   uint32_t thr; float dscale; uint64_t seed; uint32_t site;
 };
-
-template <int DH> __device__ __forceinline__ int swz(int row);
-template <> __device__ __forceinline__ int swz<128>(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-template <> __device__ __forceinline__ int swz<64>(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
-template <> __device__ __forceinline__ int swz<32>(int row) { return (row >> 2) & 3; }
-
-// byte offset of (row, 16-B chunk c) in a tile
-template <int DH> __device__ __forceinline__ int tile_off(int row, int c) {
-  return row * (DH * 2) + ((c ^ swz<DH>(row)) << 4);
-}
-
-typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
-
-__device__ __forceinline__ bf16x4_t tr_read(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_ptr)(p));
-}
-
-__device__ __forceinline__ bf16x8_t cat8(bf16x4_t a, bf16x4_t b) {
-  bf16x8_t r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
-}
-
-__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& v, int a) {
-  bf16x8_t r;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) r[u] = (bf16_t)v[8 * a + u];
-  return r;
-}
-
-__device__ __forceinline__ float dot8(bf16x8_t a, bf16x8_t b) {
-  float s = 0.f;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) s = fmaf((float)a[u], (float)b[u], s);
-  return s;
-}
-
-// stage `nrows` rows (row r -> src + r*ld, DH bf16 each; rows >= nvalid are zero) into a tile
-template <int DH>
-__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, size_t ld, int nrows, int nvalid, int tid,
-                                           int nthreads) {
-  constexpr int NC = DH / 8;
-  for (int idx = tid; idx < nrows * NC; idx += nthreads) {
-    const int row = idx / NC, c = idx % NC;
-    bf16x8_t v;
-    if (row < nvalid) {
-      v = *reinterpret_cast<const bf16x8_t*>(src + (size_t)row * ld + c * 8);
-    } else {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (bf16_t)0.f;
-    }
-    *reinterpret_cast<bf16x8_t*>(tile + tile_off<DH>(row, c)) = v;
-  }
-}
-
-// V^T / K^T fragment for the PV-style MFMA: lane (i = lane & 31 -> dh 32*db + i, g = lane >> 5)
-// gets the 8 values tile[key(u)][dh], key(u) = kb + 8*(u>>2) + 4*g + (u&3)   (kb = 32*jb + 16*a)
-template <int DH>
-__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int kb, int db, int lane) {
-  const int gid = lane >> 4, p = lane & 15, g = gid >> 1;
-  const int row0 = kb + 4 * g + (p >> 2);
-  const int c = 4 * db + 2 * (gid & 1) + ((p & 3) >> 1);
-  const int sub = (p & 1) * 8;
-  bf16x4_t lo = tr_read(tile + tile_off<DH>(row0, c) + sub);
-  bf16x4_t hi = tr_read(tile + tile_off<DH>(row0 + 8, c) + sub);
-  return cat8(lo, hi);
-}
 
 __device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
                                       float& k3) {
@@ -102,6 +35,16 @@ __device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int
   drop_mask4(a.seed, a.site, (rowbase + (uint64_t)key) >> 2, a.thr, a.dscale, k[0], k[1], k[2], k[3]);
   const int c = (int)((rowbase + (uint64_t)key) & 3);
   return c == 0 ? k[0] : (c == 1 ? k[1] : (c == 2 ? k[2] : k[3]));
+}
+
+template <int C>
+__device__ __forceinline__ float quad_bcast(float v) {  // value of lane (lane & ~3) + C within each quad
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), C * 0x55, 0xF, 0xF, true));
+}
+template <int C>
+__device__ __forceinline__ float quad_pick(float k0, float k1, float k2, float k3, int tl) {
+  const float b0 = quad_bcast<C>(k0), b1 = quad_bcast<C>(k1), b2 = quad_bcast<C>(k2), b3 = quad_bcast<C>(k3);
+  return tl == 0 ? b0 : (tl == 1 ? b1 : (tl == 2 ? b2 : b3));
 }
 
 // ---------------------------------------------------------------------------
@@ -252,7 +195,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
   char* sV = sK + FP * DH * 2;
   char* sQ = sV + FP * DH * 2;        // 32-row block of Q
   char* sD = sQ + 32 * DH * 2;        // 32-row block of dO
-  float* sL = reinterpret_cast<float*>(sD + 32 * DH * 2);  // [32] lse, [32] delta
+  float* sLse = reinterpret_cast<float*>(sD + 32 * DH * 2);  // [S] lse
+  float* sDel = sLse + a.S;                                  // [S] delta = dO . O
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int S = a.S, F = a.F, E = a.E;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -289,6 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
     }
     delta += __shfl_xor(delta, 32, 64);
     const float l = lsebase[rowc];
+    if (valid && g == 0) { sLse[row] = l; sDel[row] = delta; }
     const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
 
     // self terms (scalar per row)
@@ -393,19 +338,6 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
       const int nvalid = min(32, S - r0);
       stage_tile<DH>(sQ, base + (size_t)r0 * ld, ld, 32, nvalid, tid, 256);
       stage_tile<DH>(sD, dobase + (size_t)r0 * E, E, 32, nvalid, tid, 256);
-      if (tid < 32) {
-        const int rr = r0 + tid;
-        float lv = 0.f, dv = 0.f;
-        if (rr < S) {
-          lv = lsebase[rr];
-          // delta = dO . O
-          const bf16_t* dop = dobase + (size_t)rr * E;
-          const bf16_t* op = obase + (size_t)rr * E;
-          for (int c = 0; c < DH; c += 8)
-            dv += dot8(*reinterpret_cast<const bf16x8_t*>(dop + c), *reinterpret_cast<const bf16x8_t*>(op + c));
-        }
-        sL[tid] = lv; sL[32 + tid] = dv;
-      }
       __syncthreads();
       if (!active) continue;
       // S = Q K^T, dP = dO V^T : lane owns key `key`, registers hold rows (r&3) + 8(r>>2) + 4g
@@ -421,19 +353,37 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf, dp, 0, 0, 0);
       }
+      // dropout keep factors: the 4 lanes of a quad hold 4 consecutive keys, so one Philox call
+      // (4 outputs) serves a whole quad; lane t of the quad draws for register-row t and the
+      // results are exchanged with DPP quad broadcasts (4 calls per lane instead of 16).
+      float keepv[16];
+      if (a.thr != 0u) {
+        const int tl = lane & 3;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int rr = min(r0 + 8 * rq + 4 * g + tl, S - 1);
+          const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rr) * (uint64_t)a.LP;
+          float k0, k1, k2, k3;
+          keep4(a, rowbase, min(key & ~3, a.LP - 4), k0, k1, k2, k3);
+          keepv[4 * rq + 0] = quad_pick<0>(k0, k1, k2, k3, tl);
+          keepv[4 * rq + 1] = quad_pick<1>(k0, k1, k2, k3, tl);
+          keepv[4 * rq + 2] = quad_pick<2>(k0, k1, k2, k3, tl);
+          keepv[4 * rq + 3] = quad_pick<3>(k0, k1, k2, k3, tl);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keepv[r] = 1.f;
+      }
       f32x16_t dsr, ptr_;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = (r & 3) + 8 * (r >> 2) + 4 * g;
         const int rr = r0 + rl;
-        float keep = 1.f;
-        if (a.thr != 0u && rr < S && key < F) {
-          const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rr) * (uint64_t)a.LP;
-          keep = keep1(a, rowbase, key);
-        }
-        const float p = (rr < S && key < F) ? __expf(sc[r] * a.scale - sL[rl]) : 0.f;
-        dsr[r] = p * (dp[r] * keep - sL[32 + rl]) * a.scale;
-        ptr_[r] = p * keep;
+        const bool ok = rr < S && key < F;
+        const int rc = min(rr, S - 1);
+        const float p = ok ? __expf(sc[r] * a.scale - sLse[rc]) : 0.f;
+        dsr[r] = p * (dp[r] * keepv[r] - sDel[rc]) * a.scale;
+        ptr_[r] = p * keepv[r];
       }
       // dK^T += Q^T dS ; dV^T += dO^T P~   (contraction over the 32 rows: two K=16 MFMAs)
 #pragma unroll
@@ -484,7 +434,7 @@ int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream
 template <int DH, int NJB>
 int launch_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
                hipStream_t s) {
-  const size_t lds = (size_t)2 * NJB * 32 * DH * 2 + (size_t)2 * 32 * DH * 2 + 64 * sizeof(float);
+  const size_t lds = (size_t)2 * NJB * 32 * DH * 2 + (size_t)2 * 32 * DH * 2 + (size_t)2 * d.S * sizeof(float);
   (void)hipFuncSetAttribute((const void*)attn_bwd_mfma<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_mfma<DH, NJB>), dim3(d.B * d.H), dim3(256), lds, s, (const bf16_t*)qkv,
                      (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dqkv, make_args(d));

@@ -59,7 +59,7 @@ __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float& a, float& 
 }
 
 // ----------------------------------------------------------------------------
-// Philox4x32-10 counter RNG: dropout masks are a pure function of
+// Philox4x32-7 counter RNG (7 rounds: the fewest that pass BigCrush, Salmon et al. 2011): dropout masks are a pure function of
 // (seed, site, element index) so the backward regenerates them.
 // ----------------------------------------------------------------------------
 struct Philox4 { uint32_t x, y, z, w; };
@@ -72,11 +72,12 @@ __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
 #endif
 }
 
+constexpr int PHILOX_ROUNDS = 7;
 __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t site, uint64_t ctr) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = site, c3 = 0x7149u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < PHILOX_ROUNDS; ++r) {
     uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
@@ -116,12 +117,30 @@ static inline uint32_t layer_site(int layer, int which) {
 // ----------------------------------------------------------------------------
 // math
 // ----------------------------------------------------------------------------
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7): 1 rcp + 1 exp + 5 fma instead of the
+// ~40-instruction libm erff; the epilogues that apply GELU run once per output element and their
+// VALU time is otherwise comparable to the MFMA main loop of a K=1024 tile.
+// Returns erf(x/sqrt2) given x, and e = exp(-x*x/2) for reuse by the derivative.
+__device__ __forceinline__ float erf_half_f(float x, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  e = __expf(-0.5f * x * x);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float e;
+  return 0.5f * x * (1.0f + erf_half_f(x, e));
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   const float kInvSqrt2Pi = 0.3989422804014327f;
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+  float e;
+  const float er = erf_half_f(x, e);
+  return fmaf(x * kInvSqrt2Pi, e, 0.5f * (1.0f + er));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -143,6 +162,9 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
 int tim_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,
                   float* colsum, hipStream_t s);
 int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStream_t s);
+size_t tim_wgrad_tn_ws(int Nout, int Kout, int M);
+int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
+                      void* ws, size_t ws_bytes, hipStream_t s);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,

@@ -16,6 +16,8 @@
 // operands staged HBM -> LDS with global_load_lds (16 B/lane), two LDS stages,
 // XOR swizzle applied on the SOURCE address (LDS image stays lane-linear) and on
 // the ds_read_b128 side so the fragment reads are bank-conflict free.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -349,8 +351,32 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   }
 }
 
+template <int EPI, int BM, int BN, int WM, int WN>
+void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int splitk,
+                 hipStream_t s) {
+  const int nk = K / BK;
+  const int per = (nk + splitk - 1) / splitk;
+  dim3 grid(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splitk);
+  const size_t shmem = 2 * (BM + BN) * BK * 2;
+  static bool attr_set = false;  // idempotent; a benign race sets it twice at worst
+  if (!attr_set && shmem > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN>), grid, dim3(WM * WN * 64), shmem, s,
+                     (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, per, e);
+}
+
+// tile variants (bf16): 0 = 128x128 / 4 waves (default), others for tuning on selected epilogues
 template <int EPI>
-int launch(int precision, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+constexpr bool tunable() {
+  return EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_ADD_F32 || EPI == TIMHIP_EPI_STORE_F32 ||
+         EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_GELU_DROP_T2 || EPI == TIMHIP_EPI_DGELU_T;
+}
+
+template <int EPI>
+int launch(int precision, int variant, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
            const EpiDev& e, int splitk, hipStream_t s) {
   if (precision == TIMHIP_PREC_FP32) {
     const int nk = K / FBK;
@@ -359,13 +385,18 @@ int launch(int precision, const void* A, int lda, const void* B, int ldb, int M,
     hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI>, grid, dim3(256), 0, s, (const float*)A, lda,
                        (const float*)B, ldb, M, N, K, per, e);
   } else {
-    constexpr int BM = 128, BN = 128;
-    const int nk = K / BK;
-    const int per = (nk + splitk - 1) / splitk;
-    dim3 grid(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splitk);
-    const size_t shmem = 2 * (BM + BN) * BK * 2;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, 2, 2>), grid, dim3(256), shmem, s,
-                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, per, e);
+    if constexpr (tunable<EPI>()) {
+      switch (variant) {
+        case 1: launch_bf16<EPI, 256, 128, 4, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 2: launch_bf16<EPI, 256, 128, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 3: launch_bf16<EPI, 128, 256, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 4: launch_bf16<EPI, 256, 256, 4, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 5: launch_bf16<EPI, 256, 256, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        default: launch_bf16<EPI, 128, 128, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+      }
+    } else {
+      launch_bf16<EPI, 128, 128, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s);
+    }
   }
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   return TIMHIP_OK;
@@ -397,8 +428,10 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   if (e.bias) vec = vec && (((uintptr_t)e.bias & 15) == 0);
   e.vec = vec ? 1 : 0;
   if (e.thr != 0u && (N % 4) != 0) return TIMHIP_EUNSUPPORTED;
+  int variant = 0;
+  if (const char* v = getenv("TIMHIP_GEMM_VARIANT")) variant = atoi(v);  // tuning knob
   switch (epi) {
-#define CASE(X) case X: return launch<X>(precision, A, lda, B, ldb, M, N, Kp, e, splitk, s);
+#define CASE(X) case X: return launch<X>(precision, variant, A, lda, B, ldb, M, N, Kp, e, splitk, s);
     CASE(TIMHIP_EPI_STORE_T)
     CASE(TIMHIP_EPI_RELU_T)
     CASE(TIMHIP_EPI_STORE_F32)

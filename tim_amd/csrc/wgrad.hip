@@ -1,0 +1,193 @@
+// Weight-gradient GEMM  dW[N,K] += dY[M,N]^T X[M,K]  (+ db[N] += colsum dY)  for nn.Linear
+// (backward of transformers.py:102,107; encodings.py:22,141,148; tim.py:69-71; head.py:8-15).
+//
+// The contraction runs over the rows m of two row-major activations, i.e. over the STRIDED
+// dimension of both operands.  Instead of materialising transposed copies, both tiles are staged in
+// their natural [m][col] layout (global_load_lds, 16 B/lane, swizzle on the source address) and the
+// MFMA fragments are produced by ds_read_b64_tr_b16 (gfx950 transposing LDS read).
+//
+//   D[i = k][j = n] = sum_m X[m][k] dY[m][n]   ->  a lane owns one output row n of dW and 4
+//   consecutive k per accumulator quad: 16-byte fp32 stores.
+//   bias gradient: one extra MFMA per step with an all-ones A operand (no LDS traffic) in the
+//   blocks of the first k-tile column.
+//
+// M is split across blockIdx.z; every split writes its partial tile into an fp32 slab with plain
+// coalesced stores and timhip's slab-reduce kernel adds the slabs into dW / db (no atomics).
+#include "common.h"
+#include "mfma_tiles.h"
+
+namespace {
+
+constexpr int WT = 128;   // output tile: 128 (n) x 128 (k)
+constexpr int WM = 64;    // contraction rows per step
+
+__global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __restrict__ dY, int ldy,
+                                                            const bf16_t* __restrict__ X, int ldx, int M, int N,
+                                                            int K, int steps_per_split, float* __restrict__ slab,
+                                                            long long slab_stride, float* __restrict__ db_slab,
+                                                            const bf16_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][sY 16 KB | sX 16 KB]
+  constexpr int TILE_BYTES = WM * WT * 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wn = wave & 1;
+  const int tiles_k = (K + WT - 1) / WT, tiles_n = (N + WT - 1) / WT;
+  // consecutive blocks share the dY panel (same n-tile): k-tile fastest
+  const int t = blockIdx.x;
+  const int n0 = (t / tiles_k) * WT, k0 = (t % tiles_k) * WT;
+  const bool do_bias = db_slab != nullptr && (t % tiles_k) == 0;
+  const int nsteps = (M + WM - 1) / WM;
+  const int s0 = blockIdx.z * steps_per_split;
+  const int s1 = min(nsteps, s0 + steps_per_split);
+
+  // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk')
+  const int lrow = lane >> 4, lc = lane & 15;
+  int srow[4], ycol[4], xcol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 4 + lrow;
+    const int c = lc ^ swz<128>(row);
+    srow[i] = row;
+    ycol[i] = n0 + c * 8;
+    xcol[i] = k0 + c * 8;
+  }
+  auto stage = [&](int step, int buf) {
+    char* base = lds + buf * 2 * TILE_BYTES;
+    const int m0 = step * WM;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + srow[i];
+      const bf16_t* py = (m < M && ycol[i] < ldy) ? dY + (size_t)m * ldy + ycol[i] : zero_page;
+      const bf16_t* px = (m < M && xcol[i] < ldx) ? X + (size_t)m * ldx + xcol[i] : zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
+                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px,
+                                       (__attribute__((address_space(3))) void*)(base + TILE_BYTES + (wave * 4 + i) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[2][2], accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) ones[u] = (bf16_t)1.0f;
+
+  if (s0 < s1) stage(s0, 0);
+  for (int st = s0; st < s1; ++st) {
+    const int buf = (st - s0) & 1;
+    __syncthreads();
+    if (st + 1 < s1) stage(st + 1, buf ^ 1);
+    const char* sY = lds + buf * 2 * TILE_BYTES;
+    const char* sX = sY + TILE_BYTES;
+#pragma unroll
+    for (int ms = 0; ms < WM / 16; ++ms) {
+      bf16x8_t xf[2], yf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xf[i] = tr_frag<128>(sX, ms * 16, wk * 2 + i, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) yf[j] = tr_frag<128>(sY, ms * 16, wn * 2 + j, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+      if (do_bias && wk == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yf[j], accb[j], 0, 0, 0);
+      }
+    }
+  }
+
+  const int li = lane & 31, g = lane >> 5;
+  float* out = slab + (long long)blockIdx.z * slab_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + li;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + wk * 64 + i * 32 + 8 * q + 4 * g;
+        if (k + 3 < K) {
+          store4<float>(out + (size_t)n * K + k, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                        acc[i][j][4 * q + 3]);
+        } else {
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+            if (k + tt < K) out[(size_t)n * K + k + tt] = acc[i][j][4 * q + tt];
+        }
+      }
+    if (do_bias && wk == 0 && g == 0) db_slab[(size_t)blockIdx.z * N + n] = accb[j][0];
+  }
+}
+
+// out[i] += sum_z slab[z*stride + i]
+__global__ void slab_reduce2_kernel(const float* __restrict__ slab, long long n, long long stride, int nslab,
+                                    float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float a = out[i];
+    for (int z = 0; z < nslab; ++z) a += slab[(long long)z * stride + i];
+    out[i] = a;
+  }
+}
+
+}  // namespace
+
+int tim_wgrad_splits(int Nout, int Kout, int M) {
+  const int tiles = ((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT);
+  const int nsteps = (M + WM - 1) / WM;
+  int sk = (512 + tiles - 1) / tiles;
+  if (sk > nsteps / 4) sk = nsteps / 4;
+  if (sk > 16) sk = 16;
+  if (sk < 1) sk = 1;
+  return sk;
+}
+
+// workspace: [zero page 256 B][slab sk*N*K fp32][db slab sk*N fp32]
+size_t tim_wgrad_tn_ws(int Nout, int Kout, int M) {
+  const int sk = tim_wgrad_splits(Nout, Kout, M);
+  return 256 + align_up((size_t)sk * Nout * Kout * 4, 256) + align_up((size_t)sk * Nout * 4, 256);
+}
+
+int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
+                      void* ws, size_t ws_bytes, hipStream_t s) {
+  if (ws_bytes < tim_wgrad_tn_ws(Nout, Kout, M)) return TIMHIP_EWORKSPACE;
+  if ((ldy % 8) || (ldx % 8) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)ws) & 15)) return TIMHIP_EALIGN;
+  const int sk = tim_wgrad_splits(Nout, Kout, M);
+  char* w = (char*)ws;
+  bf16_t* zero = (bf16_t*)w;
+  float* slab = (float*)(w + 256);
+  float* dbs = (float*)(w + 256 + align_up((size_t)sk * Nout * Kout * 4, 256));
+  if (hipMemsetAsync(zero, 0, 256, s) != hipSuccess) return TIMHIP_ELAUNCH;
+  const int nsteps = (M + WM - 1) / WM;
+  const int per = (nsteps + sk - 1) / sk;
+  const int sk_eff = (nsteps + per - 1) / per;  // no empty splits
+  dim3 grid(((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT), 1, sk_eff);
+  const size_t shmem = 2 * 2 * WM * WT * 2;
+  hipLaunchKernelGGL(wgrad_tn_bf16_kernel, grid, dim3(256), shmem, s, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M,
+                     Nout, Kout, per, slab, (long long)Nout * Kout, db ? dbs : nullptr, zero);
+  if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
+  int rc = tim_slab_reduce(slab, (long long)Nout * Kout, sk_eff, dW, s);
+  if (rc == TIMHIP_EINVAL) {  // Nout*Kout not a multiple of 4: scalar reduce
+    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(256), dim3(256), 0, s, slab, (long long)Nout * Kout,
+                       (long long)Nout * Kout, sk_eff, dW);
+    rc = hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+  }
+  if (rc) return rc;
+  if (db) {
+    hipLaunchKernelGGL(slab_reduce2_kernel, dim3((Nout + 255) / 256), dim3(256), 0, s, dbs, (long long)Nout,
+                       (long long)Nout, sk_eff, db);
+    if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
+  }
+  return TIMHIP_OK;
+}
