@@ -51,7 +51,7 @@ __device__ __forceinline__ float quad_pick(float k0, float k1, float k2, float k
 // forward
 // ---------------------------------------------------------------------------
 template <int DH, int NJB>
-__global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+__global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                      float* __restrict__ lse, AttnArgsM a) {
   constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,21 +63,24 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t ld = (size_t)3 * E;
   const bf16_t* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
-  stage_tile<DH>(sK, base + E, ld, FP, F, tid, 256);
-  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, 256);
+  stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
+  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
 
   const int li = lane & 31, g = lane >> 5;
   const int nrb = (S + 31) >> 5;
-  for (int rb = wave; rb < nrb; rb += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int rb = wave; rb < nrb; rb += nwaves) {
     const int row = rb * 32 + li;
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
     const bool isq = rowc >= F;
     const bf16_t* qp = base + (size_t)rowc * ld;
-    bf16x8_t qf[NKK];
+    bf16x8_t qf[NKK], kself[NKK];
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 16 + g * 8);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) kself[kk] = *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8);
 
     // S^T = K Q^T : lane owns query row `row`, registers hold keys 32jb + (r&3) + 8(r>>2) + 4g
     f32x16_t sc[NJB];
@@ -90,90 +93,110 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
         sc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sc[jb], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the K-fragment reads of later key blocks from being hoisted
     }
-    // self score of query tokens
+    // self score of query tokens (raw, unscaled like sc)
     float sself = -INFINITY;
-    if (isq) {
-      float t = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk)
-        t += dot8(qf[kk], *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8));
-      sself = t;
-    }
     {
-      const float other = __shfl_xor(isq ? sself : 0.f, 32, 64);
-      if (isq) sself = (sself + other) * a.scale;
+      float t = 0.f;
+      if (isq) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) t += dot8(qf[kk], kself[kk]);
+      }
+      const float other = __shfl_xor(t, 32, 64);
+      if (isq) sself = t + other;
+    }
+    // only the last key block can hold padded keys
+    {
+      constexpr int jb = NJB - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (key >= F) sc[jb][r] = -INFINITY;
+      }
     }
     float mx = sself;
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float s = key < F ? sc[jb][r] * a.scale : -INFINITY;
-        sc[jb][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[jb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // p = exp(scale*(s - mx)) = exp2(c*s - c*mx)
+    const float c2 = a.scale * 1.4426950408889634f;
+    const float mc = mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __expf(sc[jb][r] - mx);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[jb][r], c2, -mc));
         sc[jb][r] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 32, 64);
-    const float pself_un = isq ? __expf(sself - mx) : 0.f;
+    const float pself_un = isq ? __builtin_amdgcn_exp2f(fmaf(sself, c2, -mc)) : 0.f;
     sum += pself_un;
     const float inv = 1.f / sum;
-    if (valid && g == 0) lse[((size_t)b * a.H + h) * S + row] = mx + __logf(sum);
+    if (valid && g == 0) lse[((size_t)b * a.H + h) * S + row] = mx * a.scale + __logf(sum);
     const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
-        if (a.thr != 0u) keep4(a, rowbase, jb * 32 + 8 * q + 4 * g, k0, k1, k2, k3);
-        sc[jb][4 * q] *= inv * k0; sc[jb][4 * q + 1] *= inv * k1;
-        sc[jb][4 * q + 2] *= inv * k2; sc[jb][4 * q + 3] *= inv * k3;
+        if (a.thr != 0u) {
+          float k0, k1, k2, k3;
+          keep4(a, rowbase, jb * 32 + 8 * q + 4 * g, k0, k1, k2, k3);
+          sc[jb][4 * q] *= inv * k0; sc[jb][4 * q + 1] *= inv * k1;
+          sc[jb][4 * q + 2] *= inv * k2; sc[jb][4 * q + 3] *= inv * k3;
+        } else {
+          sc[jb][4 * q] *= inv; sc[jb][4 * q + 1] *= inv; sc[jb][4 * q + 2] *= inv; sc[jb][4 * q + 3] *= inv;
+        }
       }
     float pself = pself_un * inv;
     if (isq && a.thr != 0u) pself *= keep1(a, rowbase, F);
 
-    // O^T = V^T P^T
-    f32x16_t oa[NDB];
+    // O^T = V^T P^T.  P is packed to bf16 first (frees the fp32 score registers); the head dim is
+    // processed in halves so only NDB/2 accumulator tiles are live at a time.
+    bf16x8_t pf[NJB][2];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+    for (int jb = 0; jb < NJB; ++jb) {
+      pf[jb][0] = pack8(sc[jb], 0);
+      pf[jb][1] = pack8(sc[jb], 1);
+    }
+    constexpr int NH = NDB >= 2 ? 2 : 1, DBH = NDB / NH;
+    bf16_t* op = o + ((size_t)b * S + rowc) * E + (size_t)h * DH;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oa[db][r] = 0.f;
+    for (int hh = 0; hh < NH; ++hh) {
+      f32x16_t oa[DBH];
 #pragma unroll
-    for (int jb = 0; jb < NJB; ++jb)
+      for (int d2 = 0; d2 < DBH; ++d2)
 #pragma unroll
-      for (int aa = 0; aa < 2; ++aa) {
-        const bf16x8_t pf = pack8(sc[jb], aa);
+        for (int r = 0; r < 16; ++r) oa[d2][r] = 0.f;
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-          const bf16x8_t vf = tr_frag<DH>(sV, jb * 32 + 16 * aa, db, lane);
-          oa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oa[db], 0, 0, 0);
-        }
-      }
-    if (valid) {
-      bf16_t* op = o + ((size_t)b * S + row) * E + (size_t)h * DH;
+      for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
-      for (int db = 0; db < NDB; ++db)
+        for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int dh = 32 * db + 8 * q + 4 * g;
-          float v0 = oa[db][4 * q], v1 = oa[db][4 * q + 1], v2 = oa[db][4 * q + 2], v3 = oa[db][4 * q + 3];
-          if (isq) {
-            float s0, s1, s2, s3;
-            load4<bf16_t>(qp + 2 * E + dh, s0, s1, s2, s3);
-            v0 = fmaf(pself, s0, v0); v1 = fmaf(pself, s1, v1); v2 = fmaf(pself, s2, v2); v3 = fmaf(pself, s3, v3);
+          for (int d2 = 0; d2 < DBH; ++d2) {
+            const bf16x8_t vf = tr_frag<DH>(sV, jb * 32 + 16 * aa, hh * DBH + d2, lane);
+            oa[d2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jb][aa], oa[d2], 0, 0, 0);
+            if (d2 == DBH - 1 && aa == 1) __builtin_amdgcn_sched_barrier(0);
           }
-          store4<bf16_t>(op + dh, v0, v1, v2, v3);
-        }
+      if (valid) {
+#pragma unroll
+        for (int d2 = 0; d2 < DBH; ++d2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int dh = 32 * (hh * DBH + d2) + 8 * q + 4 * g;
+            float v0 = oa[d2][4 * q], v1 = oa[d2][4 * q + 1], v2 = oa[d2][4 * q + 2], v3 = oa[d2][4 * q + 3];
+            if (isq) {
+              float s0, s1, s2, s3;
+              load4<bf16_t>(qp + 2 * E + dh, s0, s1, s2, s3);
+              v0 = fmaf(pself, s0, v0); v1 = fmaf(pself, s1, v1); v2 = fmaf(pself, s2, v2); v3 = fmaf(pself, s3, v3);
+            }
+            store4<bf16_t>(op + dh, v0, v1, v2, v3);
+          }
+      }
     }
   }
 }
@@ -207,15 +230,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
   const bf16_t* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
   const bf16_t* obase = o + (size_t)b * S * E + (size_t)h * DH;
   const float* lsebase = lse + ((size_t)b * a.H + h) * S;
-  stage_tile<DH>(sK, base + E, ld, FP, F, tid, 256);
-  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, 256);
+  stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
+  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
 
   const int li = lane & 31, g = lane >> 5;
   const int nrb = (S + 31) >> 5;
 
   // ---------------- phase 1 ----------------
-  for (int rb = wave; rb < nrb; rb += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int rb = wave; rb < nrb; rb += nwaves) {
     const int row = rb * 32 + li;
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
@@ -322,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
 
   // ---------------- phase 2 ----------------
   // wave w owns key blocks w, w+4; accumulators dK^T, dV^T [dh][key] over all row blocks
-  for (int jb0 = 0; jb0 < NJB; jb0 += 4) {
+  for (int jb0 = 0; jb0 < NJB; jb0 += nwaves) {
     const int jb = jb0 + wave;
     const bool active = jb < NJB;
     f32x16_t ka[NDB], va[NDB];
@@ -336,8 +360,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
       __syncthreads();  // previous block's sQ/sD fully consumed
       const int r0 = rb * 32;
       const int nvalid = min(32, S - r0);
-      stage_tile<DH>(sQ, base + (size_t)r0 * ld, ld, 32, nvalid, tid, 256);
-      stage_tile<DH>(sD, dobase + (size_t)r0 * E, E, 32, nvalid, tid, 256);
+      stage_tile<DH>(sQ, base + (size_t)r0 * ld, ld, 32, nvalid, tid, blockDim.x);
+      stage_tile<DH>(sD, dobase + (size_t)r0 * E, E, 32, nvalid, tid, blockDim.x);
       __syncthreads();
       if (!active) continue;
       // S = Q K^T, dP = dO V^T : lane owns key `key`, registers hold rows (r&3) + 8(r>>2) + 4g
@@ -423,11 +447,14 @@ AttnArgsM make_args(const TimDesc& d) {
   return a;
 }
 
+// one wave per 32-row block of queries, at most 8 waves (2 per SIMD keeps the 256-VGPR budget)
+static inline int attn_waves(int S) { const int n = (S + 31) / 32; return n < 1 ? 1 : (n > 8 ? 8 : n); }
+
 template <int DH, int NJB>
 int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
   const size_t lds = (size_t)2 * NJB * 32 * DH * 2;
   (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_mfma<DH, NJB>), dim3(d.B * d.H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse,
+  hipLaunchKernelGGL((attn_fwd_mfma<DH, NJB>), dim3(d.B * d.H), dim3(64 * attn_waves(d.S)), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse,
                      make_args(d));
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }

@@ -155,6 +155,32 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ----------------------------------------------------------------------------
+// LDS-DMA (global_load_lds_dwordx4) issued from inline asm: hipcc does not count it, so it inserts no
+// conservative `s_waitcnt vmcnt(0)` in front of later LDS reads; the kernel waits with
+// glds_wait<N>() itself before the barrier that publishes the stage.  LDS destination =
+// wave-uniform base + lane*16.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_base_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gptr), "s"(lds_base_uniform)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void glds_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ----------------------------------------------------------------------------
 // internal C++ launchers shared between translation units
 // ----------------------------------------------------------------------------
 int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,

@@ -145,61 +145,82 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 
 // ---------------------------------------------------------------------------
 // bf16 MFMA kernel
+//   BM x BN output tile, WM x WN waves, BKT (32|64) contraction elements per stage, NST-deep LDS ring.
+//   Stages are filled by LDS-DMA issued from inline asm and retired with COUNTED vmcnt waits, so up to
+//   NST-1 stages stay in flight across the per-step barrier (latency of an L2 miss >> one step).
+//   GM > 1: "grouped" tile order - consecutive blocks walk GM row-panels of one column-panel before
+//   moving to the next column-panel, so the set of co-resident blocks shares few A and B panels (L2).
 // ---------------------------------------------------------------------------
-constexpr int BK = 64;  // bf16 elements per K step = 128 B per tile row
+constexpr int BK = 64;  // K granularity required of the operands (leading dims are multiples of 64)
 
-template <int EPI, int BM, int BN, int WM, int WN>
+template <int BKT> __device__ __forceinline__ int kswz(int row);
+template <> __device__ __forceinline__ int kswz<64>(int row) { return (row >> 1) & 7; }
+template <> __device__ __forceinline__ int kswz<32>(int row) { return (row >> 2) & 3; }
+
+template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N,
     int K, int ksteps_per_split, EpiDev e) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][A_BYTES + B_BYTES]
+  constexpr int ROWB = BKT * 2;                 // bytes per tile row
+  constexpr int NCH = ROWB / 16;                // 16-B chunks per row
+  constexpr int RPI = 1024 / ROWB;              // rows per 1-KiB wave instruction
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / RPI / NW, B_INSTR = BN / RPI / NW, LPS = A_INSTR + B_INSTR;
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [NST][A_BYTES + B_BYTES]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int pm, pn;
+  if (GM > 1) {
+    const int per_group = GM * tiles_n;
+    const int grp = t / per_group, first = grp * GM;
+    const int gsz = min(GM, tiles_m - first);
+    const int r = t - grp * per_group;
+    pm = first + r % gsz;
+    pn = r / gsz;
+  } else {
+    pm = t / tiles_n;
+    pn = t % tiles_n;
+  }
+  const int m0 = pm * BM, n0 = pn * BN;
 
-  const int nk_total = K / BK;
-  const int kt0 = blockIdx.z * ksteps_per_split;
-  const int kt1 = min(nk_total, kt0 + ksteps_per_split);
+  const int nk_total = K / BKT;
+  const int spl = ksteps_per_split * (BK / BKT);
+  const int kt0 = blockIdx.z * spl;
+  const int kt1 = min(nk_total, kt0 + spl);
   if (EPI == TIMHIP_EPI_STORE_F32) e.out0 = (float*)e.out0 + (long long)blockIdx.z * e.slab_stride;
 
-  // ---- staging: each wave-instruction moves 8 rows x 128 B ----
-  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
-  const int lrow = lane >> 3, lchunk = lane & 7;
+  // ---- staging: each wave-instruction moves RPI rows x ROWB bytes ----
+  const int lrow = lane / NCH, lchunk = lane % NCH;
   const bf16_t* a_src[A_INSTR];
   const bf16_t* b_src[B_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
-    const int row = (wave * A_INSTR + i) * 8 + lrow;
-    const int c = lchunk ^ ((row >> 1) & 7);
+    const int row = (wave * A_INSTR + i) * RPI + lrow;
+    const int c = lchunk ^ kswz<BKT>(row);
     a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
   }
 #pragma unroll
   for (int i = 0; i < B_INSTR; ++i) {
-    const int row = (wave * B_INSTR + i) * 8 + lrow;
-    const int c = lchunk ^ ((row >> 1) & 7);
+    const int row = (wave * B_INSTR + i) * RPI + lrow;
+    const int c = lchunk ^ kswz<BKT>(row);
     b_src[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
   }
-
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int kt, int buf) {
-    char* base = lds + buf * (A_BYTES + B_BYTES);
+    const uint32_t base = lds0 + buf * ST_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * BK),
-          (__attribute__((address_space(3))) void*)(base + (wave * A_INSTR + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < A_INSTR; ++i) glds16(a_src[i] + (size_t)kt * BKT, base + (wave * A_INSTR + i) * 1024);
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(b_src[i] + (size_t)kt * BK),
-          (__attribute__((address_space(3))) void*)(base + A_BYTES + (wave * B_INSTR + i) * 1024), 16, 0, 0);
+      glds16(b_src[i] + (size_t)kt * BKT, base + A_BYTES + (wave * B_INSTR + i) * 1024);
   };
 
   f32x16_t acc[TN][TM];
@@ -216,38 +237,53 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int row = wm * (BM / WM) + j * 32 + frow;
-    a_off[j] = row * 128;
-    a_swz[j] = (row >> 1) & 7;
+    a_off[j] = row * ROWB;
+    a_swz[j] = kswz<BKT>(row);
   }
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int row = wn * (BN / WN) + i * 32 + frow;
-    b_off[i] = A_BYTES + row * 128;
-    b_swz[i] = (row >> 1) & 7;
+    b_off[i] = A_BYTES + row * ROWB;
+    b_swz[i] = kswz<BKT>(row);
   }
 
-  if (kt0 < kt1) stage(kt0, 0);
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    __syncthreads();  // stage(kt) landed (vmcnt(0)) and every wave is done reading buf^1
-    if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
-    const char* base = lds + buf * (A_BYTES + B_BYTES);
+  // prologue: NST-1 stages in flight
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8_t xa[TM], wb[TN];
+  for (int p = 0; p < NST - 1; ++p)
+    if (kt0 + p < kt1) stage(kt0 + p, p);
+  int buf = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    // stage kt must have landed; the (up to NST-2) younger stages may stay in flight
+    const int younger = min(NST - 2, kt1 - 1 - kt);
+    if (NST >= 4 && younger >= 2) glds_wait<2 * LPS>();
+    else if (NST >= 3 && younger >= 1) glds_wait<LPS>();
+    else glds_wait<0>();
+    __syncthreads();  // everybody's part of stage kt is in LDS; everybody finished reading stage kt-1
+    if (kt + NST - 1 < kt1) stage(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    const char* base = lds + buf * ST_BYTES;
+    // fragments are double-buffered in registers: the ds_reads of step kk+1 are in flight while
+    // the MFMAs of step kk run
+    bf16x8_t xa[2][TM], wb[2][TN];
+    auto load_frags = [&](int kk, int set) {
       const int c = kk * 2 + fhalf;
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        xa[j] = *reinterpret_cast<const bf16x8_t*>(base + a_off[j] + ((c ^ a_swz[j]) << 4));
+        xa[set][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off[j] + ((c ^ a_swz[j]) << 4));
 #pragma unroll
       for (int i = 0; i < TN; ++i)
-        wb[i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
+        wb[set][i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < BKT / 16; ++kk) {
+      if (kk + 1 < BKT / 16) load_frags(kk + 1, (kk + 1) & 1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i], xa[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk & 1][i], xa[kk & 1][j], acc[i][j], 0, 0, 0);
     }
+    buf = buf + 1 == NST ? 0 : buf + 1;
   }
 
   // ---- epilogue: D[i = n][j = m]; lane owns row m = lane & 31 ----
@@ -351,28 +387,27 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN>
+template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM>
 void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int splitk,
                  hipStream_t s) {
   const int nk = K / BK;
   const int per = (nk + splitk - 1) / splitk;
   dim3 grid(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splitk);
-  const size_t shmem = 2 * (BM + BN) * BK * 2;
+  const size_t shmem = (size_t)NST * (BM + BN) * BKT * 2;
   static bool attr_set = false;  // idempotent; a benign race sets it twice at worst
   if (!attr_set && shmem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN>), grid, dim3(WM * WN * 64), shmem, s,
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM>), grid, dim3(WM * WN * 64), shmem, s,
                      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, per, e);
 }
 
-// tile variants (bf16): 0 = 128x128 / 4 waves (default), others for tuning on selected epilogues
+// tile variants (bf16): 0 = default, others for tuning on selected epilogues
 template <int EPI>
 constexpr bool tunable() {
-  return EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_ADD_F32 || EPI == TIMHIP_EPI_STORE_F32 ||
-         EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_GELU_DROP_T2 || EPI == TIMHIP_EPI_DGELU_T;
+  return EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_ADD_F32 || EPI == TIMHIP_EPI_DROP_RES_F32;
 }
 
 template <int EPI>
@@ -387,15 +422,18 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
   } else {
     if constexpr (tunable<EPI>()) {
       switch (variant) {
-        case 1: launch_bf16<EPI, 256, 128, 4, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 2: launch_bf16<EPI, 256, 128, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 3: launch_bf16<EPI, 128, 256, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 4: launch_bf16<EPI, 256, 256, 4, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 5: launch_bf16<EPI, 256, 256, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        default: launch_bf16<EPI, 128, 128, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 1: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 2: launch_bf16<EPI, 128, 128, 2, 2, 32, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 3: launch_bf16<EPI, 256, 128, 4, 2, 64, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 4: launch_bf16<EPI, 256, 256, 2, 4, 32, 4, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 5: launch_bf16<EPI, 256, 256, 4, 2, 32, 4, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 6: launch_bf16<EPI, 256, 128, 4, 2, 32, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 7: launch_bf16<EPI, 128, 128, 2, 2, 64, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 8: launch_bf16<EPI, 256, 256, 2, 4, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
     } else {
-      launch_bf16<EPI, 128, 128, 2, 2>(A, lda, B, ldb, M, N, K, e, splitk, s);
+      launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
     }
   }
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;

@@ -134,9 +134,9 @@ __device__ __forceinline__ float act_grad_f(int act, float v) {
   return act == 1 ? (v > 0.f ? 1.f : 0.f) : (act == 2 ? gelu_grad_f(v) : 1.f);
 }
 
-constexpr int LN_MAXV = 8;  // float4 per lane: cols <= 2048
+constexpr int LN_MAXV_MAX = 8;  // float4 per lane: cols <= 2048 (kernels are instantiated for 1, 2, 4, 8)
 
-template <typename T>
+template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ y, int rows, int cols, int ldy,
                                                      int act, const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ xf, int ldx,
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ y
 // Backward.  A block owns ROWS_PB consecutive rows (one wave walks rows wave, wave+4, ...) and
 // reduces dgamma/dbeta over its rows in registers, then LDS across its 4 waves, then one atomic
 // per column per block.
-template <typename T>
+template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dx, int lddx,
                                                      const float* __restrict__ y, int ldy,
                                                      const float* __restrict__ stats, int rows, int cols, int act,
@@ -476,10 +476,13 @@ int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w,
                       const float* b, float* xf, int ldx, void* xt, int ldt, float* stats, hipStream_t s) {
   if (!y || !w || !b || rows <= 0) return TIMHIP_EINVAL;
-  if (cols % 4 || cols > 256 * LN_MAXV || ldy % 4 || (xf && ldx % 4) || (xt && ldt % 4)) return TIMHIP_EUNSUPPORTED;
+  if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || (xf && ldx % 4) || (xt && ldt % 4)) return TIMHIP_EUNSUPPORTED;
   dim3 grid((rows + 3) / 4);
-  DISPATCH_T(precision, hipLaunchKernelGGL(ln_fwd_kernel<T>, grid, dim3(256), 0, s, y, rows, cols, ldy, act, w, b,
-                                           xf, ldx, (T*)xt, ldt, stats));
+#define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, dim3(256), 0, s, y, rows, cols, ldy, act, w, b, \
+                                   xf, ldx, (T*)xt, ldt, stats)
+  const int nv = (cols + 255) / 256;
+  DISPATCH_T(precision, if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 4) LN_FWD(4); else LN_FWD(8));
+#undef LN_FWD
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
@@ -488,16 +491,18 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
                       float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, hipStream_t s) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
-  if (cols % 4 || cols > 256 * LN_MAXV || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
+  if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
     return TIMHIP_EUNSUPPORTED;
   const int rpb = 16;
   dim3 grid((rows + rpb - 1) / rpb);
   const size_t shmem = (size_t)4 * 2 * cols * sizeof(float);
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  DISPATCH_T(precision, hipLaunchKernelGGL(ln_bwd_kernel<T>, grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats,
-                                           rows, cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site,
-                                           dgamma, dbeta, rpb));
+#define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
+                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb)
+  const int nv = (cols + 255) / 256;
+  DISPATCH_T(precision, if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4); else LN_BWD(8));
+#undef LN_BWD
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

@@ -8,8 +8,7 @@
 //
 //   D[i = k][j = n] = sum_m X[m][k] dY[m][n]   ->  a lane owns one output row n of dW and 4
 //   consecutive k per accumulator quad: 16-byte fp32 stores.
-//   bias gradient: one extra MFMA per step with an all-ones A operand (no LDS traffic) in the
-//   blocks of the first k-tile column.
+//   bias gradient: the blocks of the first k-tile column also sum their dY fragments (registers).
 //
 // M is split across blockIdx.z; every split writes its partial tile into an fp32 slab with plain
 // coalesced stores and timhip's slab-reduce kernel adds the slabs into dW / db (no atomics).
@@ -40,50 +39,52 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
   const int s0 = blockIdx.z * steps_per_split;
   const int s1 = min(nsteps, s0 + steps_per_split);
 
-  // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk')
+  // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk').  Columns beyond the
+  // leading dimension read the zero page (stride 0); rows beyond M only occur in the last step.
   const int lrow = lane >> 4, lc = lane & 15;
-  int srow[4], ycol[4], xcol[4];
+  const bf16_t* ybase[4];
+  const bf16_t* xbase[4];
+  size_t ystr[4], xstr[4];
+  int srow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 4 + lrow;
     const int c = lc ^ swz<128>(row);
     srow[i] = row;
-    ycol[i] = n0 + c * 8;
-    xcol[i] = k0 + c * 8;
+    const bool yok = n0 + c * 8 < ldy, xok = k0 + c * 8 < ldx;
+    ybase[i] = yok ? dY + (size_t)row * ldy + n0 + c * 8 : zero_page;
+    xbase[i] = xok ? X + (size_t)row * ldx + k0 + c * 8 : zero_page;
+    ystr[i] = yok ? (size_t)ldy : 0;
+    xstr[i] = xok ? (size_t)ldx : 0;
   }
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int step, int buf) {
-    char* base = lds + buf * 2 * TILE_BYTES;
+    const uint32_t base = lds0 + buf * 2 * TILE_BYTES;
     const int m0 = step * WM;
+    const bool full = m0 + WM <= M;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + srow[i];
-      const bf16_t* py = (m < M && ycol[i] < ldy) ? dY + (size_t)m * ldy + ycol[i] : zero_page;
-      const bf16_t* px = (m < M && xcol[i] < ldx) ? X + (size_t)m * ldx + xcol[i] : zero_page;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)py,
-                                       (__attribute__((address_space(3))) void*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)px,
-                                       (__attribute__((address_space(3))) void*)(base + TILE_BYTES + (wave * 4 + i) * 1024),
-                                       16, 0, 0);
+      const bool rok = full || (m0 + srow[i] < M);
+      const bf16_t* py = rok ? ybase[i] + (size_t)m0 * ystr[i] : zero_page;
+      const bf16_t* px = rok ? xbase[i] + (size_t)m0 * xstr[i] : zero_page;
+      glds16(py, base + (wave * 4 + i) * 1024);
+      glds16(px, base + TILE_BYTES + (wave * 4 + i) * 1024);
     }
   };
 
-  f32x16_t acc[2][2], accb[2];
+  f32x16_t acc[2][2];
+  float bsum[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
-  bf16x8_t ones;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) ones[u] = (bf16_t)1.0f;
-
   if (s0 < s1) stage(s0, 0);
   for (int st = s0; st < s1; ++st) {
     const int buf = (st - s0) & 1;
+    glds_wait<0>();
     __syncthreads();
     if (st + 1 < s1) stage(st + 1, buf ^ 1);
     const char* sY = lds + buf * 2 * TILE_BYTES;
@@ -100,9 +101,11 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
-      if (do_bias && wk == 0) {
+      if (do_bias && wk == 0) {  // bias gradient: column sums of dY straight from the B fragments
 #pragma unroll
-        for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, yf[j], accb[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) bsum[j] += (float)yf[j][u];
       }
     }
   }
@@ -127,7 +130,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
             if (k + tt < K) out[(size_t)n * K + k + tt] = acc[i][j][4 * q + tt];
         }
       }
-    if (do_bias && wk == 0 && g == 0) db_slab[(size_t)blockIdx.z * N + n] = accb[j][0];
+    if (do_bias && wk == 0) {
+      const float t2 = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+      if (g == 0) db_slab[(size_t)blockIdx.z * N + n] = t2;
+    }
   }
 }
 
