@@ -203,6 +203,22 @@ int timhip_layer_bwd(const TimDesc* d, const TimLayerParams* w, const void* x_in
                      const void* saved, float* dx_out, float* dx_in, const TimLayerGrads* g,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Two-stream form of the layer backward.  The data chain (LayerNorm / GELU / attention backward and
+ * the input-gradient GEMMs) produces dx_in and leaves the four gradient operands df, du, da, dqkv in
+ * `dy` (timhip_layer_dy_bytes); the weight-gradient part consumes `dy` and the saved activations and
+ * may be enqueued on a second stream so that it overlaps the data chain of the next layer
+ * (the caller orders the two streams with events).  LayerNorm gradients are written by the data chain,
+ * all other parameter gradients by the weights part. */
+size_t timhip_layer_dy_bytes(const TimDesc* d);
+size_t timhip_layer_data_workspace_bytes(const TimDesc* d);
+size_t timhip_layer_wgrad_workspace_bytes(const TimDesc* d);
+int timhip_layer_bwd_data(const TimDesc* d, const TimLayerParams* w, const void* saved, float* dx_out,
+                          float* dx_in, void* dy, const TimLayerGrads* g, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int timhip_layer_bwd_weights(const TimDesc* d, const void* x_in_T, const void* saved, const void* dy,
+                             const TimLayerGrads* g, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ---- front end --------------------------------------------------------------
  * The time MLP (tim.py:66-74), the modality embedders and the sequence assembly
  * (encodings.py:41-75,102-121,181-251) are sequenced by the host mirror

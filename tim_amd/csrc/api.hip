@@ -149,7 +149,7 @@ const char* timhip_strerror(int code) {
 }
 
 size_t timhip_layer_saved_bytes(const TimDesc* d) { return d ? saved_layout(*d).total : 0; }
-size_t timhip_layer_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).total : 0; }
+size_t timhip_layer_workspace_bytes(const TimDesc* d);
 
 int timhip_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
                    const TimEpi* e, int splitk, void* stream) {
@@ -210,9 +210,29 @@ int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_
   return tim_layernorm_fwd(prec, y2, M, E, E, 0, w->n2_w, w->n2_b, x_out, E, x_out_T, E, st2, s);
 }
 
-int timhip_layer_bwd(const TimDesc* dp, const TimLayerParams* w, const void* x_in_T, const void* saved, float* dx_out,
-                     float* dx_in, const TimLayerGrads* g, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!dp || !w || !x_in_T || !saved || !dx_out || !dx_in || !g || !workspace) return TIMHIP_EINVAL;
+// gradient operands handed from the data chain to the weight-gradient part: df[M,E] | du[M,FF] | da[M,E] | dqkv[M,3E]
+struct DyLayout { size_t df, du, da, dqkv, total; };
+static DyLayout dy_layout(const TimDesc& d) {
+  const size_t M = (size_t)d.B * d.S, ts = opsize(d.precision);
+  DyLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+  L.df = take(M * d.E * ts);
+  L.du = take(M * d.FF * ts);
+  L.da = take(M * d.E * ts);
+  L.dqkv = take(M * 3 * d.E * ts);
+  L.total = off;
+  return L;
+}
+
+size_t timhip_layer_dy_bytes(const TimDesc* d) { return d ? dy_layout(*d).total : 0; }
+size_t timhip_layer_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).total + dy_layout(*d).total : 0; }
+size_t timhip_layer_data_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).total : 0; }
+size_t timhip_layer_wgrad_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).wg_bytes : 0; }
+
+int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void* saved, float* dx_out, float* dx_in,
+                          void* dy, const TimLayerGrads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !w || !saved || !dx_out || !dx_in || !dy || !g || !workspace) return TIMHIP_EINVAL;
   const TimDesc& d = *dp;
   int rc = check_layer_desc(d);
   if (rc) return rc;
@@ -221,46 +241,76 @@ int timhip_layer_bwd(const TimDesc* dp, const TimLayerParams* w, const void* x_i
   const int M = d.B * d.S, E = d.E, FF = d.FF, prec = d.precision;
   hipStream_t s = (hipStream_t)stream;
   const SavedLayout L = saved_layout(d);
+  const DyLayout Y = dy_layout(d);
   const char* sv = (const char*)saved;
   const void* qkv = sv + L.qkv; const void* o = sv + L.o; const float* lse = (const float*)(sv + L.lse);
   const float* y1 = (const float*)(sv + L.y1); const float* st1 = (const float*)(sv + L.st1);
-  const void* x1t = sv + L.x1t; const void* u = sv + L.u; const void* h = sv + L.h;
+  const void* u = sv + L.u;
   const float* y2 = (const float*)(sv + L.y2); const float* st2 = (const float*)(sv + L.st2);
   char* ws = (char*)workspace;
   float* f32a = (float*)(ws + W.f32a); float* f32b = (float*)(ws + W.f32b);
-  void* Ta = ws + W.Ta; void* Tb = ws + W.Tb; void* Tc = ws + W.Tc; void* wg = ws + W.tA;
+  void* Tc = ws + W.Tc;
+  char* yb = (char*)dy;
+  void* df = yb + Y.df; void* du = yb + Y.du; void* da = yb + Y.da; void* dqkv = yb + Y.dqkv;
 
   // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
-  if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, Tb, E, d.p_drop, d.seed,
+  if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, df, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b, s))) return rc;
-  // linear2: dW2 += df^T h, db2 += colsum df
-  if ((rc = wgrad(prec, Tb, E, E, h, FF, FF, M, g->l2_w, g->l2_b, wg, W.wg_bytes, s))) return rc;
   // du = (df W2) * dropout-mask * gelu'(u)
   TimEpi e = epi0();
-  e.out0 = Ta; e.ld0 = FF; e.aux = u; e.ldaux = FF;
+  e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DGELU_T, Tb, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
-  // linear1: dW1 += du^T x1, db1 += colsum du
-  if ((rc = wgrad(prec, Ta, FF, FF, x1t, E, E, M, g->l1_w, g->l1_b, wg, W.wg_bytes, s))) return rc;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DGELU_T, df, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
   // dx1 = du W1 + dy2   (residual branch)
   e = epi0();
   e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E;
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, Ta, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
   // norm1 backward -> dy1 (fp32) and da = dropout1-mask * dy1 (T)
-  if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, Tb, E, d.p_drop, d.seed,
+  if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, da, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b, s))) return rc;
-  // out-projection: dWo += da^T o, dbo += colsum da ; do = da Wo
-  if ((rc = wgrad(prec, Tb, E, E, o, E, E, M, g->out_w, g->out_b, wg, W.wg_bytes, s))) return rc;
+  // do = da Wo
   e = epi0();
   e.out0 = Tc; e.ld0 = E;
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, Tb, E, w->out_wt, E, M, E, E, e, 1, s))) return rc;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, da, E, w->out_wt, E, M, E, E, e, 1, s))) return rc;
   // attention backward -> dqkv
-  if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, Ta, ws + W.attn, W.total - W.attn, s))) return rc;
-  // in-projection: dWin += dqkv^T x_in, dbin += colsum dqkv ; dx_in = dqkv Win + dy1
-  if ((rc = wgrad(prec, Ta, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, wg, W.wg_bytes, s))) return rc;
+  if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, dqkv, ws + W.attn, W.total - W.attn, s))) return rc;
+  // dx_in = dqkv Win + dy1
   e = epi0();
   e.out0 = dx_in; e.ld0 = E; e.res = f32a; e.ldres = E;
-  return tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, Ta, 3 * E, w->in_wt, 3 * E, M, E, 3 * E, e, 1, s);
+  return tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, dqkv, 3 * E, w->in_wt, 3 * E, M, E, 3 * E, e, 1, s);
+}
+
+int timhip_layer_bwd_weights(const TimDesc* dp, const void* x_in_T, const void* saved, const void* dy,
+                             const TimLayerGrads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !x_in_T || !saved || !dy || !g || !workspace) return TIMHIP_EINVAL;
+  const TimDesc& d = *dp;
+  int rc = check_layer_desc(d);
+  if (rc) return rc;
+  const int M = d.B * d.S, E = d.E, FF = d.FF, prec = d.precision;
+  hipStream_t s = (hipStream_t)stream;
+  const SavedLayout L = saved_layout(d);
+  const DyLayout Y = dy_layout(d);
+  const char* sv = (const char*)saved;
+  const char* yb = (const char*)dy;
+  // linear2: dW2 += df^T h ; linear1: dW1 += du^T x1 ; out-proj: dWo += da^T o ; in-proj: dWin += dqkv^T x_in
+  if ((rc = wgrad(prec, yb + Y.df, E, E, sv + L.h, FF, FF, M, g->l2_w, g->l2_b, workspace, workspace_bytes, s))) return rc;
+  if ((rc = wgrad(prec, yb + Y.du, FF, FF, sv + L.x1t, E, E, M, g->l1_w, g->l1_b, workspace, workspace_bytes, s))) return rc;
+  if ((rc = wgrad(prec, yb + Y.da, E, E, sv + L.o, E, E, M, g->out_w, g->out_b, workspace, workspace_bytes, s))) return rc;
+  return wgrad(prec, yb + Y.dqkv, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, workspace, workspace_bytes, s);
+}
+
+// single-stream form: data chain followed by the weight gradients
+int timhip_layer_bwd(const TimDesc* dp, const TimLayerParams* w, const void* x_in_T, const void* saved, float* dx_out,
+                     float* dx_in, const TimLayerGrads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp) return TIMHIP_EINVAL;
+  const WsLayout W = ws_layout(*dp);
+  const size_t need = W.total + dy_layout(*dp).total;
+  if (workspace_bytes < need) return TIMHIP_EWORKSPACE;
+  char* ws = (char*)workspace;
+  void* dy = ws + W.total;
+  int rc = timhip_layer_bwd_data(dp, w, saved, dx_out, dx_in, dy, g, ws, W.total, stream);
+  if (rc) return rc;
+  return timhip_layer_bwd_weights(dp, x_in_T, saved, dy, g, ws + W.tA, W.wg_bytes, stream);
 }
 
 }  // extern "C"

@@ -157,7 +157,7 @@ template <int BKT> __device__ __forceinline__ int kswz(int row);
 template <> __device__ __forceinline__ int kswz<64>(int row) { return (row >> 1) & 7; }
 template <> __device__ __forceinline__ int kswz<32>(int row) { return (row >> 2) & 3; }
 
-template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM>
+template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N,
     int K, int ksteps_per_split, EpiDev e) {
@@ -252,18 +252,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   for (int p = 0; p < NST - 1; ++p)
     if (kt0 + p < kt1) stage(kt0 + p, p);
   int buf = 0;
+  bf16x8_t xa[2][TM], wb[2][TN];
   for (int kt = kt0; kt < kt1; ++kt) {
     // stage kt must have landed; the (up to NST-2) younger stages may stay in flight
     const int younger = min(NST - 2, kt1 - 1 - kt);
     if (NST >= 4 && younger >= 2) glds_wait<2 * LPS>();
     else if (NST >= 3 && younger >= 1) glds_wait<LPS>();
     else glds_wait<0>();
-    __syncthreads();  // everybody's part of stage kt is in LDS; everybody finished reading stage kt-1
-    if (kt + NST - 1 < kt1) stage(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
-    const char* base = lds + buf * ST_BYTES;
+    if (ABL < 4) __syncthreads();  // everybody's part of stage kt is in LDS; everybody finished reading stage kt-1
+    if ((ABL & 1) == 0 && kt + NST - 1 < kt1) stage(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    const char* base = lds + ((ABL & 1) ? 0 : buf) * ST_BYTES;
     // fragments are double-buffered in registers: the ds_reads of step kk+1 are in flight while
     // the MFMAs of step kk run
-    bf16x8_t xa[2][TM], wb[2][TN];
     auto load_frags = [&](int kk, int set) {
       const int c = kk * 2 + fhalf;
 #pragma unroll
@@ -273,15 +273,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
       for (int i = 0; i < TN; ++i)
         wb[set][i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
     };
-    load_frags(0, 0);
+    if ((ABL & 2) == 0 || kt == kt0) load_frags(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BKT / 16; ++kk) {
-      if (kk + 1 < BKT / 16) load_frags(kk + 1, (kk + 1) & 1);
+      if (((ABL & 2) == 0 || kt == kt0) && kk + 1 < BKT / 16) load_frags(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // the next step's ds_reads are issued BEFORE this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk & 1][i], xa[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
   }
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM>
+template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
 void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int splitk,
                  hipStream_t s) {
   const int nk = K / BK;
@@ -396,11 +398,11 @@ void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, i
   const size_t shmem = (size_t)NST * (BM + BN) * BKT * 2;
   static bool attr_set = false;  // idempotent; a benign race sets it twice at worst
   if (!attr_set && shmem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM>), grid, dim3(WM * WN * 64), shmem, s,
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>), grid, dim3(WM * WN * 64), shmem, s,
                      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, per, e);
 }
 
@@ -420,6 +422,19 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
     hipLaunchKernelGGL(gemm_nt_f32_kernel<EPI>, grid, dim3(256), 0, s, (const float*)A, lda,
                        (const float*)B, ldb, M, N, K, per, e);
   } else {
+#ifdef TIMHIP_TUNING
+    if constexpr (EPI == TIMHIP_EPI_STORE_T) {  // ablation builds (tools/gemm_abl.py): variant = 100*ABL + tile
+#define ABLV(T, ...) case T: launch_bf16<EPI, __VA_ARGS__>(A, lda, B, ldb, M, N, K, e, splitk, s); return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+      switch (variant) {
+        ABLV(100, 128, 128, 2, 2, 64, 2, 1, 1) ABLV(200, 128, 128, 2, 2, 64, 2, 1, 2) ABLV(300, 128, 128, 2, 2, 64, 2, 1, 3)
+        ABLV(700, 128, 128, 2, 2, 64, 2, 1, 7)
+        ABLV(207, 128, 128, 2, 2, 64, 4, 8, 2) ABLV(208, 256, 256, 2, 4, 64, 2, 4, 2) ABLV(205, 256, 256, 4, 2, 32, 4, 4, 2)
+        ABLV(203, 256, 128, 4, 2, 64, 3, 8, 2) ABLV(202, 128, 128, 2, 2, 32, 4, 8, 2)
+        ABLV(108, 256, 256, 2, 4, 64, 2, 4, 1) ABLV(308, 256, 256, 2, 4, 64, 2, 4, 3)
+        default: break;
+      }
+#undef ABLV
+    }
     if constexpr (tunable<EPI>()) {
       switch (variant) {
         case 1: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
@@ -432,7 +447,10 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
         case 8: launch_bf16<EPI, 256, 256, 2, 4, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
-    } else {
+    } else
+#endif
+    {
+      (void)variant;
       launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
     }
   }
@@ -467,7 +485,10 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   e.vec = vec ? 1 : 0;
   if (e.thr != 0u && (N % 4) != 0) return TIMHIP_EUNSUPPORTED;
   int variant = 0;
-  if (const char* v = getenv("TIMHIP_GEMM_VARIANT")) variant = atoi(v);  // tuning knob
+#ifdef TIMHIP_TUNING  // tools/gemm_tune.py, tools/gemm_abl.py: make -C tim_amd/csrc TUNING=1
+  if (const char* v = getenv("TIMHIP_GEMM_VARIANT")) variant = atoi(v);
+  if (getenv("TIMHIP_GEMM_ALIAS")) { lda = 0; ldb = 0; }  // every operand row aliases row 0 (cache-resident)
+#endif
   switch (epi) {
 #define CASE(X) case X: return launch<X>(precision, variant, A, lda, B, ldb, M, N, Kp, e, splitk, s);
     CASE(TIMHIP_EPI_STORE_T)

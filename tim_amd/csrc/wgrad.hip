@@ -89,24 +89,30 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
     if (st + 1 < s1) stage(st + 1, buf ^ 1);
     const char* sY = lds + buf * 2 * TILE_BYTES;
     const char* sX = sY + TILE_BYTES;
+    bf16x8_t xf[2][2], yf[2][2];
+    auto load_frags = [&](int ms, int set) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xf[set][i] = tr_frag<128>(sX, ms * 16, wk * 2 + i, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) yf[set][j] = tr_frag<128>(sY, ms * 16, wn * 2 + j, lane);
+    };
+    load_frags(0, 0);
 #pragma unroll
     for (int ms = 0; ms < WM / 16; ++ms) {
-      bf16x8_t xf[2], yf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) xf[i] = tr_frag<128>(sX, ms * 16, wk * 2 + i, lane);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) yf[j] = tr_frag<128>(sY, ms * 16, wn * 2 + j, lane);
+      if (ms + 1 < WM / 16) load_frags(ms + 1, (ms + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ms & 1][i], yf[ms & 1][j], acc[i][j], 0, 0, 0);
       if (do_bias && wk == 0) {  // bias gradient: column sums of dY straight from the B fragments
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) bsum[j] += (float)yf[j][u];
+          for (int u = 0; u < 8; ++u) bsum[j] += (float)yf[ms & 1][j][u];
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

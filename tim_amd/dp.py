@@ -39,12 +39,14 @@ class DataParallel(nn.Module):
             self._comm = torch.cuda.Stream(device=dev)
         return self._comm
 
-    def _on_bucket(self, name, flat):
+    def _on_bucket(self, name, flat, ready=None):
         if self.world == 1:
             return
         if flat.is_cuda:
             comm = self._comm_stream(flat.device)
             comm.wait_stream(torch.cuda.current_stream())
+            if ready is not None:
+                comm.wait_event(ready)  # weight gradients written on the side stream
             with torch.cuda.stream(comm):
                 flat.div_(self.world)
                 dist.all_reduce(flat, group=self.pg)

@@ -39,6 +39,16 @@ class Runtime:
         self.step = 0
         self.bucket_hook = None  # callable(bucket_name, flat_grad_tensor) -> None
         self.finish_hook = None  # callable() -> None, called at the end of the encoder backward
+        # weight-gradient GEMMs of layer l run on a side stream, overlapping the data chain of layer l-1
+        self.overlap_wgrad = True
+        self._aux = {}
+
+    def aux_stream(self, dev):
+        st = self._aux.get(dev)
+        if st is None:
+            st = torch.cuda.Stream(device=dev)
+            self._aux[dev] = st
+        return st
 
     # ---- buffers -------------------------------------------------------------------------------
     def zeros_op(self, rows, cols, dev):
@@ -460,21 +470,55 @@ class EncoderFn(torch.autograd.Function):
             call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
         grads.done("heads")
 
-        # ---- layers, last to first; each layer's bucket is handed to the hook as soon as it is complete
+        # ---- layers, last to first.  Per layer: the data chain on the current stream, the four
+        # weight-gradient GEMMs on a side stream (they overlap the data chain of the next layer);
+        # each layer's bucket is handed to the hook as soon as its weight gradients are enqueued.
         desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, 0)
-        ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
-        ws = model._workspace(ws_bytes, dev)
+        lib = L.load()
         dx2 = torch.empty_like(dx)
         stack = model._stack_prefix
+        main = torch.cuda.current_stream()
+        overlap = rt.overlap_wgrad
+        keep_alive = []
+        if overlap:
+            aux = rt.aux_stream(dev)
+            dws_bytes = lib.timhip_layer_data_workspace_bytes(C.byref(desc))
+            wws_bytes = lib.timhip_layer_wgrad_workspace_bytes(C.byref(desc))
+            dy_bytes = lib.timhip_layer_dy_bytes(C.byref(desc))
+            ws = model._workspace(dws_bytes, dev)
+            wws = model._workspace(wws_bytes, dev, slot="wgrad")
+            dys = [model._workspace(dy_bytes, dev, slot="dy0"), model._workspace(dy_bytes, dev, slot="dy1")]
+            done = {}
+            aux.wait_stream(main)  # gradient buckets were zeroed on the main stream
+        else:
+            ws_bytes = lib.timhip_layer_workspace_bytes(C.byref(desc))
+            ws = model._workspace(ws_bytes, dev)
         for l in reversed(range(Lyr)):
             pre = "%s.layers.%d." % (stack, l)
             lg = L.TimLayerGrads(*[ptr(G[pre + n]) for n in model._LAYER_GRAD_NAMES])
             desc.layer = l
-            call("timhip_layer_bwd", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.xs_t[l]),
-                 ptr(ctx.layer_saved[l]), ptr(dx), ptr(dx2), C.byref(lg), ptr(ws), ws_bytes, st)
+            if overlap:
+                dyb = dys[l & 1]
+                if l + 2 in done:
+                    main.wait_event(done[l + 2])  # the weight gradients of layer l+2 no longer read this dy
+                call("timhip_layer_bwd_data", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.layer_saved[l]),
+                     ptr(dx), ptr(dx2), ptr(dyb), C.byref(lg), ptr(ws), dws_bytes, main.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                aux.wait_event(ev)
+                call("timhip_layer_bwd_weights", C.byref(desc), ptr(ctx.xs_t[l]), ptr(ctx.layer_saved[l]), ptr(dyb),
+                     C.byref(lg), ptr(wws), wws_bytes, aux.cuda_stream)
+                dn = torch.cuda.Event()
+                dn.record(aux)
+                done[l] = dn
+                keep_alive.append(ctx.layer_saved[l])
+                grads.done("layer%d" % l, ready=dn)
+            else:
+                call("timhip_layer_bwd", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.xs_t[l]),
+                     ptr(ctx.layer_saved[l]), ptr(dx), ptr(dx2), C.byref(lg), ptr(ws), ws_bytes, st)
+                grads.done("layer%d" % l)
             dx, dx2 = dx2, dx
             ctx.layer_saved[l] = None
-            grads.done("layer%d" % l)
 
         # ---- sequence assembly backward
         ncls, nmod = len(plan.cls_names), len(plan.mod_names)
@@ -508,6 +552,9 @@ class EncoderFn(torch.autograd.Function):
                 call("timhip_dropout_rows_bwd", ptr(gx), R, Cin, Cin, ptr(dxin), Cin, p_feat, seed, site, st)
                 d_inputs[name] = dxin.view(B, nf, Cin)
         grads.done("front")
+        if overlap:
+            main.wait_stream(aux)  # all weight gradients are complete before autograd sees them
+        del keep_alive
         if rt.finish_hook is not None:
             rt.finish_hook()
         out = [None, None, None, d_inputs["visual"], d_inputs["audio"], d_te if ctx.needs_input_grad[5] else None]

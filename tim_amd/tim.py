@@ -163,9 +163,10 @@ class _GradBuckets:
             self.views[n] = self.flat[b][off[b]:off[b] + p.numel()].view(p.shape)
             off[b] += (p.numel() + 3) // 4 * 4
 
-    def done(self, bucket):
+    def done(self, bucket, ready=None):
+        """`ready`: event after which the side-stream part of the bucket is complete (None: current stream)"""
         if self.rt.bucket_hook is not None and bucket in self.flat:
-            self.rt.bucket_hook(bucket, self.flat[bucket])
+            self.rt.bucket_hook(bucket, self.flat[bucket], ready)
 
 
 class TIM(nn.Module):
@@ -247,11 +248,12 @@ class TIM(nn.Module):
             self._plans[key] = p
         return p
 
-    def _workspace(self, nbytes, dev):
-        w = self._ws.get(dev)
+    def _workspace(self, nbytes, dev, slot="main"):
+        key = (dev, slot)
+        w = self._ws.get(key)
         if w is None or w.numel() < nbytes:
-            w = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._ws[dev] = w
+            w = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+            self._ws[key] = w
         return w
 
     @staticmethod
