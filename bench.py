@@ -133,7 +133,7 @@ def gemm_roofline(model, cfg, B, nv, na, precision, reps=20):
     return out, tot_flop, tot_ms
 
 
-def cpu_baseline(cfg, sd_np, nv, na, budget_s=20.0):
+def cpu_baseline(cfg, sd_np, nv, na, budget_s=12.0):
     """The oracle (torch CPU fp32 restatement, kind "port") timed on this box's host cores on a bounded
     sample of the same workload: fwd+bwd of B=4 windows of the same shapes."""
     from oracle import tim_oracle as O
@@ -158,7 +158,7 @@ def cpu_baseline(cfg, sd_np, nv, na, budget_s=20.0):
     while True:
         one()
         n += 1
-        if time.time() - t0 > budget_s or n >= 16:
+        if time.time() - t0 > budget_s or n >= 64:
             break
     dt = time.time() - t0
     return {"value": round(B * (nv + na) * n / dt, 2), "unit": "interval-queries/s", "cores": cores, "kind": "port",

@@ -1,0 +1,97 @@
+"""Data-parallel gradient-bucket logic on CPU: 2 processes, gloo backend.
+
+The HIP kernels cannot run here, so the test drives exactly the host-side pieces that the
+multi-GPU path adds on top of the single-GPU backward: the per-layer flat gradient buckets
+(views handed to the kernels), the bucket hook that averages a bucket across ranks as soon as
+it is complete, and the flat reduction of the few parameters outside the encoder Function.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import helpers as H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.manual_seed(0)
+        from tim_amd.dp import DataParallel
+        from tim_amd.tim import TIM, _GradBuckets
+        cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+        m = TIM(cfg.num_class, visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2, num_feats=6)
+        dp = DataParallel(m)
+        assert dp.world == world and m.rt.bucket_hook is not None
+        names = m._encoder_param_names
+        params = m._encoder_param_list()
+        # every rank has the same parameters (same seed) ...
+        flat0 = torch.cat([p.detach().reshape(-1) for p in params])
+        ref = flat0.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(ref, flat0)
+        # ... buckets: one per layer + front + heads, views alias the flat buffers
+        gb = _GradBuckets(m.rt, names, params, torch.device("cpu"), m._bucket_of)
+        assert set(gb.flat) == {"front", "heads", "layer0", "layer1"}
+        for i, n in enumerate(names):
+            gb.views[n].fill_(float(i + 1) * (rank + 1))  # what the kernels would have accumulated
+        for b in ("heads", "layer1", "layer0", "front"):  # order in which the backward completes them
+            gb.done(b)
+        mean = (1 + world) / 2.0
+        for i, n in enumerate(names):
+            v = gb.views[n]
+            assert v.shape == dict(zip(names, params))[n].shape
+            assert torch.allclose(v, torch.full_like(v, (i + 1) * mean)), n
+        # the few parameters outside the encoder Function (time MLP, DRLoc MLP): one flat all-reduce
+        for j, p in enumerate(dp._small):
+            p.grad = torch.full_like(p, float(j + 1) * (rank + 1))
+        dp._reduce_small()
+        for j, p in enumerate(dp._small):
+            assert torch.allclose(p.grad, torch.full_like(p, (j + 1) * mean))
+        assert len(dp._small) == 8 + 6
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def test_two_rank_gradient_buckets_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def test_bench_shards_windows_across_ranks():
+    """bench.py gives every rank its own windows (weak scaling, no data-path collective)."""
+    import numpy as np
+    from tim_amd import synth
+    from tim_amd.config import named_config
+    cfg = named_config("tiny")
+    a = synth.make_inputs(cfg, 2, 4, 2, seed=100)
+    b = synth.make_inputs(cfg, 2, 4, 2, seed=101)
+    assert not np.allclose(a["visual"], b["visual"])
+    assert np.allclose(a["times"][:, :12], b["times"][:, :12])  # feature times are the window grid

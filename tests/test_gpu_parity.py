@@ -253,3 +253,69 @@ def test_cpu_input_fails_loudly():
             input_modality="visual", data_modality="visual", num_feats=6)
     with pytest.raises(TimHipError):
         m(inp["times"], "time_mlp")
+
+
+# ------------------------------------------------------------------------------------------------
+# detection variant (dense query pyramid, regression heads)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("im,dm,nc,tag", H.DET_CASES)
+def test_tiny_detection_fp32_vs_golden_reference(im, dm, nc, tag):
+    g = np.load(os.path.join(H.GOLDEN, "tiny_det_%s_%s_%s.npz" % (im, dm, tag)))
+    cfg = H.tiny_cfg("detection", im, dm, tag == "vn", num_class=nc)
+    sd, inp = H.synth_torch(cfg, 2, 0, 0, seed=3, dtype=torch.float64)
+    m = build(cfg, "fp32", sd)
+    assert m.num_queries == 399
+    vis = inp["visual"].to(DEV).float()
+    aud = inp["audio"].to(DEV).float()
+    if vis.dim() == 3:
+        vis.requires_grad_(True)
+    if aud.dim() == 3:
+        aud.requires_grad_(True)
+    (cls, reg, feats), offs, labels, queries, ious = m([vis, aud], "encoder", inp["times"].to(DEV).float(), None,
+                                                       label_queries=False)
+    outs = H.named_outputs(cls, feats, reg)
+    assert set(outs) == {k[4:] for k in g.files if k.startswith("out/")}
+    for k, v in outs.items():
+        assert maxerr(v.detach().cpu(), torch.from_numpy(g["out/" + k])) <= TOL_FP32 * max(1.0, amax(torch.from_numpy(g["out/" + k]))), k
+    R = H.cotangents(cfg, 2, 0, 0, {k: v.detach().cpu() for k, v in outs.items()}, seed=3, dtype=torch.float32)
+    loss = sum((outs[k] * R[k].to(DEV)).sum() for k in outs)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3 * max(1.0, abs(float(g["loss"])))
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    for k in g.files:
+        if k.startswith("grad/") and g[k].ndim > 0:
+            assert relerr(grads[k[5:]], torch.from_numpy(g[k])) <= 2e-4, k
+        elif k.startswith("grad/"):
+            n = grads[k[5:]].double().norm().item()
+            assert abs(n - float(g[k])) <= 2e-4 * max(1.0, float(g[k])), k
+    if vis.dim() == 3 and "gin/visual" in g.files:
+        assert relerr(vis.grad.cpu(), torch.from_numpy(g["gin/visual"])) <= 2e-4
+
+
+def test_c4_detection_bf16_long_sequence():
+    """BASELINE configs[3]: 399 dense interval queries per window (S = 499), bf16 path vs the oracle and the
+    committed slices of the fp32 reference."""
+    g = np.load(os.path.join(H.GOLDEN, "C4_det_summary.npz"))
+    cfg = named_config("C4")
+    sd, inp = H.synth_torch(cfg, 1, 0, 0, seed=4, dtype=torch.float32)
+    q = O.generate_queries(0.01)
+    times = torch.cat([inp["times"], q.expand(1, -1, -1)], 1)
+    with torch.no_grad():
+        cls32, feats32, reg32 = O.forward(sd, cfg, inp["visual"], inp["audio"], times, 399, 0)
+        clsbf, featsbf, regbf = O.forward(sd, cfg, inp["visual"], inp["audio"], times, 399, 0, rd=torch.bfloat16)
+    assert maxerr(cls32[2][:, :8], torch.from_numpy(g["out/action/slice"])) <= 5e-5
+    for prec in ("fp32", "bf16"):
+        m = build(cfg, prec, sd)
+        with torch.no_grad():
+            (cls, reg, feats), _, _, _, _ = m([inp["visual"].to(DEV), inp["audio"].to(DEV)], "encoder",
+                                              inp["times"].to(DEV), None, label_queries=False)
+        torch.cuda.synchronize()
+        a, r = cls[2].cpu(), reg[0].cpu()
+        if prec == "fp32":
+            assert maxerr(a, cls32[2]) <= TOL_FP32 * max(1.0, amax(cls32[2]))
+            assert maxerr(r, reg32[0]) <= TOL_FP32
+        else:
+            pred = maxerr(clsbf[2], cls32[2])
+            assert maxerr(a, cls32[2]) <= max(2.0 * pred, 1e-3), (maxerr(a, cls32[2]), pred)
+            assert maxerr(r, reg32[0]) <= 2e-2
