@@ -178,10 +178,20 @@ def test_named_config_bf16(cname, B, nv, na):
     cfg = named_config(cname)
     sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
     m = build(cfg, "bf16", sd)
-    res = run_model(m, inp, nv, na, grads=False)
     with torch.no_grad():
         obf = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na, rd=torch.bfloat16))
         o32 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+    R = H.cotangents(cfg, B, nv, na, o32, seed=2, dtype=torch.float32)
+    res = run_model(m, inp, nv, na, True, R)
+    _, _, g32, _ = oracle_run(cfg, sd, inp, nv, na, R, torch.float32)
+    for k, v in res["grads"].items():
+        # every parameter gradient: bf16 noise class.  Gradient signals are rounded to bf16 at ~30 GEMM inputs on
+        # the way down to the time MLP, so the bound is on direction (cosine) and on the worst element relative to
+        # the tensor's largest element.
+        a, b = v.double().flatten(), g32[k].double().flatten()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        assert cos >= 0.995, (k, cos)
+        assert relerr(v, g32[k]) <= 0.2, (k, relerr(v, g32[k]))
     for k, v in res["outs"].items():
         # 6 layers deep, two bf16 evaluations decorrelate through rounding flips, so the bound is the
         # bf16 quantisation-noise class itself: the HIP path must be no further from the fp32 oracle

@@ -175,6 +175,53 @@ __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_base_unifo
       : "v"(gptr), "s"(lds_base_uniform)
       : "memory");
 }
+// make a wave-uniform pointer provably uniform (SGPR pair) for the "s" constraints below
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const void*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+// SGPR base (wave-uniform 64-bit address) + per-lane 32-bit byte offset: the per-step address update is
+// one scalar add instead of a 64-bit vector add per load.
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_base_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base_uniform)
+      : "memory");
+}
+// four loads to LDS base, base+1 KiB, +2 KiB, +3 KiB with one M0 save/restore
+__device__ __forceinline__ void glds16_x4(const void* sbase, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+                                          uint32_t lds_base_uniform) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %6\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %3, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %4, %5\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(sbase), "s"(lds_base_uniform)
+      : "memory", "scc");
+}
+template <int N>
+__device__ __forceinline__ void glds16_xn(const void* sbase_, const uint32_t (&off)[N], uint32_t lds_base_uniform) {
+  const void* sbase = uniform_ptr(sbase_);
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) glds16_x4(sbase, off[i], off[i + 1], off[i + 2], off[i + 3], lds_base_uniform + i * 1024);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) glds16_s(sbase, off[i], lds_base_uniform + i * 1024);
+  }
+}
 template <int N>
 __device__ __forceinline__ void glds_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

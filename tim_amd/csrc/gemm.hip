@@ -199,28 +199,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
 
   // ---- staging: each wave-instruction moves RPI rows x ROWB bytes ----
   const int lrow = lane / NCH, lchunk = lane % NCH;
-  const bf16_t* a_src[A_INSTR];
-  const bf16_t* b_src[B_INSTR];
+  uint32_t a_off32[A_INSTR], b_off32[B_INSTR];  // per-lane byte offsets; the K advance is a scalar add on the base
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
     const int row = (wave * A_INSTR + i) * RPI + lrow;
     const int c = lchunk ^ kswz<BKT>(row);
-    a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+    a_off32[i] = (uint32_t)(((size_t)min(m0 + row, M - 1) * lda + c * 8) * 2);
   }
 #pragma unroll
   for (int i = 0; i < B_INSTR; ++i) {
     const int row = (wave * B_INSTR + i) * RPI + lrow;
     const int c = lchunk ^ kswz<BKT>(row);
-    b_src[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
+    b_off32[i] = (uint32_t)(((size_t)min(n0 + row, N - 1) * ldb + c * 8) * 2);
   }
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int kt, int buf) {
     const uint32_t base = lds0 + buf * ST_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) glds16(a_src[i] + (size_t)kt * BKT, base + (wave * A_INSTR + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i)
-      glds16(b_src[i] + (size_t)kt * BKT, base + A_BYTES + (wave * B_INSTR + i) * 1024);
+    glds16_xn<A_INSTR>(reinterpret_cast<const char*>(A) + (size_t)kt * BKT * 2, a_off32, base + wave * A_INSTR * 1024);
+    glds16_xn<B_INSTR>(reinterpret_cast<const char*>(B) + (size_t)kt * BKT * 2, b_off32,
+                       base + A_BYTES + wave * B_INSTR * 1024);
   };
 
   f32x16_t acc[TN][TM];
@@ -468,6 +465,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   const int Kp = round_up(K, 64);
   if (lda % 64 || ldb % 64 || lda < Kp || ldb < Kp) return TIMHIP_EALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return TIMHIP_EALIGN;
+  if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return TIMHIP_EUNSUPPORTED;  // 32-bit lane offsets
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && epi != TIMHIP_EPI_ATOMIC_F32 && epi != TIMHIP_EPI_STORE_F32) return TIMHIP_EINVAL;
   EpiDev e;

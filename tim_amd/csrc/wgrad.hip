@@ -39,36 +39,38 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
   const int s0 = blockIdx.z * steps_per_split;
   const int s1 = min(nsteps, s0 + steps_per_split);
 
-  // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk').  Columns beyond the
-  // leading dimension read the zero page (stride 0); rows beyond M only occur in the last step.
+  // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk').  Column chunks beyond the
+  // leading dimension are clamped (they only feed output columns that are never stored); rows beyond M
+  // (last step only) must contribute zeros and read the zero page.
   const int lrow = lane >> 4, lc = lane & 15;
-  const bf16_t* ybase[4];
-  const bf16_t* xbase[4];
-  size_t ystr[4], xstr[4];
+  uint32_t yoff[4], xoff[4];
   int srow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wave * 4 + i) * 4 + lrow;
     const int c = lc ^ swz<128>(row);
     srow[i] = row;
-    const bool yok = n0 + c * 8 < ldy, xok = k0 + c * 8 < ldx;
-    ybase[i] = yok ? dY + (size_t)row * ldy + n0 + c * 8 : zero_page;
-    xbase[i] = xok ? X + (size_t)row * ldx + k0 + c * 8 : zero_page;
-    ystr[i] = yok ? (size_t)ldy : 0;
-    xstr[i] = xok ? (size_t)ldx : 0;
+    yoff[i] = (uint32_t)(((size_t)row * ldy + min(n0 + c * 8, ldy - 8)) * 2);
+    xoff[i] = (uint32_t)(((size_t)row * ldx + min(k0 + c * 8, ldx - 8)) * 2);
   }
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int step, int buf) {
-    const uint32_t base = lds0 + buf * 2 * TILE_BYTES;
+    const uint32_t base = lds0 + buf * 2 * TILE_BYTES + wave * 4096;
     const int m0 = step * WM;
-    const bool full = m0 + WM <= M;
+    if (m0 + WM <= M) {
+      glds16_xn<4>(reinterpret_cast<const char*>(dY) + (size_t)m0 * ldy * 2, yoff, base);
+      glds16_xn<4>(reinterpret_cast<const char*>(X) + (size_t)m0 * ldx * 2, xoff, base + TILE_BYTES);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool rok = full || (m0 + srow[i] < M);
-      const bf16_t* py = rok ? ybase[i] + (size_t)m0 * ystr[i] : zero_page;
-      const bf16_t* px = rok ? xbase[i] + (size_t)m0 * xstr[i] : zero_page;
-      glds16(py, base + (wave * 4 + i) * 1024);
-      glds16(px, base + TILE_BYTES + (wave * 4 + i) * 1024);
+      for (int i = 0; i < 4; ++i) {
+        const bool rok = m0 + srow[i] < M;
+        const char* py = rok ? reinterpret_cast<const char*>(dY) + (size_t)m0 * ldy * 2 + yoff[i]
+                             : reinterpret_cast<const char*>(zero_page);
+        const char* px = rok ? reinterpret_cast<const char*>(X) + (size_t)m0 * ldx * 2 + xoff[i]
+                             : reinterpret_cast<const char*>(zero_page);
+        glds16(py, base + i * 1024);
+        glds16(px, base + TILE_BYTES + i * 1024);
+      }
     }
   };
 
@@ -81,6 +83,22 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
+  // per-lane byte offsets of the first transposing read of each fragment (rows 0..7 of a 16-row slice)
+  int xtr[2][2], ytr[2][2];  // [fragment][rows 0-7 | rows 8-15]
+  {
+    const int gid = lane >> 4, p = lane & 15, g = gid >> 1;
+    const int row0 = 4 * g + (p >> 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cx = 4 * (wk * 2 + i) + 2 * (gid & 1) + ((p & 3) >> 1);
+      const int cy = 4 * (wn * 2 + i) + 2 * (gid & 1) + ((p & 3) >> 1);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        xtr[i][hh] = tile_off<128>(row0 + 8 * hh, cx) + (p & 1) * 8;
+        ytr[i][hh] = tile_off<128>(row0 + 8 * hh, cy) + (p & 1) * 8;
+      }
+    }
+  }
   if (s0 < s1) stage(s0, 0);
   for (int st = s0; st < s1; ++st) {
     const int buf = (st - s0) & 1;
@@ -91,10 +109,13 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
     const char* sX = sY + TILE_BYTES;
     bf16x8_t xf[2][2], yf[2][2];
     auto load_frags = [&](int ms, int set) {
+      // rows advance by 16 per ms (16*256 B) and swz<128>(row + 16) == swz<128>(row): immediates
 #pragma unroll
-      for (int i = 0; i < 2; ++i) xf[set][i] = tr_frag<128>(sX, ms * 16, wk * 2 + i, lane);
+      for (int i = 0; i < 2; ++i)
+        xf[set][i] = cat8(tr_read(sX + xtr[i][0] + ms * 4096), tr_read(sX + xtr[i][1] + ms * 4096));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) yf[set][j] = tr_frag<128>(sY, ms * 16, wn * 2 + j, lane);
+      for (int j = 0; j < 2; ++j)
+        yf[set][j] = cat8(tr_read(sY + ytr[j][0] + ms * 4096), tr_read(sY + ytr[j][1] + ms * 4096));
     };
     load_frags(0, 0);
 #pragma unroll
