@@ -52,7 +52,7 @@ def step_fn(model, batch, nv, na, R):
     inner = model.module if hasattr(model, "module") else model
     for p in inner.parameters():
         p.grad = None
-    inner.rt._wcache.clear()  # weights changed (optimizer step): redo the operand copies
+    inner.rt.invalidate_weights()  # weights changed (optimizer step): redo the operand copies
     te = model(batch["times"], "time_mlp")
     (verb, noun, action, audio), feats = model([batch["visual"], batch["audio"]], "encoder", te, nv, na)
     outs = [t for t in (verb, noun, action, audio, feats) if t is not None]

@@ -117,6 +117,11 @@ size_t timhip_layer_workspace_bytes(const TimDesc* d);
 int timhip_cast_weight(int precision, const float* src, int rows, int cols, void* dst, int ld,
                        int transpose, void* stream);
 
+/* both operand copies of one fp32 weight [rows, cols] in a single pass:
+ * plain[rows, ldp] = cast(src), tr[cols, ldt] = cast(src^T), zero padded; ldp, ldt multiples of 64 */
+int timhip_cast_weight_both(int precision, const float* src, int rows, int cols, void* plain, int ldp,
+                            void* tr, int ldt, void* stream);
+
 /* ---------------------------------------------------------------- generic ops (also unit-test hooks) */
 typedef struct TimEpi {
   void* out0;

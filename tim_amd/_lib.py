@@ -51,6 +51,7 @@ _SIGS = {
     "timhip_layer_saved_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_layer_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_cast_weight": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, vp]),
+    "timhip_cast_weight_both": (C.c_int, [i32, vp, i32, i32, vp, i32, vp, i32, vp]),
     "timhip_gemm_nt": (C.c_int, [i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(TimEpi), i32, vp]),
     "timhip_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, sz, vp]),

@@ -58,7 +58,7 @@ WgradWs wgrad_ws(int prec, int Nout, int Kout, int M) {
 }
 
 struct WsLayout {
-  size_t f32a, f32b, Ta, Tb, Tc, tA, tB, attn, total, wg_bytes;
+  size_t f32a, f32b, Ta, Tb, Tc, tA, tB, attn, lnp, total, wg_bytes;
 };
 
 WsLayout ws_layout(const TimDesc& d) {
@@ -86,6 +86,7 @@ WsLayout ws_layout(const TimDesc& d) {
   }
   (void)Mp; (void)wide; (void)mid;
   L.attn = take(tim_attention_bwd_ws(d));
+  L.lnp = take(tim_layernorm_bwd_ws((int)M, d.E));
   L.total = off;
   return L;
 }
@@ -255,7 +256,7 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
 
   // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
   if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, df, E, d.p_drop, d.seed,
-                              layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b, s))) return rc;
+                              layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b, (float*)(ws + W.lnp), s))) return rc;
   // du = (df W2) * dropout-mask * gelu'(u)
   TimEpi e = epi0();
   e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;
@@ -267,13 +268,13 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
   // norm1 backward -> dy1 (fp32) and da = dropout1-mask * dy1 (T)
   if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, da, E, d.p_drop, d.seed,
-                              layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b, s))) return rc;
+                              layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b, (float*)(ws + W.lnp), s))) return rc;
   // do = da Wo
   e = epi0();
   e.out0 = Tc; e.ld0 = E;
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, da, E, w->out_wt, E, M, E, E, e, 1, s))) return rc;
   // attention backward -> dqkv
-  if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, dqkv, ws + W.attn, W.total - W.attn, s))) return rc;
+  if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, dqkv, ws + W.attn, W.lnp - W.attn, s))) return rc;
   // dx_in = dqkv Win + dy1
   e = epi0();
   e.out0 = dx_in; e.ld0 = E; e.res = f32a; e.ldres = E;

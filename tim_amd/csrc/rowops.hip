@@ -55,6 +55,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ s
   }
 }
 
+// fp32 master weight [rows, cols] -> operand copies W[rows, ldp] and W^T[cols, ldt] in one pass
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weight_both_kernel(const float* __restrict__ src, int rows, int cols,
+                                                               T* __restrict__ plain, int ldp, T* __restrict__ tr,
+                                                               int ldt) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    const float v = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    tile[i][tx] = v;
+    if (r < rows && c < ldp) plain[(size_t)r * ldp + c] = OpT<T>::from_f(v);
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ldt) tr[(size_t)c * ldt + r] = OpT<T>::from_f(tile[tx][i]);
+  }
+}
+
+// column sums of per-block partials: out[c] += sum_b part[b][c]   (deterministic second stage of LN backward)
+__global__ void partial_colsum_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ o0,
+                                      float* __restrict__ o1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * cols) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += part[(size_t)b * 2 * cols + c];
+    s1 += part[(size_t)(b + 1) * 2 * cols + c];
+    s2 += part[(size_t)(b + 2) * 2 * cols + c];
+    s3 += part[(size_t)(b + 3) * 2 * cols + c];
+  }
+  for (; b < b1; ++b) s0 += part[(size_t)b * 2 * cols + c];
+  float* o = c < cols ? o0 : o1;
+  if (o) atomicAdd(o + (c < cols ? c : c - cols), (s0 + s1) + (s2 + s3));
+}
+
 // dW[i] += sum_z slab[z][i]   (split-K weight-gradient partials)
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, long long n, int nslab, float* __restrict__ dW) {
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
@@ -196,7 +237,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ w, float* __restrict__ dyf, int lddy,
                                                      T* __restrict__ dyt, int ldt, uint32_t thr, float scale,
                                                      uint64_t seed, uint32_t site, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows_pb) {
+                                                     float* __restrict__ dbeta, int rows_pb,
+                                                     float* __restrict__ partial) {
   extern __shared__ float red[];  // [4][2][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (cols + 255) >> 8;
@@ -265,8 +307,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { sg += red[(size_t)k * 2 * cols + c]; sb += red[(size_t)k * 2 * cols + cols + c]; }
-    if (dgamma) atomicAdd(dgamma + c, sg);
-    if (dbeta) atomicAdd(dbeta + c, sb);
+    if (partial) {  // deterministic two-stage reduction: [block][gamma | beta][cols]
+      partial[(size_t)blockIdx.x * 2 * cols + c] = sg;
+      partial[(size_t)blockIdx.x * 2 * cols + cols + c] = sb;
+    } else {
+      if (dgamma) atomicAdd(dgamma + c, sg);
+      if (dbeta) atomicAdd(dbeta + c, sb);
+    }
   }
 }
 
@@ -487,9 +534,12 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
   return TIMHIP_OK;
 }
 
+size_t tim_layernorm_bwd_ws(int rows, int cols) { return (size_t)((rows + 15) / 16) * 2 * cols * sizeof(float); }
+
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
-                      float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, hipStream_t s) {
+                      float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, float* partial_ws,
+                      hipStream_t s) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
     return TIMHIP_EUNSUPPORTED;
@@ -499,11 +549,16 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
-                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb)
+                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws)
   const int nv = (cols + 255) / 256;
   DISPATCH_T(precision, if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4); else LN_BWD(8));
 #undef LN_BWD
   TIM_CHECK_LAUNCH();
+  if (partial_ws && (dgamma || dbeta)) {
+    hipLaunchKernelGGL(partial_colsum_kernel, dim3((2 * cols + 255) / 256, 32), dim3(256), 0, s, partial_ws,
+                       (int)grid.x, cols, dgamma, dbeta);
+    TIM_CHECK_LAUNCH();
+  }
   return TIMHIP_OK;
 }
 
@@ -523,6 +578,17 @@ int timhip_cast_weight(int precision, const float* src, int rows, int cols, void
     DISPATCH_T(precision, hipLaunchKernelGGL((transpose_kernel<float, T>), grid, dim3(256), 0, s, src, rows, cols,
                                              cols, (T*)dst, ld, (float*)nullptr));
   }
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_cast_weight_both(int precision, const float* src, int rows, int cols, void* plain, int ldp, void* tr, int ldt,
+                            void* stream) {
+  if (!src || !plain || !tr || rows <= 0 || cols <= 0 || ldp % 64 || ldt % 64 || ldp < cols || ldt < rows)
+    return TIMHIP_EINVAL;
+  dim3 grid((max(ldp, cols) + 31) / 32, (max(ldt, rows) + 31) / 32);
+  DISPATCH_T(precision, hipLaunchKernelGGL(cast_weight_both_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src,
+                                           rows, cols, (T*)plain, ldp, (T*)tr, ldt));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
@@ -576,7 +642,7 @@ int timhip_layernorm_bwd(int precision, const float* dx, int lddx, const float* 
                          int rows, int cols, int act, const float* w, float* dy_f32, int lddy, void* dy_T, int ldt,
                          float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, void* stream) {
   return tim_layernorm_bwd(precision, dx, lddx, y, ldy, stats, rows, cols, act, w, dy_f32, lddy, dy_T, ldt, p_drop,
-                           seed, site, dgamma, dbeta, (hipStream_t)stream);
+                           seed, site, dgamma, dbeta, nullptr, (hipStream_t)stream);
 }
 
 int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const float* w, const float* b, void* h,

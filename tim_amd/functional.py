@@ -60,26 +60,30 @@ class Runtime:
 
     # ---- weight working copies -----------------------------------------------------------------
     def weight(self, p, transposed=False):
-        """operand-dtype copy of a [N,K] fp32 weight: [N, ru(K)] or (transposed) [K, ru(N)]"""
-        key = (id(p), transposed)
-        ent = self._wcache.get(key)
+        """operand-dtype copy of a [N,K] fp32 weight: [N, ru(K)] or (transposed) [K, ru(N)].  Both copies are
+        produced together (one pass over the fp32 master) whenever the parameter's version changed."""
+        ent = self._wcache.get(id(p))
         ver = (p.data_ptr(), p._version)
-        if ent is not None and ent[0] == ver and ent[1].device == p.device:
-            return ent[1]
-        N, K = p.shape
-        src = p.detach()
-        if src.dtype != torch.float32 or not src.is_contiguous():
-            src = src.float().contiguous()
-        if transposed:
-            buf = ent[1] if ent is not None and ent[1].device == p.device else \
-                torch.empty((K, _ru(N)), dtype=self.op_dtype, device=p.device)
-            call("timhip_cast_weight", self.prec, ptr(src), N, K, ptr(buf), buf.shape[1], 1, _stream())
-        else:
-            buf = ent[1] if ent is not None and ent[1].device == p.device else \
-                torch.empty((N, _ru(K)), dtype=self.op_dtype, device=p.device)
-            call("timhip_cast_weight", self.prec, ptr(src), N, K, ptr(buf), buf.shape[1], 0, _stream())
-        self._wcache[key] = (ver, buf)
-        return buf
+        if ent is None or ent[0] != ver or ent[1].device != p.device:
+            N, K = p.shape
+            src = p.detach()
+            if src.dtype != torch.float32 or not src.is_contiguous():
+                src = src.float().contiguous()
+            if ent is not None and ent[1].device == p.device and ent[1].shape == (N, _ru(K)):
+                plain, tr = ent[1], ent[2]
+            else:
+                plain = torch.empty((N, _ru(K)), dtype=self.op_dtype, device=p.device)
+                tr = torch.empty((K, _ru(N)), dtype=self.op_dtype, device=p.device)
+            call("timhip_cast_weight_both", self.prec, ptr(src), N, K, ptr(plain), plain.shape[1], ptr(tr),
+                 tr.shape[1], _stream())
+            ent = (ver, plain, tr)
+            self._wcache[id(p)] = ent
+        return ent[2] if transposed else ent[1]
+
+    def invalidate_weights(self):
+        """force the operand copies to be rebuilt (bench: emulate the state after an optimizer step)"""
+        for k, ent in list(self._wcache.items()):
+            self._wcache[k] = (None, ent[1], ent[2])
 
     def next_seed(self):
         self.step += 1
