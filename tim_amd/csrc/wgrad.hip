@@ -23,8 +23,7 @@ constexpr int WM = 64;    // contraction rows per step
 __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __restrict__ dY, int ldy,
                                                             const bf16_t* __restrict__ X, int ldx, int M, int N,
                                                             int K, int steps_per_split, float* __restrict__ slab,
-                                                            long long slab_stride, float* __restrict__ db_slab,
-                                                            const bf16_t* __restrict__ zero_page) {
+                                                            long long slab_stride, float* __restrict__ db_slab) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][sY 16 KB | sX 16 KB]
   constexpr int TILE_BYTES = WM * WT * 2;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -41,7 +40,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
 
   // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk').  Column chunks beyond the
   // leading dimension are clamped (they only feed output columns that are never stored); rows beyond M
-  // (last step only) must contribute zeros and read the zero page.
+  // (last step only) must contribute zeros: that stage reads clamped rows and the padding rows of both LDS tiles
+  // are zeroed before the fragments are read.
   const int lrow = lane >> 4, lc = lane & 15;
   uint32_t yoff[4], xoff[4];
   int srow[4];
@@ -63,13 +63,9 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bool rok = m0 + srow[i] < M;
-        const char* py = rok ? reinterpret_cast<const char*>(dY) + (size_t)m0 * ldy * 2 + yoff[i]
-                             : reinterpret_cast<const char*>(zero_page);
-        const char* px = rok ? reinterpret_cast<const char*>(X) + (size_t)m0 * ldx * 2 + xoff[i]
-                             : reinterpret_cast<const char*>(zero_page);
-        glds16(py, base + i * 1024);
-        glds16(px, base + TILE_BYTES + i * 1024);
+        const int over = max(m0 + srow[i] - (M - 1), 0);  // rows past the end re-read row M-1
+        glds16(reinterpret_cast<const char*>(dY) + ((size_t)m0 - over) * ldy * 2 + yoff[i], base + i * 1024);
+        glds16(reinterpret_cast<const char*>(X) + ((size_t)m0 - over) * ldx * 2 + xoff[i], base + TILE_BYTES + i * 1024);
       }
     }
   };
@@ -105,8 +101,20 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
     glds_wait<0>();
     __syncthreads();
     if (st + 1 < s1) stage(st + 1, buf ^ 1);
-    const char* sY = lds + buf * 2 * TILE_BYTES;
-    const char* sX = sY + TILE_BYTES;
+    char* sY = lds + buf * 2 * TILE_BYTES;
+    char* sX = sY + TILE_BYTES;
+    if (st * WM + WM > M) {  // last, partial step: zero the rows >= M of both tiles (uniform branch)
+      const int first = M - st * WM;
+      bf16x8_t z;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = (bf16_t)0.f;
+      for (int idx = tid; idx < (WM - first) * 16; idx += 256) {
+        const int off = (first + idx / 16) * 256 + (idx % 16) * 16;  // whole rows: the chunk swizzle stays inside a row
+        *reinterpret_cast<bf16x8_t*>(sY + off) = z;
+        *reinterpret_cast<bf16x8_t*>(sX + off) = z;
+      }
+      __syncthreads();
+    }
     bf16x8_t xf[2][2], yf[2][2];
     auto load_frags = [&](int ms, int set) {
       // rows advance by 16 per ms (16*256 B) and swz<128>(row + 16) == swz<128>(row): immediates
@@ -164,6 +172,28 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
   }
 }
 
+// dW[i] += sum_z slab[z*n + i] (float4) and db[j] += sum_z dbs[z*nb + j]: one launch for both
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n, int nslab, float* __restrict__ dW,
+                                    const float* __restrict__ dbs, int nb, float* __restrict__ db) {
+  const long long nq = n >> 2;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq + nb; q += (long long)gridDim.x * blockDim.x) {
+    if (q < nq) {
+      const long long i = q << 2;
+      float4 a = *reinterpret_cast<const float4*>(dW + i);
+      for (int z = 0; z < nslab; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (long long)z * n + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      *reinterpret_cast<float4*>(dW + i) = a;
+    } else if (db) {
+      const int j = (int)(q - nq);
+      float a = db[j];
+      for (int z = 0; z < nslab; ++z) a += dbs[(long long)z * nb + j];
+      db[j] = a;
+    }
+  }
+}
+
 // out[i] += sum_z slab[z*stride + i]
 __global__ void slab_reduce2_kernel(const float* __restrict__ slab, long long n, long long stride, int nslab,
                                     float* __restrict__ out) {
@@ -186,10 +216,10 @@ int tim_wgrad_splits(int Nout, int Kout, int M) {
   return sk;
 }
 
-// workspace: [zero page 256 B][slab sk*N*K fp32][db slab sk*N fp32]
+// workspace: [slab sk*N*K fp32][db slab sk*N fp32]
 size_t tim_wgrad_tn_ws(int Nout, int Kout, int M) {
   const int sk = tim_wgrad_splits(Nout, Kout, M);
-  return 256 + align_up((size_t)sk * Nout * Kout * 4, 256) + align_up((size_t)sk * Nout * 4, 256);
+  return align_up((size_t)sk * Nout * Kout * 4, 256) + align_up((size_t)sk * Nout * 4, 256);
 }
 
 int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
@@ -198,25 +228,25 @@ int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx,
   if ((ldy % 8) || (ldx % 8) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)ws) & 15)) return TIMHIP_EALIGN;
   const int sk = tim_wgrad_splits(Nout, Kout, M);
   char* w = (char*)ws;
-  bf16_t* zero = (bf16_t*)w;
-  float* slab = (float*)(w + 256);
-  float* dbs = (float*)(w + 256 + align_up((size_t)sk * Nout * Kout * 4, 256));
-  if (hipMemsetAsync(zero, 0, 256, s) != hipSuccess) return TIMHIP_ELAUNCH;
+  float* slab = (float*)w;
+  float* dbs = (float*)(w + align_up((size_t)sk * Nout * Kout * 4, 256));
   const int nsteps = (M + WM - 1) / WM;
   const int per = (nsteps + sk - 1) / sk;
   const int sk_eff = (nsteps + per - 1) / per;  // no empty splits
   dim3 grid(((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT), 1, sk_eff);
   const size_t shmem = 2 * 2 * WM * WT * 2;
   hipLaunchKernelGGL(wgrad_tn_bf16_kernel, grid, dim3(256), shmem, s, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M,
-                     Nout, Kout, per, slab, (long long)Nout * Kout, db ? dbs : nullptr, zero);
+                     Nout, Kout, per, slab, (long long)Nout * Kout, db ? dbs : nullptr);
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
-  int rc = tim_slab_reduce(slab, (long long)Nout * Kout, sk_eff, dW, s);
-  if (rc == TIMHIP_EINVAL) {  // Nout*Kout not a multiple of 4: scalar reduce
-    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(256), dim3(256), 0, s, slab, (long long)Nout * Kout,
-                       (long long)Nout * Kout, sk_eff, dW);
-    rc = hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+  const long long n = (long long)Nout * Kout;
+  if ((n & 3) == 0) {
+    long long blocks = (n / 4 + Nout + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, n, sk_eff, dW, dbs, Nout, db);
+    return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
   }
-  if (rc) return rc;
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(256), dim3(256), 0, s, slab, n, n, sk_eff, dW);
+  if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   if (db) {
     hipLaunchKernelGGL(slab_reduce2_kernel, dim3((Nout + 255) / 256), dim3(256), 0, s, dbs, (long long)Nout,
                        (long long)Nout, sk_eff, db);
