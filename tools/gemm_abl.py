@@ -4,7 +4,7 @@ import torch
 from tim_amd import _lib as L
 from tim_amd.functional import Runtime
 dev = "cuda:0"; rt = Runtime("bf16"); g = torch.Generator().manual_seed(3)
-for (M, N, K) in ((9920, 3072, 1024), (9920, 1024, 1024), (9920, 1024, 4096), (8192, 4096, 4096)):
+for (M, N, K) in ((9920, 3072, 1024), (9920, 1024, 1024), (9920, 2048, 1024), (9920, 1024, 2048), (9920, 1024, 3072)):
     A = torch.randn(M, K, generator=g).to(dev).bfloat16(); B = (torch.randn(N, K, generator=g) / 32).to(dev).bfloat16()
     out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev); bias = torch.zeros(N, device=dev)
     row = []
