@@ -147,27 +147,43 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
 
   const int li = lane & 31, g = lane >> 5;
   float* out = slab + (long long)blockIdx.z * slab_stride;
+  // transpose the accumulators through a wave-private LDS region so that 16 lanes store one contiguous
+  // 64-column row segment of the slab (same scheme as the NT GEMM epilogue)
+  constexpr int EP_LD = 64 + 4;
+  __syncthreads();
+  float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + li;
-    if (n >= N) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = k0 + wk * 64 + i * 32 + 8 * q + 4 * g;
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(ep + li * EP_LD + i * 32 + 8 * q + 4 * g) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx >> 4, ch = idx & 15;
+      const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
+      const int n = n0 + wn * 64 + j * 32 + row;
+      const int k = k0 + wk * 64 + ch * 4;
+      if (n < N) {
         if (k + 3 < K) {
-          store4<float>(out + (size_t)n * K + k, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                        acc[i][j][4 * q + 3]);
+          *reinterpret_cast<float4*>(out + (size_t)n * K + k) = v;
         } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int tt = 0; tt < 4; ++tt)
-            if (k + tt < K) out[(size_t)n * K + k + tt] = acc[i][j][4 * q + tt];
+            if (k + tt < K) out[(size_t)n * K + k + tt] = vv[tt];
         }
       }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (do_bias && wk == 0) {
+      const int n = n0 + wn * 64 + j * 32 + li;
       const float t2 = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-      if (g == 0) db_slab[(size_t)blockIdx.z * N + n] = t2;
+      if (g == 0 && n < N) db_slab[(size_t)blockIdx.z * N + n] = t2;
     }
   }
 }
