@@ -473,6 +473,9 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
         case 7: launch_bf16<EPI, 128, 128, 2, 2, 64, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 8: launch_bf16<EPI, 256, 256, 2, 4, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 9: launch_bf16<EPI, 128, 128, 2, 2, 32, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 11: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 12: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 13: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 39>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 10: launch_bf16<EPI, 128, 128, 2, 2, 32, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }

@@ -17,6 +17,12 @@
 
 namespace {
 
+__device__ __forceinline__ int xcd_remap_w(int b, int nb) {  // bijective for any grid size
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 constexpr int WT = 128;   // output tile: 128 (n) x 128 (k)
 constexpr int WM = 64;    // contraction rows per step
 
@@ -30,12 +36,18 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave >> 1, wn = wave & 1;
   const int tiles_k = (K + WT - 1) / WT, tiles_n = (N + WT - 1) / WT;
-  // consecutive blocks share the dY panel (same n-tile): k-tile fastest
-  const int t = blockIdx.x;
+  // 1-D grid over (split, tile) work items, split-major.  Block b runs on XCD b % 8 (observed), so every XCD
+  // is given a CONTIGUOUS range of work items: one split's row range of dY / X and a few n-tile rows, instead
+  // of every XCD's L2 streaming all of dY and X (fabric reads 245 MB -> ~1.5x the operand bytes).
+  const int ntiles = tiles_k * tiles_n;
+  const int w = xcd_remap_w(blockIdx.x, gridDim.x);
+  const int zsplit = w / ntiles;
+  const int t = w - zsplit * ntiles;
+  // consecutive work items share the dY panel (same n-tile): k-tile fastest
   const int n0 = (t / tiles_k) * WT, k0 = (t % tiles_k) * WT;
   const bool do_bias = db_slab != nullptr && (t % tiles_k) == 0;
   const int nsteps = (M + WM - 1) / WM;
-  const int s0 = blockIdx.z * steps_per_split;
+  const int s0 = zsplit * steps_per_split;
   const int s1 = min(nsteps, s0 + steps_per_split);
 
   // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk').  Column chunks beyond the
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
   }
 
   const int li = lane & 31, g = lane >> 5;
-  float* out = slab + (long long)blockIdx.z * slab_stride;
+  float* out = slab + (long long)zsplit * slab_stride;
   // transpose the accumulators through a wave-private LDS region so that 16 lanes store one contiguous
   // 64-column row segment of the slab (same scheme as the NT GEMM epilogue)
   constexpr int EP_LD = 64 + 4;
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
     if (do_bias && wk == 0) {
       const int n = n0 + wn * 64 + j * 32 + li;
       const float t2 = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-      if (g == 0 && n < N) db_slab[(size_t)blockIdx.z * N + n] = t2;
+      if (g == 0 && n < N) db_slab[(size_t)zsplit * N + n] = t2;
     }
   }
 }
@@ -249,7 +261,7 @@ int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx,
   const int nsteps = (M + WM - 1) / WM;
   const int per = (nsteps + sk - 1) / sk;
   const int sk_eff = (nsteps + per - 1) / per;  // no empty splits
-  dim3 grid(((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT), 1, sk_eff);
+  dim3 grid(((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT) * sk_eff, 1, 1);
   const size_t shmem = 2 * 2 * WM * WT * 2;
   hipLaunchKernelGGL(wgrad_tn_bf16_kernel, grid, dim3(256), shmem, s, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M,
                      Nout, Kout, per, slab, (long long)Nout * Kout, db ? dbs : nullptr);

@@ -1,10 +1,11 @@
-"""Run one GEMM shape repeatedly (for rocprofv3 PMC collection)."""
+"""Run one GEMM shape repeatedly (for rocprofv3 PMC collection).  usage: gemm_one.py nt|tn [variant]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tim_amd import _lib as L
 from tim_amd.functional import Runtime
 kind = sys.argv[1] if len(sys.argv) > 1 else "nt"
+if len(sys.argv) > 2: os.environ["TIMHIP_GEMM_VARIANT"] = sys.argv[2]
 dev = "cuda:0"; rt = Runtime("bf16"); g = torch.Generator().manual_seed(3)
 M, E = 9920, 1024
 if kind == "nt":
