@@ -250,8 +250,19 @@ def main():
         per, fl, ms = gemm_roofline(model, cfg, B, nv, na, args.precision)
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         ach = fl / ms / 1e9
+        traffic = None  # HBM-side bytes per launch of the GEMM kernels, from the committed rocprofv3 PMC passes
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            if args.precision == "bf16" and args.workload == "C2a" and B == 64:
+                nt, tn = tj["gemm_nt_bf16_kernel"], tj["wgrad_tn_bf16_kernel"]
+                traffic = round((8 * nt["bytes_per_launch"] + 4 * tn["bytes_per_launch"]) / 12.0)
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": None,
+                           "frac": round(ach / peak, 4), "traffic": traffic,
+                           "traffic_note": "average HBM-side bytes per GEMM launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                                           "profiles/r01_pmc_traffic.json, tools/pmc_traffic.py); algorithmic operand+result "
+                                           "bytes average 70 MB per launch",
                            "kernel": "MFMA GEMM family: gemm_nt_%s_kernel (8 launches) + wgrad_tn kernel incl. its slab "
                                      "reduce (4 launches) = the 12 GEMMs of one encoder layer fwd+bwd, 2*M*N*K "
                                      "algorithmic FLOPs each, HIP-event timed on the launch stream" % (
