@@ -94,7 +94,8 @@ WsLayout ws_layout(const TimDesc& d) {
 int check_layer_desc(const TimDesc& d) {
   if (d.B <= 0 || d.S <= 0 || d.F <= 0 || d.F > d.S || d.E <= 0 || d.H <= 0 || d.FF <= 0) return TIMHIP_EINVAL;
   if (d.E % 64 || d.FF % 64 || d.E % d.H) return TIMHIP_EUNSUPPORTED;
-  if (d.precision != TIMHIP_PREC_BF16 && d.precision != TIMHIP_PREC_FP32) return TIMHIP_EUNSUPPORTED;
+  if (d.precision != TIMHIP_PREC_BF16 && d.precision != TIMHIP_PREC_FP32 && d.precision != TIMHIP_PREC_BF16X3)
+    return TIMHIP_EUNSUPPORTED;
   if (d.p_drop < 0.f || d.p_drop >= 1.f) return TIMHIP_EINVAL;
   return TIMHIP_OK;
 }

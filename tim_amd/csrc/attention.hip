@@ -253,7 +253,7 @@ int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hi
   const size_t lds = simple_lds(d, 1);
   if (lds > 160 * 1024) return TIMHIP_EUNSUPPORTED;
   AttnArgs a = make_args(d);
-  if (d.precision == TIMHIP_PREC_FP32) {
+  if (f32_storage(d.precision)) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_simple<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_fwd_simple<float>, dim3(d.B * d.H), dim3(256), lds, s, (const float*)qkv, (float*)o, lse, a);
   } else {
@@ -281,7 +281,7 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
   const size_t lds = simple_lds(d, 2);
   if (lds > 160 * 1024) return TIMHIP_EUNSUPPORTED;
   AttnArgs a = make_args(d);
-  if (d.precision == TIMHIP_PREC_FP32) {
+  if (f32_storage(d.precision)) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_simple<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_bwd_simple<float>, dim3(d.B * d.H), dim3(256), lds, s, (const float*)qkv, (const float*)o,
                        lse, (const float*)d_o, (float*)dqkv, (float*)ws, a);

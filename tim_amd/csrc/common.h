@@ -252,4 +252,6 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
                       const void* d_o, void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);
 size_t tim_attention_bwd_ws(const TimDesc& d);
 
-static inline size_t opsize(int precision) { return precision == TIMHIP_PREC_FP32 ? 4 : 2; }
+// operand storage: bf16 for TIMHIP_PREC_BF16, fp32 for TIMHIP_PREC_FP32 and TIMHIP_PREC_BF16X3
+static inline bool f32_storage(int precision) { return precision != TIMHIP_PREC_BF16; }
+static inline size_t opsize(int precision) { return f32_storage(precision) ? 4 : 2; }

@@ -416,6 +416,117 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// bf16x3 kernel (TIMHIP_PREC_BF16X3): fp32 operands, each split on the fly into hi = bf16(x) and
+// lo = bf16(x - hi); three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, the lo*lo term is < 2^-16
+// relative) with fp32 accumulation: ~16 mantissa bits per operand at 3x the MFMA work of plain bf16
+// (still ~5x the rate of the exact f32 MFMA).  128x128x32 tile, 4 waves, register-staged.
+// ---------------------------------------------------------------------------
+constexpr int XBK = 32;
+
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = (bf16_t)x;
+  lo = (bf16_t)(x - (float)hi);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_x3_kernel(const float* __restrict__ A, int lda,
+                                                         const float* __restrict__ B, int ldb, int M, int N, int K,
+                                                         int ksteps_per_split, EpiDev e) {
+  constexpr int BM = 128, BN = 128, ROWB = XBK * 2, TILE = BM * ROWB;  // bf16 tile bytes
+  __shared__ __attribute__((aligned(16))) char sm[4 * TILE];            // Ahi | Alo | Bhi | Blo
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  const int nk_total = K / XBK;
+  const int spl = ksteps_per_split * (BK / XBK);
+  const int kt0 = blockIdx.z * spl;
+  const int kt1 = min(nk_total, kt0 + spl);
+  if (EPI == TIMHIP_EPI_STORE_F32) e.out0 = (float*)e.out0 + (long long)blockIdx.z * e.slab_stride;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, row = idx >> 3, c4 = idx & 7;  // 8 float4 per 32-float row
+      ra[i] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + row, M - 1) * lda + kt * XBK + c4 * 4);
+      rb[i] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + row, N - 1) * ldb + kt * XBK + c4 * 4);
+    }
+    __syncthreads();  // previous step's fragments consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, row = idx >> 3, c4 = idx & 7;
+      const int off = row * ROWB + (((c4 >> 1) ^ kswz<32>(row)) << 4) + (c4 & 1) * 8;
+      bf16x4_t h, l;
+      const float va[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { bf16_t hh, ll; split_bf16(va[u], hh, ll); h[u] = hh; l[u] = ll; }
+      *reinterpret_cast<bf16x4_t*>(sm + off) = h;
+      *reinterpret_cast<bf16x4_t*>(sm + TILE + off) = l;
+      const float vb[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { bf16_t hh, ll; split_bf16(vb[u], hh, ll); h[u] = hh; l[u] = ll; }
+      *reinterpret_cast<bf16x4_t*>(sm + 2 * TILE + off) = h;
+      *reinterpret_cast<bf16x4_t*>(sm + 3 * TILE + off) = l;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < XBK / 16; ++kk) {
+      const int c = kk * 2 + fhalf;
+      bf16x8_t xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wm * 64 + j * 32 + frow;
+        const int off = row * ROWB + ((c ^ kswz<32>(row)) << 4);
+        xh[j] = *reinterpret_cast<const bf16x8_t*>(sm + off);
+        xl[j] = *reinterpret_cast<const bf16x8_t*>(sm + TILE + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wn * 64 + i * 32 + frow;
+        const int off = row * ROWB + ((c ^ kswz<32>(row)) << 4);
+        wh[i] = *reinterpret_cast<const bf16x8_t*>(sm + 2 * TILE + off);
+        wl[i] = *reinterpret_cast<const bf16x8_t*>(sm + 3 * TILE + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + wm * 64 + j * 32 + frow;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nb = n0 + wn * 64 + i * 32 + 4 * fhalf;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q;
+        if (n < N)
+          epi_quad<EPI, float>(e, m, n, N, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                               acc[i][j][4 * q + 3]);
+      }
+    }
+  }
+}
+
 template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
 void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int splitk,
                  hipStream_t s) {
@@ -442,7 +553,13 @@ constexpr bool tunable() {
 template <int EPI>
 int launch(int precision, int variant, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
            const EpiDev& e, int splitk, hipStream_t s) {
-  if (precision == TIMHIP_PREC_FP32) {
+  if (precision == TIMHIP_PREC_BF16X3) {
+    const int nk = K / BK;
+    const int per = (nk + splitk - 1) / splitk;
+    dim3 grid(((M + 127) / 128) * ((N + 127) / 128), 1, splitk);
+    hipLaunchKernelGGL(gemm_nt_x3_kernel<EPI>, grid, dim3(256), 0, s, (const float*)A, lda, (const float*)B, ldb, M,
+                       N, K, per, e);
+  } else if (precision == TIMHIP_PREC_FP32) {
     const int nk = K / FBK;
     const int per = (nk + splitk - 1) / splitk;
     dim3 grid(((M + 127) / 128) * ((N + 127) / 128), 1, splitk);
@@ -496,7 +613,8 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
                 int K, const TimEpi& te, int splitk, hipStream_t s) {
   if (!A || !B || !te.out0) return TIMHIP_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return TIMHIP_EINVAL;
-  if (precision != TIMHIP_PREC_BF16 && precision != TIMHIP_PREC_FP32) return TIMHIP_EUNSUPPORTED;
+  if (precision != TIMHIP_PREC_BF16 && precision != TIMHIP_PREC_FP32 && precision != TIMHIP_PREC_BF16X3)
+    return TIMHIP_EUNSUPPORTED;
   const int Kp = round_up(K, 64);
   if (lda % 64 || ldb % 64 || lda < Kp || ldb < Kp) return TIMHIP_EALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return TIMHIP_EALIGN;

@@ -487,7 +487,7 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ d_rows, int B,
 // ---------------------------------------------------------------------------
 #define DISPATCH_T(prec, ...)                                    \
   do {                                                           \
-    if ((prec) == TIMHIP_PREC_FP32) { using T = float; __VA_ARGS__; } \
+    if (f32_storage(prec)) { using T = float; __VA_ARGS__; } \
     else { using T = bf16_t; __VA_ARGS__; }                      \
   } while (0)
 

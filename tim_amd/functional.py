@@ -29,11 +29,9 @@ class Runtime:
     def __init__(self, precision="bf16"):
         if precision not in L.PRECISIONS:
             raise ValueError("precision must be one of %s" % list(L.PRECISIONS))
-        if precision == "bf16x3":
-            raise L.TimHipError("precision 'bf16x3' is not implemented yet")
         self.precision_name = precision
         self.prec = L.PRECISIONS[precision]
-        self.op_dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.op_dtype = torch.bfloat16 if precision == "bf16" else torch.float32  # bf16x3 stores fp32 and splits on the fly
         self._wcache = {}
         self.seed = 0x5EED
         self.step = 0
