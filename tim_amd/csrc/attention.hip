@@ -241,6 +241,9 @@ int check_desc(const TimDesc& d) {
 int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
 int tim_attention_bwd_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                            void* dqkv, hipStream_t s);
+int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
+                            void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);
+size_t tim_attention_bwd2_ws(const TimDesc& d);
 
 int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
   int rc = check_desc(d);
@@ -265,7 +268,9 @@ int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hi
 }
 
 size_t tim_attention_bwd_ws(const TimDesc& d) {
-  return (size_t)d.B * d.H * 2 * d.S * (d.F + 4) * sizeof(float);
+  const size_t simple = (size_t)d.B * d.H * 2 * d.S * (d.F + 4) * sizeof(float);
+  const size_t two = tim_attention_bwd2_ws(d);
+  return simple > two ? simple : two;
 }
 
 int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
@@ -274,6 +279,10 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
   if (rc) return rc;
   if (!qkv || !o || !lse || !d_o || !dqkv || !ws) return TIMHIP_EINVAL;
   if (d.precision == TIMHIP_PREC_BF16 && !(d.reserved & 1)) {
+    if (!(d.reserved & 2)) {  // reserved bit 1: force the single-kernel MFMA backward
+      rc = tim_attention_bwd2_mfma(d, qkv, o, lse, d_o, dqkv, ws, ws_bytes, s);
+      if (rc != TIMHIP_EUNSUPPORTED) return rc;
+    }
     rc = tim_attention_bwd_mfma(d, qkv, o, lse, d_o, dqkv, s);
     if (rc != TIMHIP_EUNSUPPORTED) return rc;
   }

@@ -1,0 +1,346 @@
+// MFMA (bf16) structured-attention backward, two-kernel form (see attention_mfma.hip for the math and the
+// LDS tile layout):
+//   attn_bwd_rows  : lane = query row.  Recomputes S^T and dP^T = V dO^T per 32-row block, forms dS, writes
+//                    dQ (+ the self-term dK/dV of query tokens) and hands dS and the dropped probabilities P~
+//                    to the second kernel through a bf16 scratch [B*H][S][FP].
+//   attn_bwd_keys  : dK = dS^T Q and dV = P~^T dO for the F feature keys: a batched "TN" product whose
+//                    contraction runs over the token rows, with both operands read in their natural layout and
+//                    transposed by ds_read_b64_tr_b16 (same scheme as wgrad.hip).
+// Compared with the single-kernel version (attn_bwd_mfma) nothing is recomputed in the transposed orientation:
+// no second exp / Philox pass, and the row kernel runs one wave per row block.
+#include "common.h"
+#include "mfma_tiles.h"
+
+namespace {
+
+struct AttnArgsM {
+  int S, F, E, H, LP;
+  float scale;
+  uint32_t thr; float dscale; uint64_t seed; uint32_t site;
+};
+
+__device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
+                                      float& k3) {
+  drop_mask4(a.seed, a.site, (rowbase + (uint64_t)key) >> 2, a.thr, a.dscale, k0, k1, k2, k3);
+}
+__device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int key) {
+  float k[4];
+  drop_mask4(a.seed, a.site, (rowbase + (uint64_t)key) >> 2, a.thr, a.dscale, k[0], k[1], k[2], k[3]);
+  const int c = (int)((rowbase + (uint64_t)key) & 3);
+  return c == 0 ? k[0] : (c == 1 ? k[1] : (c == 2 ? k[2] : k[3]));
+}
+
+template <int DH, int NJB>
+__global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                     const float* __restrict__ lse, const bf16_t* __restrict__ d_o,
+                                                     bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dS_scr,
+                                                     bf16_t* __restrict__ Pt_scr, AttnArgsM a) {
+  constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = sK + FP * DH * 2;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int S = a.S, F = a.F, E = a.E;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t ld = (size_t)3 * E;
+  const bf16_t* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
+  bf16_t* dbase = dqkv + (size_t)b * S * ld + (size_t)h * DH;
+  const bf16_t* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
+  const bf16_t* obase = o + (size_t)b * S * E + (size_t)h * DH;
+  const float* lsebase = lse + ((size_t)b * a.H + h) * S;
+  bf16_t* dSs = dS_scr + (size_t)blockIdx.x * S * FP;
+  bf16_t* Pts = Pt_scr + (size_t)blockIdx.x * S * FP;
+  stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
+  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
+  __syncthreads();
+
+  const int li = lane & 31, g = lane >> 5;
+  const int nrb = (S + 31) >> 5;
+
+  // ---------------- phase 1 ----------------
+  const int nwaves = blockDim.x >> 6;
+  for (int rb = wave; rb < nrb; rb += nwaves) {
+    const int row = rb * 32 + li;
+    const bool valid = row < S;
+    const int rowc = valid ? row : S - 1;
+    const bool isq = rowc >= F;
+    const bf16_t* qp = base + (size_t)rowc * ld;
+    const bf16_t* dop = dobase + (size_t)rowc * E;
+    const bf16_t* op = obase + (size_t)rowc * E;
+    bf16x8_t qf[NKK], df[NKK];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 16 + g * 8);
+      df[kk] = *reinterpret_cast<const bf16x8_t*>(dop + kk * 16 + g * 8);
+      delta += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(op + kk * 16 + g * 8));
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float l = lsebase[rowc];
+    const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
+
+    // self terms (scalar per row)
+    float ds_self = 0.f, pt_self = 0.f;
+    if (isq) {
+      float t = 0.f, u = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        t += dot8(qf[kk], *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8));
+        u += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(qp + 2 * E + kk * 16 + g * 8));
+      }
+      ds_self = t; pt_self = u;
+    }
+    {
+      const float t2 = __shfl_xor(ds_self, 32, 64), u2 = __shfl_xor(pt_self, 32, 64);
+      if (isq) {
+        const float t = (ds_self + t2) * a.scale, u = pt_self + u2;
+        const float p = __expf(t - l);
+        const float keep = a.thr != 0u ? keep1(a, rowbase, F) : 1.f;
+        ds_self = p * (u * keep - delta) * a.scale;
+        pt_self = p * keep;
+      }
+    }
+    // per key block: S^T, dP^T -> dS^T (registers) -> dQ^T += K^T dS^T
+    f32x16_t qa[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qa[db][r] = 0.f;
+#pragma unroll 1
+    for (int jb = 0; jb < NJB; ++jb) {
+      f32x16_t sc, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[kk], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float k[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.thr != 0u) keep4(a, rowbase, jb * 32 + 8 * q + 4 * g, k[0], k[1], k[2], k[3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = 4 * q + t;
+          const int key = jb * 32 + 8 * q + 4 * g + t;
+          const float p = key < F ? __expf(sc[r] * a.scale - l) : 0.f;
+          sc[r] = p * (dp[r] * k[t] - delta) * a.scale;
+          dp[r] = p * k[t];
+        }
+        if (valid) {  // hand dS and the dropped probabilities P~ to the key-side kernel
+          const size_t so = (size_t)row * FP + jb * 32 + 8 * q + 4 * g;
+          store4<bf16_t>(dSs + so, sc[4 * q], sc[4 * q + 1], sc[4 * q + 2], sc[4 * q + 3]);
+          store4<bf16_t>(Pts + so, dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], dp[4 * q + 3]);
+        }
+      }
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const bf16x8_t sf = pack8(sc, aa);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const bf16x8_t kf = tr_frag<DH>(sK, jb * 32 + 16 * aa, db, lane);
+          qa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, qa[db], 0, 0, 0);
+        }
+      }
+    }
+    if (valid) {
+      bf16_t* dq = dbase + (size_t)row * ld;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dh = 32 * db + 8 * q + 4 * g;
+          float v0 = qa[db][4 * q], v1 = qa[db][4 * q + 1], v2 = qa[db][4 * q + 2], v3 = qa[db][4 * q + 3];
+          if (isq) {
+            float k0, k1, k2, k3, q0, q1, q2, q3, d0, d1, d2, d3;
+            load4<bf16_t>(qp + E + dh, k0, k1, k2, k3);
+            load4<bf16_t>(qp + dh, q0, q1, q2, q3);
+            load4<bf16_t>(dop + dh, d0, d1, d2, d3);
+            v0 = fmaf(ds_self, k0, v0); v1 = fmaf(ds_self, k1, v1); v2 = fmaf(ds_self, k2, v2); v3 = fmaf(ds_self, k3, v3);
+            // a query token's own key / value receive the self term only
+            store4<bf16_t>(dq + E + dh, ds_self * q0, ds_self * q1, ds_self * q2, ds_self * q3);
+            store4<bf16_t>(dq + 2 * E + dh, pt_self * d0, pt_self * d1, pt_self * d2, pt_self * d3);
+          }
+          store4<bf16_t>(dq + dh, v0, v1, v2, v3);
+        }
+    }
+  }
+
+}
+
+// dK / dV of the feature keys: out[key][dh] = sum_row Y[row][key] X[row][dh]
+//   blockIdx.y = 0: Y = dS, X = Q  -> dK ;  blockIdx.y = 1: Y = P~, X = dO -> dV ;  blockIdx.z = (window, head)
+__global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ dS_scr, const bf16_t* __restrict__ Pt_scr,
+                                                     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                     bf16_t* __restrict__ dqkv, int S, int F, int FP, int E, int H,
+                                                     int DH) {
+  constexpr int WT = 128, WM = 64, TILE_BYTES = WM * WT * 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wn = wave & 1;
+  const int bh = blockIdx.z, b = bh / H, h = bh % H, prod = blockIdx.y;
+  const bf16_t* Y = (prod ? Pt_scr : dS_scr) + (size_t)bh * S * FP;
+  const int ldy = FP;
+  const bf16_t* X = prod ? d_o + (size_t)b * S * E + (size_t)h * DH : qkv + (size_t)b * S * 3 * E + (size_t)h * DH;
+  const int ldx = prod ? E : 3 * E;
+  bf16_t* out = dqkv + (size_t)b * S * 3 * E + (prod ? 2 * E : E) + (size_t)h * DH;
+  const int ldo = 3 * E;
+  const int n0 = blockIdx.x * WT, k0 = 0, M = S, N = F, K = DH;
+  const int nsteps = (M + WM - 1) / WM;
+
+  const int lrow = lane >> 4, lc = lane & 15;
+  uint32_t yoff[4], xoff[4];
+  int srow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 4 + lrow;
+    const int c = lc ^ swz<128>(row);
+    srow[i] = row;
+    yoff[i] = (uint32_t)(((size_t)row * ldy + min(n0 + c * 8, ldy - 8)) * 2);
+    xoff[i] = (uint32_t)(((size_t)row * ldx + min(k0 + c * 8, ldx - 8)) * 2);
+  }
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  auto stage = [&](int step, int buf) {
+    const uint32_t bs = lds0 + buf * 2 * TILE_BYTES + wave * 4096;
+    const int m0 = step * WM;
+    if (m0 + WM <= M) {
+      glds16_xn<4>(reinterpret_cast<const char*>(Y) + (size_t)m0 * ldy * 2, yoff, bs);
+      glds16_xn<4>(reinterpret_cast<const char*>(X) + (size_t)m0 * ldx * 2, xoff, bs + TILE_BYTES);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int over = max(m0 + srow[i] - (M - 1), 0);
+        glds16(reinterpret_cast<const char*>(Y) + ((size_t)m0 - over) * ldy * 2 + yoff[i], bs + i * 1024);
+        glds16(reinterpret_cast<const char*>(X) + ((size_t)m0 - over) * ldx * 2 + xoff[i], bs + TILE_BYTES + i * 1024);
+      }
+    }
+  };
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int xtr[2][2], ytr[2][2];
+  {
+    const int gid = lane >> 4, p = lane & 15, g = gid >> 1;
+    const int row0 = 4 * g + (p >> 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cx = 4 * (wk * 2 + i) + 2 * (gid & 1) + ((p & 3) >> 1);
+      const int cy = 4 * (wn * 2 + i) + 2 * (gid & 1) + ((p & 3) >> 1);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        xtr[i][hh] = tile_off<128>(row0 + 8 * hh, cx) + (p & 1) * 8;
+        ytr[i][hh] = tile_off<128>(row0 + 8 * hh, cy) + (p & 1) * 8;
+      }
+    }
+  }
+  stage(0, 0);
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    glds_wait<0>();
+    __syncthreads();
+    if (st + 1 < nsteps) stage(st + 1, buf ^ 1);
+    char* sY = lds + buf * 2 * TILE_BYTES;
+    char* sX = sY + TILE_BYTES;
+    if (st * WM + WM > M) {
+      const int first = M - st * WM;
+      bf16x8_t z;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = (bf16_t)0.f;
+      for (int idx = tid; idx < (WM - first) * 16; idx += 256) {
+        const int off = (first + idx / 16) * 256 + (idx % 16) * 16;
+        *reinterpret_cast<bf16x8_t*>(sY + off) = z;
+        *reinterpret_cast<bf16x8_t*>(sX + off) = z;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ms = 0; ms < WM / 16; ++ms) {
+      bf16x8_t xf[2], yf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xf[i] = cat8(tr_read(sX + xtr[i][0] + ms * 4096), tr_read(sX + xtr[i][1] + ms * 4096));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) yf[j] = cat8(tr_read(sY + ytr[j][0] + ms * 4096), tr_read(sY + ytr[j][1] + ms * 4096));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // D[i = dh][j = key]: lane owns one key row of dK / dV, 4 consecutive dh per quad
+  const int li = lane & 31, g = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + li;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = wk * 64 + i * 32 + 8 * q + 4 * g;
+        if (k + 3 < K)
+          store4<bf16_t>(out + (size_t)n * ldo + k, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                         acc[i][j][4 * q + 3]);
+      }
+  }
+}
+
+AttnArgsM make_args2(const TimDesc& d) {
+  AttnArgsM a;
+  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 4);
+  a.scale = 1.f / sqrtf((float)(d.E / d.H));
+  a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
+  a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
+  a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
+  return a;
+}
+
+static inline int rows_waves(int S) { const int n = (S + 31) / 32; return n < 1 ? 1 : (n > 8 ? 8 : n); }
+
+template <int DH, int NJB>
+int launch_bwd2(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
+                void* ws, hipStream_t s) {
+  const int FP = NJB * 32;
+  bf16_t* dS = (bf16_t*)ws;
+  bf16_t* Pt = dS + (size_t)d.B * d.H * d.S * FP;
+  const size_t lds1 = (size_t)2 * FP * DH * 2;
+  (void)hipFuncSetAttribute((const void*)attn_bwd_rows<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  hipLaunchKernelGGL((attn_bwd_rows<DH, NJB>), dim3(d.B * d.H), dim3(64 * rows_waves(d.S)), lds1, s, (const bf16_t*)qkv,
+                     (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dqkv, dS, Pt, make_args2(d));
+  if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
+  const size_t lds2 = 2 * 2 * 64 * 128 * 2;
+  hipLaunchKernelGGL(attn_bwd_keys, dim3((d.F + 127) / 128, 2, d.B * d.H), dim3(256), lds2, s, dS, Pt, (const bf16_t*)qkv,
+                     (const bf16_t*)d_o, (bf16_t*)dqkv, d.S, d.F, FP, d.E, d.H, DH);
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
+
+}  // namespace
+
+size_t tim_attention_bwd2_ws(const TimDesc& d) {
+  return (size_t)2 * d.B * d.H * d.S * round_up(d.F, 32) * sizeof(bf16_t);
+}
+
+int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
+                            void* dqkv, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (d.precision != TIMHIP_PREC_BF16 || (d.E % 8) != 0 || d.B * d.H > 65535) return TIMHIP_EUNSUPPORTED;
+  if (!ws || ws_bytes < tim_attention_bwd2_ws(d)) return TIMHIP_EUNSUPPORTED;
+  const int DHv = d.E / d.H, NJBv = (d.F + 31) / 32;
+#define B2(DHc, NJBc) return launch_bwd2<DHc, NJBc>(d, qkv, o, lse, d_o, dqkv, ws, s)
+  if (DHv == 128) {
+    switch (NJBv) { case 1: B2(128, 1); case 2: B2(128, 2); case 3: B2(128, 3); case 4: B2(128, 4); case 5: B2(128, 5); default: break; }
+  } else if (DHv == 64) {
+    switch (NJBv) { case 1: B2(64, 1); case 2: B2(64, 2); case 4: B2(64, 4); default: break; }
+  } else if (DHv == 32) {
+    switch (NJBv) { case 1: B2(32, 1); case 2: B2(32, 2); default: break; }
+  }
+#undef B2
+  return TIMHIP_EUNSUPPORTED;
+}
