@@ -46,7 +46,8 @@ def tol(prec, ref):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (9, 3806, 128), (333, 64, 2304), (1, 5, 24)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 192), (9, 3806, 128), (333, 64, 2304), (1, 5, 24),
+                                   (9925, 1000, 128), (4000, 2056, 64)])  # the last two select the 160-row tile
 def test_gemm_store(prec, M, N, K):
     rt = Runtime(prec)
     A, Ar = to_op(rt, rnd(M, K, seed=1))
@@ -87,9 +88,9 @@ def test_gemm_transpose_detecting(prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-def test_gemm_fused_epilogues(prec):
+@pytest.mark.parametrize("M,N,K", [(310, 256, 128), (4000, 2056, 128)])  # 128-row and 160-row bf16 tiles
+def test_gemm_fused_epilogues(prec, M, N, K):
     rt = Runtime(prec)
-    M, N, K = 310, 256, 128
     A, Ar = to_op(rt, rnd(M, K, seed=1))
     B, Br = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))
     bias = rnd(N, seed=3).to(DEV)

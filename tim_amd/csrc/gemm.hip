@@ -544,6 +544,20 @@ void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, i
                      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, per, e);
 }
 
+// Tile height.  Two tiles are built: 128 x 128 (2 x 2 waves of 64 x 64) and 160 x 128 (1 x 4 waves of 160 x 32).
+// The taller tile stages 71 instead of 64 FLOP per LDS-DMA byte (the kernel is staging-bound) and quantises the
+// encoder's M = 64 windows x 155 tokens = 9920 = 62 x 160 rows exactly: N = 1024 -> 496 tiles = ONE round of the
+// 512 block slots (2 per CU) instead of 624 = 1.2 rounds.  Measured on M = 9920 (tools/gemm_tune.py, variant 14):
+// +8...+35 % on every shape of the layer.  Cost model: rounds of 512 slots x tile height; the tall tile also wins ties.
+static inline bool tall_tile_wins(int M, int N, int splitk) {
+  if (M <= 128) return false;
+  const long long tn = (N + 127) / 128;
+  const long long t128 = (long long)((M + 127) / 128) * tn * splitk, t160 = (long long)((M + 159) / 160) * tn * splitk;
+  const long long c128 = ((t128 + 511) / 512) * 128, c160 = ((t160 + 511) / 512) * 160;
+  if (c160 != c128) return c160 < c128;
+  return (long long)((M + 159) / 160) * 160 <= (long long)((M + 127) / 128) * 128 + 32;
+}
+
 // tile variants (bf16): 0 = default, others for tuning on selected epilogues
 template <int EPI>
 constexpr bool tunable() {
@@ -594,13 +608,27 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
         case 12: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 13: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 39>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 10: launch_bf16<EPI, 128, 128, 2, 2, 32, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 14: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 15: launch_bf16<EPI, 160, 256, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 16: launch_bf16<EPI, 320, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 17: launch_bf16<EPI, 320, 128, 2, 2, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 18: launch_bf16<EPI, 160, 256, 1, 4, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 19: launch_bf16<EPI, 192, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 20: launch_bf16<EPI, 320, 128, 2, 2, 32, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 22: launch_bf16<EPI, 320, 128, 2, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 24: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 25: launch_bf16<EPI, 192, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 26: launch_bf16<EPI, 320, 256, 2, 4, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
     } else
 #endif
     {
       (void)variant;
-      launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+      if (tall_tile_wins(M, N, splitk))
+        launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+      else
+        launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
     }
   }
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;

@@ -22,6 +22,7 @@ for name, m_, n_, k_, epi, sk in shapes:
     res = torch.zeros((m_, n_), dtype=torch.float32, device=dev)
     bias = torch.zeros(n_, device=dev)
     row = []
+    ref = None
     for v in variants:
         os.environ["TIMHIP_GEMM_VARIANT"] = str(v)
         kw = dict(out1=o1, ld1=n_, bias=None if epi in (L.EPI_ADD_F32, L.EPI_DGELU_T) else bias, res=res, ldres=n_,
@@ -37,5 +38,9 @@ for name, m_, n_, k_, epi, sk in shapes:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
-        row.append("v%d %5.1fus %4.0fTF" % (v, ms * 1e3, 2.0 * m_ * n_ * k_ / ms / 1e9))
+        got = o0.view(torch.bfloat16).flatten()[:m_ * n_].float() if epi in (L.EPI_STORE_T,) else o0[:m_].clone()
+        if ref is None:
+            ref = got.clone()
+        bad = (got - ref).abs().max().item()
+        row.append("v%d %5.1fus %4.0fTF%s" % (v, ms * 1e3, 2.0 * m_ * n_ * k_ / ms / 1e9, "" if bad < 1e-2 else " BAD%.2g" % bad))
     print("%-16s M%5d N%5d K%5d sk%d | " % (name, m_, n_, k_, sk) + " | ".join(row), flush=True)
