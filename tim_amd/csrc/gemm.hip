@@ -253,7 +253,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   for (int kt = kt0; kt < kt1; ++kt) {
     // stage kt must have landed; the (up to NST-2) younger stages may stay in flight
     const int younger = min(NST - 2, kt1 - 1 - kt);
-    if (NST >= 4 && younger >= 2) glds_wait<2 * LPS>();
+    if (NST >= 5 && younger >= 3) glds_wait<3 * LPS>();
+    else if (NST >= 4 && younger >= 2) glds_wait<2 * LPS>();
     else if (NST >= 3 && younger >= 1) glds_wait<LPS>();
     else glds_wait<0>();
     if (ABL < 4) __syncthreads();  // everybody's part of stage kt is in LDS; everybody finished reading stage kt-1
@@ -609,16 +610,13 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
         case 13: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 39>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 10: launch_bf16<EPI, 128, 128, 2, 2, 32, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 14: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 15: launch_bf16<EPI, 160, 256, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 16: launch_bf16<EPI, 320, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 17: launch_bf16<EPI, 320, 128, 2, 2, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 18: launch_bf16<EPI, 160, 256, 1, 4, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 19: launch_bf16<EPI, 192, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 20: launch_bf16<EPI, 320, 128, 2, 2, 32, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 22: launch_bf16<EPI, 320, 128, 2, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 24: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 25: launch_bf16<EPI, 192, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 26: launch_bf16<EPI, 320, 256, 2, 4, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 27: launch_bf16<EPI, 128, 128, 2, 2, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 28: launch_bf16<EPI, 128, 128, 2, 2, 32, 5, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 29: launch_bf16<EPI, 128, 128, 2, 2, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
     } else

@@ -246,27 +246,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
   const int r0 = blockIdx.x * rows_pb, r1 = min(rows, r0 + rows_pb);
+  // gamma stays in registers; the loads of row + 4 are issued before the arithmetic of the current row so that every
+  // wave always has a full row of y and dx in flight (the kernel is a pure HBM stream: 2 fp32 reads, 1.5 writes)
+  float4 ww[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    ww[i] = (i < nv && c < cols) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
+  }
+  float4 tn[LN_MAXV], dn[LN_MAXV];
+  float2 stn = make_float2(0.f, 0.f);
+  auto fetch = [&](int row) {
+    stn = *reinterpret_cast<const float2*>(stats + 2 * row);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (i < nv && c < cols) {
+        tn[i] = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+        dn[i] = *reinterpret_cast<const float4*>(dx + (size_t)row * lddx + c);
+      }
+    }
+  };
+  if (r0 + wave < r1) fetch(r0 + wave);
+#pragma unroll 1
   for (int row = r0 + wave; row < r1; row += 4) {
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float4 xh[LN_MAXV], g[LN_MAXV];
+    const float mean = stn.x, rstd = stn.y;
+    float4 xh[LN_MAXV], d[LN_MAXV], ga[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { xh[i] = tn[i]; d[i] = dn[i]; }
+    if (row + 4 < r1) fetch(row + 4);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < cols) {
-        float4 t = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
-        const float4 d = *reinterpret_cast<const float4*>(dx + (size_t)row * lddx + c);
-        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        const float4 t = xh[i];
+        if (act != 0) ga[i] = make_float4(act_grad_f(act, t.x), act_grad_f(act, t.y), act_grad_f(act, t.z),
+                                          act_grad_f(act, t.w));
         float4 h;
         h.x = (act_f(act, t.x) - mean) * rstd; h.y = (act_f(act, t.y) - mean) * rstd;
         h.z = (act_f(act, t.z) - mean) * rstd; h.w = (act_f(act, t.w) - mean) * rstd;
         xh[i] = h;
-        ag[i].x += d.x * h.x; ag[i].y += d.y * h.y; ag[i].z += d.z * h.z; ag[i].w += d.w * h.w;
-        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-        float4 gg = make_float4(d.x * ww.x, d.y * ww.y, d.z * ww.z, d.w * ww.w);
-        g[i] = gg;
-        s1 += (gg.x + gg.y) + (gg.z + gg.w);
-        s2 += (gg.x * h.x + gg.y * h.y) + (gg.z * h.z + gg.w * h.w);
+        ag[i].x += d[i].x * h.x; ag[i].y += d[i].y * h.y; ag[i].z += d[i].z * h.z; ag[i].w += d[i].w * h.w;
+        ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+        d[i].x *= ww[i].x; d[i].y *= ww[i].y; d[i].z *= ww[i].z; d[i].w *= ww[i].w;
+        s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+        s2 += (d[i].x * h.x + d[i].y * h.y) + (d[i].z * h.z + d[i].w * h.w);
       }
     }
     s1 = wave_sum(s1) / (float)cols;
@@ -275,13 +300,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < cols) {
-        float o0 = rstd * (g[i].x - s1 - xh[i].x * s2), o1 = rstd * (g[i].y - s1 - xh[i].y * s2);
-        float o2 = rstd * (g[i].z - s1 - xh[i].z * s2), o3 = rstd * (g[i].w - s1 - xh[i].w * s2);
-        if (act != 0) {
-          const float4 t = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
-          o0 *= act_grad_f(act, t.x); o1 *= act_grad_f(act, t.y);
-          o2 *= act_grad_f(act, t.z); o3 *= act_grad_f(act, t.w);
-        }
+        float o0 = rstd * (d[i].x - s1 - xh[i].x * s2), o1 = rstd * (d[i].y - s1 - xh[i].y * s2);
+        float o2 = rstd * (d[i].z - s1 - xh[i].z * s2), o3 = rstd * (d[i].w - s1 - xh[i].w * s2);
+        if (act != 0) { o0 *= ga[i].x; o1 *= ga[i].y; o2 *= ga[i].z; o3 *= ga[i].w; }
         if (dyf) store4<float>(dyf + (size_t)row * lddy + c, o0, o1, o2, o3);
         if (dyt) {
           float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
@@ -543,7 +564,9 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
     return TIMHIP_EUNSUPPORTED;
-  const int rpb = 16;
+  // 16 rows per block, more when that would exceed the 512 co-resident blocks (2 per CU): one balanced round
+  int rpb = 16;
+  if (rows > 16 * 512) rpb = (((rows + 511) / 512) + 3) / 4 * 4;
   dim3 grid((rows + rpb - 1) / rpb);
   const size_t shmem = (size_t)4 * 2 * cols * sizeof(float);
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;

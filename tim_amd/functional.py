@@ -6,6 +6,7 @@ Two autograd Functions mirror the two entry points the reference loops call
 buffers, the current stream and autograd bookkeeping only.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -38,7 +39,7 @@ class Runtime:
         self.bucket_hook = None  # callable(bucket_name, flat_grad_tensor) -> None
         self.finish_hook = None  # callable() -> None, called at the end of the encoder backward
         # weight-gradient GEMMs of layer l run on a side stream, overlapping the data chain of layer l-1
-        self.overlap_wgrad = True
+        self.overlap_wgrad = os.environ.get("TIM_AMD_SERIAL_BWD", "0") != "1"  # 1: single-stream (profiling)
         self._aux = {}
 
     def aux_stream(self, dev):
