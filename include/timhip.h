@@ -122,6 +122,16 @@ int timhip_cast_weight(int precision, const float* src, int rows, int cols, void
 int timhip_cast_weight_both(int precision, const float* src, int rows, int cols, void* plain, int ldp,
                             void* tr, int ldt, void* stream);
 
+/* the same for n weights in one launch (the refresh of every operand copy after an optimizer step);
+ * items is a HOST array, copied into the kernel arguments */
+typedef struct TimCastItem {
+  const float* src; /* fp32 master [rows, cols], 16-byte aligned */
+  void* plain;      /* [rows, ldp] */
+  void* tr;         /* [cols, ldt] */
+  int32_t rows, cols, ldp, ldt;
+} TimCastItem;
+int timhip_cast_weights(int precision, const TimCastItem* items, int n, void* stream);
+
 /* ---------------------------------------------------------------- generic ops (also unit-test hooks) */
 typedef struct TimEpi {
   void* out0;

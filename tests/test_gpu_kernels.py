@@ -138,6 +138,32 @@ def test_gemm_fused_epilogues(prec, M, N, K):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+def test_weight_operand_copies(prec):
+    """Runtime.weight: plain and transposed operand copies of fp32 masters (batched refresh, one launch for all
+    stale weights), zero padded to multiples of 64; ragged shapes take the scalar-load path."""
+    rt = Runtime(prec)
+    shapes = [(512, 2), (97, 1024), (3806, 1024), (300, 70), (1, 512), (130, 131), (2048, 1024)]
+    ws = [torch.nn.Parameter(rnd(r, c, seed=40 + i).to(DEV)) for i, (r, c) in enumerate(shapes)]
+    for w in ws:  # register; the first call casts one weight, later stale ones are refreshed together
+        rt.weight(w)
+    rt.invalidate_weights()
+    for w, (r, c) in zip(ws, shapes):
+        plain, tr = rt.weight(w), rt.weight(w, True)
+        torch.cuda.synchronize()
+        ref = w.detach().to(rt.op_dtype).float().cpu()
+        assert plain.shape == (r, _ru(c)) and tr.shape == (c, _ru(r))
+        assert torch.equal(plain.float().cpu()[:, :c], ref)
+        assert torch.equal(tr.float().cpu()[:, :r], ref.t())
+        assert (plain.float().cpu()[:, c:] == 0).all() and (tr.float().cpu()[:, r:] == 0).all()
+    # an in-place update (optimizer step) makes the copies stale again
+    with torch.no_grad():
+        ws[1].mul_(2.0)
+    torch.cuda.synchronize()
+    got = rt.weight(ws[1]).float().cpu()[:, :1024]
+    assert torch.equal(got, ws[1].detach().to(rt.op_dtype).float().cpu())
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_wgrad_and_colsum(prec):
     rt = Runtime(prec)
     M, N, K = 523, 200, 72

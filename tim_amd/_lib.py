@@ -39,6 +39,10 @@ class TimLayerGrads(C.Structure):
     _fields_ = [(n, vp) for n in _LG]
 
 
+class TimCastItem(C.Structure):
+    _fields_ = [("src", vp), ("plain", vp), ("tr", vp), ("rows", i32), ("cols", i32), ("ldp", i32), ("ldt", i32)]
+
+
 class TimEpi(C.Structure):
     _fields_ = [("out0", vp), ("out1", vp), ("bias", vp), ("res", vp), ("aux", vp),
                 ("ld0", i32), ("ld1", i32), ("ldres", i32), ("ldaux", i32),
@@ -52,6 +56,7 @@ _SIGS = {
     "timhip_layer_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_cast_weight": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, vp]),
     "timhip_cast_weight_both": (C.c_int, [i32, vp, i32, i32, vp, i32, vp, i32, vp]),
+    "timhip_cast_weights": (C.c_int, [i32, vp, i32, vp]),
     "timhip_gemm_nt": (C.c_int, [i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(TimEpi), i32, vp]),
     "timhip_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, sz, vp]),

@@ -17,7 +17,13 @@ struct AttnArgsM {
   int S, F, E, H, LP;
   float scale;
   uint32_t thr; float dscale; uint64_t seed; uint32_t site;
+  int abl;  // tuning builds only (TimDesc.reserved >> 8): 1 no scratch stores, 2 no dqkv stores, 4 operand rows alias row 0
 };
+#ifdef TIMHIP_TUNING
+#define ATT_ABL(a, bit) (((a).abl & (bit)) != 0)
+#else
+#define ATT_ABL(a, bit) false
+#endif
 
 __device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
                                       float& k3) {
@@ -65,9 +71,10 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
     const bool isq = rowc >= F;
-    const bf16_t* qp = base + (size_t)rowc * ld;
-    const bf16_t* dop = dobase + (size_t)rowc * E;
-    const bf16_t* op = obase + (size_t)rowc * E;
+    const int rowl = ATT_ABL(a, 4) ? (rowc & 1) : rowc;
+    const bf16_t* qp = base + (size_t)rowl * ld;
+    const bf16_t* dop = dobase + (size_t)rowl * E;
+    const bf16_t* op = obase + (size_t)rowl * E;
     bf16x8_t qf[NKK], df[NKK];
     float delta = 0.f;
 #pragma unroll
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
           sc[r] = p * (dp[r] * k[t] - delta) * a.scale;
           dp[r] = p * k[t];
         }
-        if (valid) {  // hand dS and the dropped probabilities P~ to the key-side kernel
+        if (valid && !ATT_ABL(a, 1)) {  // hand dS and the dropped probabilities P~ to the key-side kernel
           const size_t so = (size_t)row * FP + jb * 32 + 8 * q + 4 * g;
           store4<bf16_t>(dSs + so, sc[4 * q], sc[4 * q + 1], sc[4 * q + 2], sc[4 * q + 3]);
           store4<bf16_t>(Pts + so, dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], dp[4 * q + 3]);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
         }
       }
     }
-    if (valid) {
+    if (valid && !ATT_ABL(a, 2)) {
       bf16_t* dq = dbase + (size_t)row * ld;
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
@@ -300,6 +307,7 @@ AttnArgsM make_args2(const TimDesc& d) {
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
+  a.abl = d.reserved >> 8;
   return a;
 }
 

@@ -250,15 +250,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
     if (kt0 + p < kt1) stage(kt0 + p, p);
   int buf = 0;
   bf16x8_t xa[2][TM], wb[2][TN];
+  // ABL & 16 (tuning builds): per-phase shader-cycle counters of one wave per block, summed into e.aux[0..7]
+  constexpr bool PROF = (ABL & 16) != 0;
+  long long t_wait = 0, t_issue = 0, t_mma = 0, t_begin = 0, t0 = 0, t1 = 0;
+  long long w_begin = 0;
+  if constexpr (PROF) { t_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
   for (int kt = kt0; kt < kt1; ++kt) {
+    if constexpr (PROF) t0 = __builtin_readcyclecounter();
     // stage kt must have landed; the (up to NST-2) younger stages may stay in flight
     const int younger = min(NST - 2, kt1 - 1 - kt);
     if (NST >= 5 && younger >= 3) glds_wait<3 * LPS>();
     else if (NST >= 4 && younger >= 2) glds_wait<2 * LPS>();
     else if (NST >= 3 && younger >= 1) glds_wait<LPS>();
     else glds_wait<0>();
-    if (ABL < 4) __syncthreads();  // everybody's part of stage kt is in LDS; everybody finished reading stage kt-1
+    if ((ABL & 7) < 4) __syncthreads();  // everybody's part of stage kt is in LDS; everybody finished reading stage kt-1
+    if constexpr (PROF) { t1 = __builtin_readcyclecounter(); t_wait += t1 - t0; }
     if ((ABL & 1) == 0 && kt + NST - 1 < kt1) stage(kt + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    if constexpr (PROF) { t0 = __builtin_readcyclecounter(); t_issue += t0 - t1; }
     const char* base = lds + ((ABL & 1) ? 0 : buf) * ST_BYTES;
     // fragments are double-buffered in registers: the ds_reads of step kk+1 are in flight while
     // the MFMAs of step kk run
@@ -284,7 +292,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
       __builtin_amdgcn_sched_barrier(0);
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
+    if constexpr (PROF) t_mma += __builtin_readcyclecounter() - t0;
   }
+  long long t_loop_end = 0;
+  if constexpr (PROF) t_loop_end = __builtin_readcyclecounter();
 
   // ---- epilogue: D[i = n][j = m]; lane owns row m = lane & 31 ----
   if constexpr ((ABL & 8) != 0) {  // ablation: keep the accumulators alive, store (practically) nothing
@@ -332,6 +343,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
       if (m < M && n < N) epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block of rows overwrites
+  }
+  if constexpr (PROF) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t_end = __builtin_readcyclecounter();
+    if (tid == 0 && e.aux) {
+      unsigned long long* c = (unsigned long long*)e.aux;
+      atomicAdd(c + 0, (unsigned long long)t_wait);
+      atomicAdd(c + 1, (unsigned long long)t_issue);
+      atomicAdd(c + 2, (unsigned long long)t_mma);
+      atomicAdd(c + 3, (unsigned long long)(t_end - t_loop_end));
+      atomicAdd(c + 4, (unsigned long long)(t_end - t_begin));
+      atomicAdd(c + 5, 1ull);
+      atomicAdd(c + 6, (unsigned long long)(wall_clock64() - w_begin));
+    }
   }
 }
 
@@ -587,6 +612,9 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
       switch (variant) {
         ABLV(100, 128, 128, 2, 2, 64, 2, 1, 1) ABLV(200, 128, 128, 2, 2, 64, 2, 1, 2) ABLV(300, 128, 128, 2, 2, 64, 2, 1, 3)
         ABLV(700, 128, 128, 2, 2, 64, 2, 1, 7) ABLV(800, 128, 128, 2, 2, 64, 2, 1, 8)
+        ABLV(1600, 128, 128, 2, 2, 64, 2, 1, 16) ABLV(1614, 160, 128, 1, 4, 64, 2, 1, 16)
+        ABLV(814, 160, 128, 1, 4, 64, 2, 1, 8) ABLV(114, 160, 128, 1, 4, 64, 2, 1, 1) ABLV(214, 160, 128, 1, 4, 64, 2, 1, 2)
+        ABLV(314, 160, 128, 1, 4, 64, 2, 1, 3)
         ABLV(207, 128, 128, 2, 2, 64, 4, 8, 2) ABLV(208, 256, 256, 2, 4, 64, 2, 4, 2) ABLV(205, 256, 256, 4, 2, 32, 4, 4, 2)
         ABLV(203, 256, 128, 4, 2, 64, 3, 8, 2) ABLV(202, 128, 128, 2, 2, 32, 4, 8, 2)
 
@@ -614,9 +642,10 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
         case 22: launch_bf16<EPI, 320, 128, 2, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 24: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 25: launch_bf16<EPI, 192, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 27: launch_bf16<EPI, 128, 128, 2, 2, 32, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 28: launch_bf16<EPI, 128, 128, 2, 2, 32, 5, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 29: launch_bf16<EPI, 128, 128, 2, 2, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 33: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 34: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 35: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 36: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 62>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
     } else
@@ -654,6 +683,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   e.scale = te.p_drop > 0.f ? 1.f / (1.f - te.p_drop) : 1.f;
   e.site = te.site; e.seed = te.seed;
   e.slab_stride = splitk > 1 ? (long long)M * te.ld0 : 0;
+
   bool vec = (e.ld0 % 4 == 0) && (((uintptr_t)e.out0 & 15) == 0);
   if (e.out1) vec = vec && (e.ld1 % 4 == 0) && (((uintptr_t)e.out1 & 15) == 0);
   if (e.res) vec = vec && (e.ldres % 4 == 0) && (((uintptr_t)e.res & 15) == 0);

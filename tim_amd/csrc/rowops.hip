@@ -76,6 +76,59 @@ __global__ __launch_bounds__(256) void cast_weight_both_kernel(const float* __re
   }
 }
 
+// The same for up to CAST_MAX weights in ONE launch (the per-step refresh of every operand copy after an optimizer
+// step): 64 x 64 tiles, float4 loads, 8-byte bf16x4 stores in both orientations (the transposed copy goes through LDS).
+constexpr int CAST_MAX = 32;
+struct CastBatch {
+  int n;
+  int blk0[CAST_MAX + 1];  // first block of item i
+  TimCastItem it[CAST_MAX];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weights_kernel(CastBatch cb) {
+  __shared__ float tile[64][65];
+  int w = 0;
+  while (w + 1 < cb.n && (int)blockIdx.x >= cb.blk0[w + 1]) ++w;
+  const TimCastItem it = cb.it[w];
+  const int rows = it.rows, cols = it.cols, ldp = it.ldp, ldt = it.ldt;
+  const int tiles_x = (max(ldp, cols) + 63) / 64;
+  const int lb = blockIdx.x - cb.blk0[w];
+  const int c0 = (lb % tiles_x) * 64, r0 = (lb / tiles_x) * 64;
+  const float* __restrict__ src = it.src;
+  T* __restrict__ plain = (T*)it.plain;
+  T* __restrict__ tr = (T*)it.tr;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const bool vec = (cols & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      if (vec && c + 3 < cols) {
+        v = *reinterpret_cast<const float4*>(src + (size_t)r * cols + c);
+      } else {
+        if (c < cols) v.x = src[(size_t)r * cols + c];
+        if (c + 1 < cols) v.y = src[(size_t)r * cols + c + 1];
+        if (c + 2 < cols) v.z = src[(size_t)r * cols + c + 2];
+        if (c + 3 < cols) v.w = src[(size_t)r * cols + c + 3];
+      }
+      if (c < ldp) store4<T>(plain + (size_t)r * ldp + c, v.x, v.y, v.z, v.w);  // ldp % 64 == 0: whole quads
+    }
+    float* t = &tile[ty + 16 * i][tx * 4];
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 16 * i, r = r0 + tx * 4;
+    if (c < cols && r < ldt) {
+      const int lc = ty + 16 * i, lr = tx * 4;
+      store4<T>(tr + (size_t)c * ldt + r, tile[lr][lc], tile[lr + 1][lc], tile[lr + 2][lc], tile[lr + 3][lc]);
+    }
+  }
+}
+
 // column sums of per-block partials: out[c] += sum_b part[b][c]   (deterministic second stage of LN backward)
 __global__ void partial_colsum_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ o0,
                                       float* __restrict__ o1) {
@@ -613,6 +666,29 @@ int timhip_cast_weight_both(int precision, const float* src, int rows, int cols,
   DISPATCH_T(precision, hipLaunchKernelGGL(cast_weight_both_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src,
                                            rows, cols, (T*)plain, ldp, (T*)tr, ldt));
   TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_cast_weights(int precision, const TimCastItem* items, int n, void* stream) {
+  if (!items || n < 0) return TIMHIP_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += CAST_MAX) {
+    CastBatch cb;
+    cb.n = n - i0 < CAST_MAX ? n - i0 : CAST_MAX;
+    int blocks = 0;
+    for (int i = 0; i < cb.n; ++i) {
+      const TimCastItem& it = items[i0 + i];
+      if (!it.src || !it.plain || !it.tr || it.rows <= 0 || it.cols <= 0 || it.ldp % 64 || it.ldt % 64 ||
+          it.ldp < it.cols || it.ldt < it.rows)
+        return TIMHIP_EINVAL;
+      if ((((uintptr_t)it.src | (uintptr_t)it.plain | (uintptr_t)it.tr) & 15) != 0) return TIMHIP_EALIGN;
+      cb.it[i] = it;
+      cb.blk0[i] = blocks;
+      blocks += ((max(it.ldp, it.cols) + 63) / 64) * ((max(it.ldt, it.rows) + 63) / 64);
+    }
+    cb.blk0[cb.n] = blocks;
+    DISPATCH_T(precision, hipLaunchKernelGGL(cast_weights_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cb));
+    TIM_CHECK_LAUNCH();
+  }
   return TIMHIP_OK;
 }
 

@@ -7,6 +7,7 @@ buffers, the current stream and autograd bookkeeping only.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -34,6 +35,7 @@ class Runtime:
         self.prec = L.PRECISIONS[precision]
         self.op_dtype = torch.bfloat16 if precision == "bf16" else torch.float32  # bf16x3 stores fp32 and splits on the fly
         self._wcache = {}
+        self._wparams = {}  # id(param) -> weakref: every weight this runtime has cast
         self.seed = 0x5EED
         self.step = 0
         self.bucket_hook = None  # callable(bucket_name, flat_grad_tensor) -> None
@@ -60,24 +62,47 @@ class Runtime:
     # ---- weight working copies -----------------------------------------------------------------
     def weight(self, p, transposed=False):
         """operand-dtype copy of a [N,K] fp32 weight: [N, ru(K)] or (transposed) [K, ru(N)].  Both copies are
-        produced together (one pass over the fp32 master) whenever the parameter's version changed."""
+        produced together (one pass over the fp32 master) whenever the parameter's version changed; when one
+        weight is found stale, every stale weight this runtime has seen is refreshed in the same launch
+        (after an optimizer step that is all of them: one kernel instead of one per weight)."""
         ent = self._wcache.get(id(p))
         ver = (p.data_ptr(), p._version)
         if ent is None or ent[0] != ver or ent[1].device != p.device:
-            N, K = p.shape
-            src = p.detach()
+            self._wparams[id(p)] = weakref.ref(p)
+            self._refresh(p.device)
+            ent = self._wcache[id(p)]
+        return ent[2] if transposed else ent[1]
+
+    def _refresh(self, dev):
+        items, keep, fresh = [], [], {}
+        for key, ref in list(self._wparams.items()):
+            q = ref()
+            if q is None:
+                self._wparams.pop(key, None)
+                self._wcache.pop(key, None)
+                continue
+            if q.device != dev:
+                continue
+            ent = self._wcache.get(key)
+            ver = (q.data_ptr(), q._version)
+            if ent is not None and ent[0] == ver and ent[1].device == dev:
+                continue
+            N, K = q.shape
+            src = q.detach()
             if src.dtype != torch.float32 or not src.is_contiguous():
                 src = src.float().contiguous()
-            if ent is not None and ent[1].device == p.device and ent[1].shape == (N, _ru(K)):
+            if ent is not None and ent[1].device == dev and ent[1].shape == (N, _ru(K)):
                 plain, tr = ent[1], ent[2]
             else:
-                plain = torch.empty((N, _ru(K)), dtype=self.op_dtype, device=p.device)
-                tr = torch.empty((K, _ru(N)), dtype=self.op_dtype, device=p.device)
-            call("timhip_cast_weight_both", self.prec, ptr(src), N, K, ptr(plain), plain.shape[1], ptr(tr),
-                 tr.shape[1], _stream())
-            ent = (ver, plain, tr)
-            self._wcache[id(p)] = ent
-        return ent[2] if transposed else ent[1]
+                plain = torch.empty((N, _ru(K)), dtype=self.op_dtype, device=dev)
+                tr = torch.empty((K, _ru(N)), dtype=self.op_dtype, device=dev)
+            items.append(L.TimCastItem(ptr(src), ptr(plain), ptr(tr), N, K, plain.shape[1], tr.shape[1]))
+            keep.append(src)
+            fresh[key] = (ver, plain, tr)
+        if items:
+            arr = (L.TimCastItem * len(items))(*items)
+            call("timhip_cast_weights", self.prec, C.cast(arr, C.c_void_p), len(items), _stream())
+            self._wcache.update(fresh)
 
     def invalidate_weights(self):
         """force the operand copies to be rebuilt (bench: emulate the state after an optimizer step)"""

@@ -11,7 +11,7 @@ qkv = torch.randn(B * S, 3 * E, generator=g).to(dev).bfloat16()
 do = torch.randn(B * S, E, generator=g).to(dev).bfloat16()
 o = torch.zeros((B * S, E), dtype=torch.bfloat16, device=dev); lse = torch.empty((B, H, S), device=dev)
 dqkv = torch.zeros_like(qkv)
-desc = L.TimDesc(B, S, F, E // 2, E, H, 2 * E, 0, p, 99, 1, 0)
+desc = L.TimDesc(B, S, F, E // 2, E, H, 2 * E, 0, p, 99, 1, int(os.environ.get("ATT_ABL", "0")) << 8)
 wsb = L.load().timhip_attention_bwd_workspace_bytes(C.byref(desc)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 def fwd(): L.call("timhip_attention_fwd", C.byref(desc), L.ptr(qkv), L.ptr(o), L.ptr(lse), st)

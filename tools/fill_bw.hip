@@ -20,13 +20,18 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
 // mode 0: VGPR loads; 1: LDS-DMA; 2: VGPR loads + ds_write
 template <int MODE>
 __global__ __launch_bounds__(256) void fill_kernel(const char* __restrict__ src, int ld, int ksteps, int iters,
-                                                   int blocks_share, uint32_t* __restrict__ sink) {
+                                                   int blocks_share, uint32_t* __restrict__ sink, int pattern) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x 36 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const char* base = src + (size_t)(blocks_share ? 0 : blockIdx.x) * ROWS * ld;
   uint32_t off[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) off[i] = (uint32_t)(((wave * NI + i) * 8 + (lane >> 3)) * ld + (lane & 7) * 16);
+  for (int i = 0; i < NI; ++i) {
+    const int q = wave * NI + i;
+    // pattern 0: 8 lanes per 128-B row (stage copy); pattern 1: MFMA-fragment order, lane -> row lane%32, two 16-B chunks
+    off[i] = pattern == 0 ? (uint32_t)((q * 8 + (lane >> 3)) * ld + (lane & 7) * 16)
+                          : (uint32_t)(((q >> 2) * 32 + (lane & 31)) * ld + ((q & 3) * 2 + (lane >> 5)) * 16);
+  }
   uint4 acc = make_uint4(0, 0, 0, 0);
   int kt = 0, buf = 0;
   for (int it = 0; it < iters; ++it) {
@@ -64,15 +69,15 @@ __global__ __launch_bounds__(256) void fill_kernel(const char* __restrict__ src,
 }
 
 template <int MODE>
-int run(const char* name, const char* src, int ld, int ksteps, int share, int nblocks, uint32_t* sink) {
+int run(const char* name, const char* src, int ld, int ksteps, int share, int nblocks, uint32_t* sink, int pattern = 0) {
   const int iters = 4000;
   const size_t shmem = 2 * ROWS * 128;
   CK(hipFuncSetAttribute((const void*)fill_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(fill_kernel<MODE>, dim3(nblocks), dim3(256), shmem, 0, src, ld, ksteps, 200, share, sink);
+  hipLaunchKernelGGL(fill_kernel<MODE>, dim3(nblocks), dim3(256), shmem, 0, src, ld, ksteps, 200, share, sink, pattern);
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(fill_kernel<MODE>, dim3(nblocks), dim3(256), shmem, 0, src, ld, ksteps, iters, share, sink);
+  hipLaunchKernelGGL(fill_kernel<MODE>, dim3(nblocks), dim3(256), shmem, 0, src, ld, ksteps, iters, share, sink, pattern);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -101,6 +106,7 @@ int main() {
     if (run<0>("global->VGPR", src, ld, c.ksteps, c.share, c.nblocks, sink)) return 1;
     if (run<1>("LDS-DMA", src, ld, c.ksteps, c.share, c.nblocks, sink)) return 1;
     if (run<2>("global->VGPR->ds_write", src, ld, c.ksteps, c.share, c.nblocks, sink)) return 1;
+    if (run<0>("global->VGPR fragment", src, ld, c.ksteps, c.share, c.nblocks, sink, 1)) return 1;
   }
   return 0;
 }
