@@ -18,6 +18,7 @@
 // the ds_read_b128 side so the fragment reads are bank-conflict free.
 #include <stdlib.h>
 
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -31,6 +32,7 @@ struct EpiDev {
   int ld0, ld1, ldres, ldaux;
   uint32_t thr; float scale; uint32_t site; uint64_t seed;
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
+  int vec8; // the operand-dtype outputs / aux of this epilogue also allow 8-element (16-byte) accesses
   long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)
 };
 
@@ -134,6 +136,65 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
   }
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>).  Used where an index into a register array
+// (the accumulators) must be a constant even when the body is too large for the unroller's thresholds.
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+constexpr bool epi_has_oct(int EPI) {
+  return EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_RELU_T || EPI == TIMHIP_EPI_GELU_DROP_T2 ||
+         EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T;
+}
+__device__ __forceinline__ void store8(bf16_t* p, float4 lo, float4 hi) {
+  bf16x8_t o;
+  o[0] = (bf16_t)lo.x; o[1] = (bf16_t)lo.y; o[2] = (bf16_t)lo.z; o[3] = (bf16_t)lo.w;
+  o[4] = (bf16_t)hi.x; o[5] = (bf16_t)hi.y; o[6] = (bf16_t)hi.z; o[7] = (bf16_t)hi.w;
+  *reinterpret_cast<bf16x8_t*>(p) = o;
+}
+// the arithmetic of the bf16-output epilogues on one quad (v in/out; a = the quad's aux values; k = dropout factors)
+template <int EPI>
+__device__ __forceinline__ float4 epi_math4(float4 v, float4 a, float4 k) {
+  if (EPI == TIMHIP_EPI_RELU_T) return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  if (EPI == TIMHIP_EPI_GELU_DROP_T2)
+    return make_float4(gelu_f(v.x) * k.x, gelu_f(v.y) * k.y, gelu_f(v.z) * k.z, gelu_f(v.w) * k.w);
+  if (EPI == TIMHIP_EPI_DGELU_T)
+    return make_float4(v.x * k.x * gelu_grad_f(a.x), v.y * k.y * gelu_grad_f(a.y), v.z * k.z * gelu_grad_f(a.z),
+                       v.w * k.w * gelu_grad_f(a.w));
+  if (EPI == TIMHIP_EPI_DRELU_T)
+    return make_float4(a.x > 0.f ? v.x : 0.f, a.y > 0.f ? v.y : 0.f, a.z > 0.f ? v.z : 0.f, a.w > 0.f ? v.w : 0.f);
+  return v;
+}
+// 8 consecutive columns n..n+7 of row m for the epilogues that write bf16: ONE 16-byte store (and 16-byte aux load)
+// per lane instead of two 8-byte ones.  Caller guarantees e.vec8 and n + 7 < N.
+template <int EPI>
+__device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, float4 lo, float4 hi) {
+  float4 klo = make_float4(1.f, 1.f, 1.f, 1.f), khi = klo;
+  if (epi_uses_dropout(EPI) && e.thr != 0u) {
+    const uint64_t q = ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2;
+    drop_mask4(e.seed, e.site, q, e.thr, e.scale, klo.x, klo.y, klo.z, klo.w);
+    drop_mask4(e.seed, e.site, q + 1, e.thr, e.scale, khi.x, khi.y, khi.z, khi.w);
+  }
+  const size_t i0 = (size_t)m * e.ld0 + n;
+  if ((EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_RELU_T || EPI == TIMHIP_EPI_GELU_DROP_T2) && e.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(e.bias + n), b1 = *reinterpret_cast<const float4*>(e.bias + n + 4);
+    lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w; hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
+  }
+  float4 alo = make_float4(0.f, 0.f, 0.f, 0.f), ahi = alo;
+  if (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T) {
+    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)e.aux + (size_t)m * e.ldaux + n);
+    alo = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
+    ahi = make_float4((float)a[4], (float)a[5], (float)a[6], (float)a[7]);
+  }
+  if (EPI == TIMHIP_EPI_GELU_DROP_T2) store8((bf16_t*)e.out1 + (size_t)m * e.ld1 + n, lo, hi);
+  store8((bf16_t*)e.out0 + i0, epi_math4<EPI>(lo, alo, klo), epi_math4<EPI>(hi, ahi, khi));
+}
+
 // XCD-aware tile order: block b runs on XCD b % 8 (observed); give each XCD a
 // contiguous range of logical tiles so that the tiles_n tiles sharing one A
 // row-panel hit the same L2.  Bijective for any grid size.
@@ -220,6 +281,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
                        base + A_BYTES + wave * B_INSTR * 1024);
   };
 
+  // one piece (1 KiB wave-instruction) of a stage: pieces 0..A_INSTR-1 belong to A, the rest to B
+  auto stage_piece = [&](int kt, int buf, int p) {
+    const uint32_t base = lds0 + buf * ST_BYTES;
+    if (p < A_INSTR)
+      glds16_s(uniform_ptr(reinterpret_cast<const char*>(A) + (size_t)kt * BKT * 2), a_off32[p < A_INSTR ? p : 0],
+               base + (wave * A_INSTR + p) * 1024);
+    else
+      glds16_s(uniform_ptr(reinterpret_cast<const char*>(B) + (size_t)kt * BKT * 2),
+               b_off32[p >= A_INSTR ? p - A_INSTR : 0], base + A_BYTES + (wave * B_INSTR + p - A_INSTR) * 1024);
+  };
+
   f32x16_t acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -255,6 +327,80 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   long long t_wait = 0, t_issue = 0, t_mma = 0, t_begin = 0, t0 = 0, t1 = 0;
   long long w_begin = 0;
   if constexpr (PROF) { t_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
+  // ABL & 64: software-pipelined loop for ONE block per CU (big tiles, 3-stage ring).  One barrier per K-step,
+  // placed after the third of the four MFMA groups: by then this wave has issued the DMA pieces of stage kt+2
+  // (spread over the first three groups), holds the last fragments of stage kt in registers, and stage kt+1 has
+  // had two K-steps to land.  After the barrier the first fragments of stage kt+1 are fetched while the fourth
+  // MFMA group runs, so neither LDS latency nor DMA issue is exposed at the top of the next K-step.
+  constexpr bool PIPE = (ABL & 64) != 0;
+  if constexpr (PIPE) {
+    static_assert(NST == 3 && BKT == 64, "pipelined loop: 3-stage ring of 64-wide stages");
+    auto frags = [&](const char* base, int kk, int set) {
+      const int c = kk * 2 + fhalf;
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        xa[set][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off[j] + ((c ^ a_swz[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wb[set][i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
+    };
+    if (kt0 + 1 < kt1) glds_wait<LPS>(); else glds_wait<0>();
+    __syncthreads();
+    frags(lds, 0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool next = kt + 1 < kt1, more2 = kt + 2 < kt1;
+      const int ibuf = buf == 0 ? 2 : buf - 1;            // ring slot of stage kt+2 (= slot of stage kt-1)
+      const int nbuf = buf == 2 ? 0 : buf + 1;
+      const char* base = lds + buf * ST_BYTES;
+      constexpr int NM = TN * TM;                 // MFMAs per group
+      constexpr bool FINE = (ABL & 128) != 0;     // one DMA piece every few MFMAs instead of a burst per group
+      // FINE: piece p is issued after MFMA number slot(p) of the K-step (0 .. 4*NM-1); the pieces whose slot lies in
+      // the first three groups are in flight at the barrier
+      constexpr int NB_FINE = (3 * NM * LPS + 4 * NM - 1) / (4 * NM) > LPS ? LPS : (3 * NM * LPS + 4 * NM - 1) / (4 * NM);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) frags(base, kk + 1, (kk + 1) & 1);
+        else if (next) frags(lds + nbuf * ST_BYTES, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk & 1][i], xa[kk & 1][j], acc[i][j], 0, 0, 0);
+            if constexpr (FINE) {
+              const int g = kk * NM + i * TM + j;      // MFMA number within the K-step
+              // piece p goes after MFMA g when p*4*NM/LPS <= g < (p+1)*4*NM/LPS and g is the first such
+#pragma unroll
+              for (int p = 0; p < LPS; ++p)
+                if (g == (p * 4 * NM) / LPS) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  if ((ABL & 1) == 0 && more2) stage_piece(kt + 2, ibuf, p);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk < 3) {
+          if (!FINE && (ABL & 1) == 0 && more2) {
+#pragma unroll
+            for (int p = kk * LPS / 3; p < (kk + 1) * LPS / 3; ++p) stage_piece(kt + 2, ibuf, p);
+          }
+          if (kk == 2) {
+            // my pieces of stage kt+1 have landed (those of stage kt+2 issued so far may stay in flight)
+            if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t0 = __builtin_readcyclecounter(); }
+            if (more2 && (ABL & 1) == 0) { if (FINE) glds_wait<NB_FINE>(); else glds_wait<LPS>(); }
+            else glds_wait<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of stage kt are in registers
+            if constexpr (PROF) { t1 = __builtin_readcyclecounter(); t_issue += t1 - t0; }
+            __syncthreads();
+            if constexpr (PROF) { t0 = __builtin_readcyclecounter(); t_wait += t0 - t1; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      buf = nbuf;
+    }
+  } else
   for (int kt = kt0; kt < kt1; ++kt) {
     if constexpr (PROF) t0 = __builtin_readcyclecounter();
     // stage kt must have landed; the (up to NST-2) younger stages may stay in flight
@@ -324,8 +470,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   }
   __syncthreads();  // every wave is done with the main-loop tiles
   float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
+  static_for<TM>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -333,17 +479,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         *reinterpret_cast<float4*>(ep + frow * EP_LD + i * 32 + 8 * q + 4 * fhalf) =
             make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no block barrier needed
+    if (epi_has_oct(EPI) && e.vec8) {
+      constexpr int OPR = EP_COLS / 8;  // 16-byte output chunks per row
 #pragma unroll
-    for (int it = 0; it < 32 * CPR / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int row = idx / CPR, ch = idx % CPR;
-      const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
-      const int m = m0 + wm * (BM / WM) + j * 32 + row;
-      const int n = n0 + wn * (BN / WN) + ch * 4;
-      if (m < M && n < N) epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w);
+      for (int it = 0; it < 32 * OPR / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / OPR, ch = idx % OPR;
+        const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 8 + 4);
+        const int m = m0 + wm * (BM / WM) + j * 32 + row;
+        const int n = n0 + wn * (BN / WN) + ch * 8;
+        if (m < M && n + 7 < N) {
+          epi_oct<EPI>(e, m, n, N, lo, hi);
+        } else if (m < M) {
+          if (n < N) epi_quad<EPI, bf16_t>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
+          if (n + 4 < N) epi_quad<EPI, bf16_t>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 32 * CPR / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / CPR, ch = idx % CPR;
+        const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
+        const int m = m0 + wm * (BM / WM) + j * 32 + row;
+        const int n = n0 + wn * (BN / WN) + ch * 4;
+        if (m < M && n < N) epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block of rows overwrites
-  }
+  });
   if constexpr (PROF) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long t_end = __builtin_readcyclecounter();
@@ -642,10 +807,14 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
         case 22: launch_bf16<EPI, 320, 128, 2, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 24: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 25: launch_bf16<EPI, 192, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 33: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 34: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 35: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 36: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 62>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 40: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 42: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1, 64>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 43: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 44: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 128>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 45: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 46: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1, 64 + 128>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 47: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 48: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 16 + 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
     } else
@@ -690,6 +859,12 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   if (e.aux) vec = vec && (e.ldaux % 4 == 0) && (((uintptr_t)e.aux & 15) == 0);
   if (e.bias) vec = vec && (((uintptr_t)e.bias & 15) == 0);
   e.vec = vec ? 1 : 0;
+  // 8-element accesses of the bf16 outputs / aux (N % 4 == 0 is implied where it matters: dropout needs it, and a
+  // ragged last chunk falls back to quads)
+  bool vec8 = vec && precision == TIMHIP_PREC_BF16 && (e.ld0 % 8 == 0);
+  if (e.out1) vec8 = vec8 && (e.ld1 % 8 == 0);
+  if (e.aux) vec8 = vec8 && (e.ldaux % 8 == 0);
+  e.vec8 = vec8 ? 1 : 0;
   if (e.thr != 0u && (N % 4) != 0) return TIMHIP_EUNSUPPORTED;
   int variant = 0;
 #ifdef TIMHIP_TUNING  // tools/gemm_tune.py, tools/gemm_abl.py: make -C tim_amd/csrc TUNING=1

@@ -9,7 +9,7 @@ dev = "cuda:0"; rt = Runtime("bf16"); g = torch.Generator().manual_seed(3)
 for (M, N, K) in ((9920, 3072, 1024), (9920, 1024, 1024), (9920, 2048, 1024), (9920, 1024, 2048), (9920, 1024, 3072)):
     A = torch.randn(M, K, generator=g).to(dev).bfloat16(); B = (torch.randn(N, K, generator=g) / 32).to(dev).bfloat16()
     out = torch.zeros((M, N), dtype=torch.bfloat16, device=dev); bias = torch.zeros(N, device=dev)
-    for v in (1600, 1614):
+    for v in [int(x) for x in os.environ.get("VARS", "1600,1614").split(",")]:
         os.environ["TIMHIP_GEMM_VARIANT"] = str(v)
         cnt = torch.zeros(8, dtype=torch.int64, device=dev)
         for _ in range(3): rt.gemm(L.EPI_STORE_T, A, B, M, N, K, out, N, bias=bias, aux=cnt, ldaux=0)
