@@ -281,17 +281,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
                        base + A_BYTES + wave * B_INSTR * 1024);
   };
 
-  // one piece (1 KiB wave-instruction) of a stage: pieces 0..A_INSTR-1 belong to A, the rest to B
-  auto stage_piece = [&](int kt, int buf, int p) {
-    const uint32_t base = lds0 + buf * ST_BYTES;
-    if (p < A_INSTR)
-      glds16_s(uniform_ptr(reinterpret_cast<const char*>(A) + (size_t)kt * BKT * 2), a_off32[p < A_INSTR ? p : 0],
-               base + (wave * A_INSTR + p) * 1024);
-    else
-      glds16_s(uniform_ptr(reinterpret_cast<const char*>(B) + (size_t)kt * BKT * 2),
-               b_off32[p >= A_INSTR ? p - A_INSTR : 0], base + A_BYTES + (wave * B_INSTR + p - A_INSTR) * 1024);
-  };
-
   f32x16_t acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -327,80 +316,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   long long t_wait = 0, t_issue = 0, t_mma = 0, t_begin = 0, t0 = 0, t1 = 0;
   long long w_begin = 0;
   if constexpr (PROF) { t_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
-  // ABL & 64: software-pipelined loop for ONE block per CU (big tiles, 3-stage ring).  One barrier per K-step,
-  // placed after the third of the four MFMA groups: by then this wave has issued the DMA pieces of stage kt+2
-  // (spread over the first three groups), holds the last fragments of stage kt in registers, and stage kt+1 has
-  // had two K-steps to land.  After the barrier the first fragments of stage kt+1 are fetched while the fourth
-  // MFMA group runs, so neither LDS latency nor DMA issue is exposed at the top of the next K-step.
-  constexpr bool PIPE = (ABL & 64) != 0;
-  if constexpr (PIPE) {
-    static_assert(NST == 3 && BKT == 64, "pipelined loop: 3-stage ring of 64-wide stages");
-    auto frags = [&](const char* base, int kk, int set) {
-      const int c = kk * 2 + fhalf;
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        xa[set][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off[j] + ((c ^ a_swz[j]) << 4));
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        wb[set][i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
-    };
-    if (kt0 + 1 < kt1) glds_wait<LPS>(); else glds_wait<0>();
-    __syncthreads();
-    frags(lds, 0, 0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const bool next = kt + 1 < kt1, more2 = kt + 2 < kt1;
-      const int ibuf = buf == 0 ? 2 : buf - 1;            // ring slot of stage kt+2 (= slot of stage kt-1)
-      const int nbuf = buf == 2 ? 0 : buf + 1;
-      const char* base = lds + buf * ST_BYTES;
-      constexpr int NM = TN * TM;                 // MFMAs per group
-      constexpr bool FINE = (ABL & 128) != 0;     // one DMA piece every few MFMAs instead of a burst per group
-      // FINE: piece p is issued after MFMA number slot(p) of the K-step (0 .. 4*NM-1); the pieces whose slot lies in
-      // the first three groups are in flight at the barrier
-      constexpr int NB_FINE = (3 * NM * LPS + 4 * NM - 1) / (4 * NM) > LPS ? LPS : (3 * NM * LPS + 4 * NM - 1) / (4 * NM);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk < 3) frags(base, kk + 1, (kk + 1) & 1);
-        else if (next) frags(lds + nbuf * ST_BYTES, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk & 1][i], xa[kk & 1][j], acc[i][j], 0, 0, 0);
-            if constexpr (FINE) {
-              const int g = kk * NM + i * TM + j;      // MFMA number within the K-step
-              // piece p goes after MFMA g when p*4*NM/LPS <= g < (p+1)*4*NM/LPS and g is the first such
-#pragma unroll
-              for (int p = 0; p < LPS; ++p)
-                if (g == (p * 4 * NM) / LPS) {
-                  __builtin_amdgcn_sched_barrier(0);
-                  if ((ABL & 1) == 0 && more2) stage_piece(kt + 2, ibuf, p);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-          }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk < 3) {
-          if (!FINE && (ABL & 1) == 0 && more2) {
-#pragma unroll
-            for (int p = kk * LPS / 3; p < (kk + 1) * LPS / 3; ++p) stage_piece(kt + 2, ibuf, p);
-          }
-          if (kk == 2) {
-            // my pieces of stage kt+1 have landed (those of stage kt+2 issued so far may stay in flight)
-            if constexpr (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t0 = __builtin_readcyclecounter(); }
-            if (more2 && (ABL & 1) == 0) { if (FINE) glds_wait<NB_FINE>(); else glds_wait<LPS>(); }
-            else glds_wait<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of stage kt are in registers
-            if constexpr (PROF) { t1 = __builtin_readcyclecounter(); t_issue += t1 - t0; }
-            __syncthreads();
-            if constexpr (PROF) { t0 = __builtin_readcyclecounter(); t_wait += t0 - t1; }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      buf = nbuf;
-    }
-  } else
   for (int kt = kt0; kt < kt1; ++kt) {
     if constexpr (PROF) t0 = __builtin_readcyclecounter();
     // stage kt must have landed; the (up to NST-2) younger stages may stay in flight
@@ -807,14 +722,6 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
         case 22: launch_bf16<EPI, 320, 128, 2, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 24: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 25: launch_bf16<EPI, 192, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 40: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 42: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1, 64>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 43: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 44: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 128>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 45: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 46: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1, 64 + 128>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 47: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 48: launch_bf16<EPI, 160, 256, 1, 4, 64, 3, 1, 64 + 16 + 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
     } else
