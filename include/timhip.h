@@ -266,6 +266,29 @@ int timhip_gather_rows(int precision, const void* x_T, int B, int S, int E, int 
 int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, int n, float* dx,
                             void* stream);
 
+/* ---------------------------------------------------------------- loss tail of the training step */
+/* Label-smoothed cross entropy under mixup, as recognition/scripts/train.py:46-49,218-316 applies it through
+ * utils/mixup.py:24-39:  loss = lam * mean_{r: ta[r] != -1} CE(logits[r], ta[r]) + (1-lam) * mean_{r: tb[r] != -1}
+ * CE(logits[r], tb[r]),  CE with label smoothing `smoothing` (torch.nn.CrossEntropyLoss(label_smoothing, ignore_index=-1)).
+ * target_b may be NULL (plain criterion, lam = 1).  stats [rows,2] and accum [4] are scratch kept for the backward;
+ * loss is a device scalar.  dlogits = grad_out[0] * d loss / d logits (grad_out: device scalar or NULL = 1). */
+int timhip_ce_mixup_fwd(const float* logits, int rows, int C, int ld, const int64_t* target_a, const int64_t* target_b,
+                        float lam, float smoothing, float* stats, float* accum, float* loss, void* stream);
+int timhip_ce_mixup_bwd(const float* logits, int rows, int C, int ld, const int64_t* target_a, const int64_t* target_b,
+                        float lam, float smoothing, const float* stats, const float* accum, const float* grad_out,
+                        float* dlogits, int ldd, void* stream);
+
+/* DRLoc sample collection (models/helpers/losses/drloc.py:11-15,24-26,37-39): out[(b*m+i), 0:D] = x1[b, pos1[b,i], :],
+ * out[.., D:2D] = x2[b, pos2[b,i], :], cast to the operand dtype ([n*m, ld] GEMM operand of drloc_mlp.0).
+ * x1, x2: fp32 [n, l, D] views with element strides (batch_stride, row_stride, 1).  The scatter adds the gradient
+ * of that operand back: dx1[b, pos1[b,i], :] += d_pts[(b*m+i), 0:D] (fp32 atomics; positions repeat). */
+int timhip_drloc_gather(int precision, const float* x1, const float* x2, int64_t batch_stride, int64_t row_stride,
+                        int n, int l, int D, const int64_t* pos1, const int64_t* pos2, int m, void* out, int ld,
+                        void* stream);
+int timhip_drloc_scatter_add(const float* d_pts, int ldg, float* dx1, float* dx2, int64_t batch_stride,
+                             int64_t row_stride, int n, int l, int D, const int64_t* pos1, const int64_t* pos2, int m,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -281,3 +281,30 @@ def generate_queries(query_size):
 
 def to_torch(sd_np, dtype=torch.float32):
     return {k: torch.from_numpy(v).to(dtype) for k, v in sd_np.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# loss tail.  Pinned by tests/golden/loss_*.npz, generated from the reference's own mixup_criterion /
+# drloc functions by tests/golden/make_golden_loss.py.
+# ---------------------------------------------------------------------------------------------------------------------
+def mixup_ce(logits, ya, yb, lam, smoothing=0.2):
+    """scripts/train.py:46-49,218-258 + utils/mixup.py:24-39: rows with target -1 are dropped on each side, the
+    label-smoothed CE is averaged over the kept rows, the two sides are blended with lam."""
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=smoothing, ignore_index=-1)
+    va = ya != -1
+    loss_a = crit(logits[va], ya[va]).mean()
+    if yb is None:
+        return loss_a
+    vb = yb != -1
+    loss_b = crit(logits[vb], yb[vb]).mean()
+    return lam * loss_a + (1 - lam) * loss_b
+
+
+def drloc_loss(sd, x1, x2, pos_1, pos_2):
+    """models/helpers/losses/drloc.py:10-41 with the sampled positions given: x1, x2 [n, l, D]; pos [n, m]"""
+    n, l, D = x1.shape
+    idx = lambda x, pos: torch.gather(x, 1, pos.to(x.device).long().unsqueeze(-1).expand(-1, -1, D))   # collect_samples
+    pts = torch.cat([idx(x1, pos_1), idx(x2, pos_2)], dim=2)
+    deltax = torch.abs((pos_1 - pos_2).float())   # fp32, as drloc.py:21-22 (the division rounds in fp32)
+    deltax /= l
+    return torch.nn.functional.l1_loss(deltax, drloc_mlp(sd, pts))

@@ -161,4 +161,5 @@ class TIM(_TIMBase):
         if forward_type == "encoder":
             return self.forward_encoder(inputs, feature_times, target, label_queries)
         elif forward_type == "drloc_mlp":
-            return self.drloc_mlp(inputs).squeeze(2)
+            from .losses import drloc_mlp_forward
+            return drloc_mlp_forward(self, inputs)

@@ -297,6 +297,6 @@ class TIM(nn.Module):
         elif forward_type == "encoder":
             return self.forward_encoder(inputs, time_encodings, num_v_queries, num_a_queries)
         elif forward_type == "drloc_mlp":
-            # DRLoc auxiliary MLP (tim.py:129-135,190-191): adjacent to the hot path,
-            # stays stock PyTorch like the losses that call it.
-            return self.drloc_mlp(inputs).squeeze(2)
+            # DRLoc auxiliary MLP (tim.py:129-135,190-191) on the GEMM kernels
+            from .losses import drloc_mlp_forward
+            return drloc_mlp_forward(self, inputs)
