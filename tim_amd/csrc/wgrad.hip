@@ -12,6 +12,7 @@
 //
 // M is split across blockIdx.z; every split writes its partial tile into an fp32 slab with plain
 // coalesced stores and timhip's slab-reduce kernel adds the slabs into dW / db (no atomics).
+#include <cstdlib>
 #include "common.h"
 #include "mfma_tiles.h"
 
@@ -234,14 +235,29 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ slab, long long n,
 
 }  // namespace
 
+// Number of splits of the contraction (token) dimension.  Work items = tiles x splits run two per CU (512 slots).
+// Cost model in units of one 64-row K-step of one block, fitted to tools/wgrad_splits.py on the C2a shapes:
+//   steps per item x (full rounds + a partial round priced at 0.5 + 0.5 x its fill) + slab traffic per split
+// e.g. in-proj (192 tiles): 3 splits = 576 items (1.125 rounds) 108 us, 5 splits = 960 items 100 us.
 int tim_wgrad_splits(int Nout, int Kout, int M) {
   const int tiles = ((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT);
   const int nsteps = (M + WM - 1) / WM;
-  int sk = (512 + tiles - 1) / tiles;
-  if (sk > nsteps / 4) sk = nsteps / 4;
-  if (sk > 16) sk = 16;
-  if (sk < 1) sk = 1;
-  return sk;
+#ifdef TIMHIP_TUNING
+  if (const char* v = getenv("TIMHIP_WGRAD_SPLITS")) { int sk = atoi(v); if (sk >= 1 && sk <= nsteps) return sk; }
+#endif
+  int maxsk = nsteps / 4;
+  if (maxsk > 16) maxsk = 16;
+  if (maxsk < 1) maxsk = 1;
+  int best = 1;
+  float best_cost = 0.f;
+  for (int sk = 1; sk <= maxsk; ++sk) {
+    const float per = (float)((nsteps + sk - 1) / sk);
+    const float r = (float)tiles * sk / 512.f;
+    const float full = floorf(r), frac = r - full;
+    const float cost = per * (full + (frac > 0.f ? 0.5f + 0.5f * frac : 0.f)) + 1.5f * (float)tiles / 128.f * sk;
+    if (sk == 1 || cost < best_cost) { best = sk; best_cost = cost; }
+  }
+  return best;
 }
 
 // workspace: [slab sk*N*K fp32][db slab sk*N fp32]
