@@ -289,6 +289,22 @@ int timhip_drloc_scatter_add(const float* d_pts, int ldg, float* dx1, float* dx2
                              int64_t row_stride, int n, int l, int D, const int64_t* pos1, const int64_t* pos2, int m,
                              void* stream);
 
+/* ---------------------------------------------------------------- detection losses */
+/* sigmoid focal loss (detection models/helpers/losses/sigmoid.py:5-52) under get_loss(.., weights, reduction="sum")
+ * (losses/loss.py:5-14):  loss_sum = sum_{r: valid[r]} w[r] * sum_c focal(logits[r,c], targets[r,c]);  targets are the
+ * smoothed one-hot floats of det tim.py:157-184; row_weights / row_valid may be NULL; loss_elem (optional, [rows,C])
+ * receives the weighted per-element terms (reduction "none").  bwd: dlogits = grad_out[0] * d loss_sum / d logits. */
+int timhip_focal_loss_fwd(const float* logits, const float* targets, int rows, int C, const float* row_weights,
+                          const uint8_t* row_valid, float alpha, float gamma, float* loss_sum, float* loss_elem,
+                          void* stream);
+int timhip_focal_loss_bwd(const float* logits, const float* targets, int rows, int C, const float* row_weights,
+                          const uint8_t* row_valid, float alpha, float gamma, const float* grad_out, float* dlogits,
+                          void* stream);
+/* 1-D centre-offset DIoU loss (losses/iou.py:4-65), summed over the valid rows; offsets are [n,2] = (left, right).
+ * loss_sum and/or dpred (= grad_out[0] * d loss / d pred) are produced when non-NULL. */
+int timhip_diou_1d(const float* pred_offsets, const float* target_offsets, int n, const uint8_t* row_valid, float eps,
+                   const float* grad_out, float* loss_sum, float* dpred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -308,3 +308,33 @@ def drloc_loss(sd, x1, x2, pos_1, pos_2):
     deltax = torch.abs((pos_1 - pos_2).float())   # fp32, as drloc.py:21-22 (the division rounds in fp32)
     deltax /= l
     return torch.nn.functional.l1_loss(deltax, drloc_mlp(sd, pts))
+
+
+def focal_loss(x, t, weights=None, alpha=0.25, gamma=2.0, reduction="sum"):
+    """detection models/helpers/losses/sigmoid.py:5-52 under losses/loss.py:5-14 (row weights, reduction)"""
+    p = torch.sigmoid(x)
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(x, t, reduction="none")
+    p_t = p * t + (1 - p) * (1 - t)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * t + (1 - alpha) * (1 - t)) * loss
+    if weights is not None:
+        loss = loss * weights[:, None]
+    return loss.sum() if reduction == "sum" else (loss.mean() if reduction == "mean" else loss)
+
+
+def diou_1d(pred, tgt, eps=1e-8):
+    """detection models/helpers/losses/iou.py:4-65 ("sum").  The reference function is TorchScript; once compiled its
+    autodiff gives min / max a gradient only under STRICT inequality and clamp(min) only where the input >= min (its first,
+    profiling calls split exact ties like eager torch) - the torch.where forms below are the compiled behaviour; the golden
+    vectors contain no exact ties."""
+    lp, rp, lg, rg = pred[:, 0], pred[:, 1], tgt[:, 0].detach(), tgt[:, 1].detach()
+    smin = lambda a, b: torch.where(a < b, a, b)
+    smax = lambda a, b: torch.where(a > b, a, b)
+    sclamp = lambda u: torch.where(u >= eps, u, torch.full_like(u, eps).detach())
+    inter = smin(rp, rg) + smin(lp, lg)
+    union = (lp + rp) + (lg + rg) - inter
+    iou = inter / sclamp(union)
+    len_c = smax(lp, lg) + smax(rp, rg)
+    rho = 0.5 * (rp - lp - rg + lg)
+    return (1.0 - iou + torch.square(rho / sclamp(len_c))).sum()

@@ -1,6 +1,7 @@
 """Golden vectors for the loss tail from the reference's own functions (build container only).
 
-    python tests/golden/make_golden_loss.py
+    python tests/golden/make_golden_loss.py              (recognition: mixup CE, DRLoc)
+    python tests/golden/make_golden_loss.py detection    (detection: focal, DIoU)
 
 Imports utils/mixup.py and models/helpers/losses/drloc.py of /root/reference/recognition (torch + numpy only) and the
 reference TIM module (for its drloc_mlp), feeds them inputs that `tim_amd.synth` regenerates from a seed, and stores
@@ -28,9 +29,11 @@ class _PM:
 
 
 sys.modules["fvcore.common.file_io"].PathManager = _PM
-sys.path.insert(0, "/root/reference/recognition")
+VARIANT = "detection" if len(sys.argv) > 1 and sys.argv[1] == "detection" else "recognition"
+sys.path.insert(0, "/root/reference/" + VARIANT)
 from time_interval_machine.models.tim import TIM  # noqa: E402
-from time_interval_machine.utils.mixup import mixup_criterion  # noqa: E402
+if VARIANT == "recognition":
+    from time_interval_machine.utils.mixup import mixup_criterion  # noqa: E402
 import time_interval_machine.models.helpers.losses.drloc as ref_drloc  # noqa: E402
 
 from tim_amd import synth  # noqa: E402
@@ -87,7 +90,45 @@ def drloc_case(name, cfg_name, n, m, seed, crossmodal):
     print(name, "loss", loss.item())
 
 
-if __name__ == "__main__":
+def det_case(name, rows, C, n_reg, seed):
+    """detection: get_loss(sigmoid_focal_loss, preds[valid], targets[valid], weights=ious, reduction="sum") and
+    get_loss(ctr_diou_loss_1d, reg[pos], offsets[pos], reduction="sum") as det train.py:222-285 calls them.
+    Run in a separate process: python tests/golden/make_golden_loss.py detection"""
+    from time_interval_machine.models.helpers.losses.sigmoid import sigmoid_focal_loss
+    from time_interval_machine.models.helpers.losses.iou import ctr_diou_loss_1d
+    from time_interval_machine.models.helpers.losses.loss import get_loss
+    logits = torch.from_numpy(synth.normal(seed, "focal_logits", (rows, C), std=3.0)).float().requires_grad_(True)
+    u = synth.uniform01(seed, "focal_aux", (rows, 3))
+    cls = np.floor(u[:, 0] * C).astype(np.int64)
+    tgt = np.full((rows, C), 0.1 / C, dtype=np.float32)                 # smoothed one-hot (det tim.py:157-184)
+    tgt[np.arange(rows), cls] += 0.9
+    tgt[u[:, 1] < 0.3] = 0.0                                              # background rows
+    targets = torch.from_numpy(tgt)
+    ious = torch.from_numpy((u[:, 2] * 1.2 - 0.2).astype(np.float32))    # < 0: row not used for classification
+    valid = ious >= 0.0
+    w = ious[valid].clone()
+    w.masked_fill_(w < 0.6, 1.0)
+    loss = get_loss(sigmoid_focal_loss, logits[valid], targets[valid], weights=w, reduction="sum")
+    loss.backward()
+    elem = get_loss(sigmoid_focal_loss, logits[valid].detach(), targets[valid], weights=w, reduction="none")
+    v = synth.uniform(seed, "diou", (n_reg, 4), 0.0, 1.0).astype(np.float32)
+    # (no exact ties / all-zero rows: there the reference's own gradient depends on whether TorchScript is still in its
+    #  profiling run - eager tie-splitting - or already runs the differentiated graph - strict comparisons)
+    pred = torch.from_numpy(v[:, :2].copy()).requires_grad_(True)
+    off = torch.from_numpy(v[:, 2:].copy())
+    reg = get_loss(ctr_diou_loss_1d, pred, off, reduction="sum")
+    reg.backward()
+    np.savez(os.path.join(HERE, "loss_det_%s.npz" % name), rows=rows, C=C, seed=seed, targets=tgt, ious=ious.numpy(),
+             focal=loss.item(), dlogits=logits.grad.numpy(), elem_rowsum=elem.sum(1).numpy(), pred=v[:, :2], off=v[:, 2:],
+             diou=reg.item(), dpred=pred.grad.numpy())
+    print(name, "focal", loss.item(), "diou", reg.item())
+
+
+if __name__ == "__main__" and VARIANT == "detection":
+    det_case("small", 29, 13, 9, 31)
+    det_case("verb", 399 * 2, 97, 40, 32)
+
+if __name__ == "__main__" and VARIANT == "recognition":
     ce_case("small", 37, 13, 0.3, 11, 0.25)
     ce_case("action", 96, 3806, 0.71, 12, 0.3)
     ce_case("nomix", 50, 97, 1.0, 13, 0.2)

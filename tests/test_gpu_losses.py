@@ -13,7 +13,7 @@ from oracle import tim_oracle as O  # noqa: E402
 from tim_amd import losses  # noqa: E402
 from tim_amd.tim import TIM  # noqa: E402
 from tests.helpers import GOLDEN  # noqa: E402
-from tests.test_loss_oracle import CE_CASES, DR_CASES, ce_inputs, drloc_inputs  # noqa: E402
+from tests.test_loss_oracle import CE_CASES, DET_CASES, DR_CASES, ce_inputs, det_inputs, drloc_inputs  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -92,3 +92,35 @@ def test_drloc_loss(case, prec):
     ref = O.drloc_mlp({k: v.double() for k, v in sd.items()}, pts.cpu().double())
     assert pred.shape == ref.shape
     assert (pred.cpu().double() - ref).abs().max().item() < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", DET_CASES)
+def test_detection_losses(case):
+    """focal (row weights, row filter, sum / none) and 1-D DIoU on the HIP kernels vs the reference-generated vectors"""
+    g = np.load(os.path.join(GOLDEN, case))
+    logits, targets, w, valid = det_inputs(g)
+    x = logits.to(DEV).requires_grad_(True)
+    # masked form: no row filtering on the host
+    loss = losses.focal_loss_sum(x, targets.to(DEV), row_weights=w.to(DEV), row_valid=valid.to(DEV))
+    (loss * 0.5).backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["focal"])) <= 2e-5 * abs(float(g["focal"]))
+    sc = float(np.abs(g["dlogits"]).max())
+    assert np.abs(x.grad.cpu().numpy() * 2.0 - g["dlogits"]).max() <= 1e-5 * sc
+    # the reference's call: get_loss(criterion, preds[valid], targets[valid], weights=ious, reduction=...)
+    xv, tv, wv = logits[valid].to(DEV), targets[valid].to(DEV), w[valid].to(DEV)
+    same = losses.get_loss(losses.sigmoid_focal_loss, xv, tv, weights=wv, reduction="sum")
+    assert abs(same.item() - float(g["focal"])) <= 2e-5 * abs(float(g["focal"]))
+    elem = losses.get_loss(losses.sigmoid_focal_loss, xv, tv, weights=wv, reduction="none")
+    assert elem.shape == xv.shape
+    assert np.abs(elem.sum(1).cpu().numpy() - g["elem_rowsum"]).max() <= 2e-5 * np.abs(g["elem_rowsum"]).max()
+    plain = losses.sigmoid_focal_loss(xv, tv, reduction="mean")
+    ref = O.focal_loss(logits[valid].double(), targets[valid].double(), None, reduction="mean")
+    assert abs(plain.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    # DIoU
+    pred = torch.from_numpy(g["pred"]).to(DEV).requires_grad_(True)
+    reg = losses.get_loss(losses.ctr_diou_loss_1d, pred, torch.from_numpy(g["off"]).to(DEV), reduction="sum")
+    reg.backward()
+    torch.cuda.synchronize()
+    assert abs(reg.item() - float(g["diou"])) <= 1e-5 * abs(float(g["diou"]))
+    assert np.abs(pred.grad.cpu().numpy() - g["dpred"]).max() <= 1e-4

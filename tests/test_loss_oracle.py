@@ -13,6 +13,7 @@ from tim_amd.config import named_config
 from tests.helpers import GOLDEN
 
 CE_CASES = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "loss_ce_*.npz")))
+DET_CASES = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "loss_det_*.npz")))
 DR_CASES = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "loss_drloc_*.npz")))
 
 
@@ -62,3 +63,31 @@ def test_drloc_oracle_matches_reference(case):
     for k in sd:
         if k.startswith("drloc_mlp."):
             assert np.abs(sd[k].grad.numpy() - g["g_" + k]).max() < 1e-7, k
+
+
+def det_inputs(g):
+    rows, C, seed = int(g["rows"]), int(g["C"]), int(g["seed"])
+    logits = torch.from_numpy(synth.normal(seed, "focal_logits", (rows, C), std=3.0)).float()
+    ious = torch.from_numpy(g["ious"])
+    valid = ious >= 0.0
+    w = ious.clone()
+    w[(w < 0.6) & valid] = 1.0          # det train.py:228: v_ious.masked_fill_(v_ious < iou_threshold, 1.0) on the valid rows
+    return logits, torch.from_numpy(g["targets"]), w, valid
+
+
+@pytest.mark.parametrize("case", DET_CASES)
+def test_detection_losses_oracle_matches_reference(case):
+    g = np.load(os.path.join(GOLDEN, case))
+    logits, targets, w, valid = det_inputs(g)
+    x = logits.clone().requires_grad_(True)
+    loss = O.focal_loss(x[valid], targets[valid], w[valid])
+    loss.backward()
+    assert abs(loss.item() - float(g["focal"])) <= 1e-6 * abs(float(g["focal"]))
+    assert np.abs(x.grad.numpy() - g["dlogits"]).max() <= 1e-6 * np.abs(g["dlogits"]).max()
+    elem = O.focal_loss(logits[valid], targets[valid], w[valid], reduction="none")
+    assert np.abs(elem.sum(1).numpy() - g["elem_rowsum"]).max() <= 1e-5 * np.abs(g["elem_rowsum"]).max()
+    pred = torch.from_numpy(g["pred"]).requires_grad_(True)
+    reg = O.diou_1d(pred, torch.from_numpy(g["off"]))
+    reg.backward()
+    assert abs(reg.item() - float(g["diou"])) <= 1e-6 * abs(float(g["diou"]))
+    assert np.abs(pred.grad.numpy() - g["dpred"]).max() <= 1e-6

@@ -99,9 +99,143 @@ __global__ void drloc_scatter_kernel(const float* __restrict__ g, int ldg, float
   for (int c = threadIdx.x; c < D; c += blockDim.x) atomicAdd(dst + c, src[c]);
 }
 
+// ---- detection losses ---------------------------------------------------------------------------------
+// sigmoid focal loss (detection models/helpers/losses/sigmoid.py:5-52) with the per-row weights and the "sum"
+// reduction of get_loss (losses/loss.py:5-14), rows with valid[r] == 0 skipped (train.py:224-226 filters them):
+//   loss = sum_r w_r sum_c alpha_t ce (1 - p_t)^gamma
+struct FocalTerm { float loss, dx; };
+__device__ __forceinline__ FocalTerm focal_term(float x, float t, float alpha, float gamma) {
+  const float p = 1.f / (1.f + __expf(-x));
+  const float ce = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));     // BCE with logits
+  const float pt = p * t + (1.f - p) * (1.f - t);
+  const float q = 1.f - pt;
+  const float mod = gamma == 2.f ? q * q : powf(q, gamma);
+  const float dmod = gamma == 2.f ? 2.f * q : (q > 0.f ? gamma * powf(q, gamma - 1.f) : 0.f);
+  const float at = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+  FocalTerm r;
+  r.loss = at * ce * mod;
+  // d ce / dx = p - t ; d q / dx = -(2t - 1) p (1 - p)
+  r.dx = at * ((p - t) * mod - ce * dmod * (2.f * t - 1.f) * p * (1.f - p));
+  return r;
+}
+
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                        long long n, int C, const float* __restrict__ w,
+                                                        const unsigned char* __restrict__ valid, float alpha,
+                                                        float gamma, float* __restrict__ out,
+                                                        float* __restrict__ elem) {
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C;
+    float v = 0.f;
+    if (!valid || valid[r]) v = (w ? w[r] : 1.f) * focal_term(x[i], t[i], alpha, gamma).loss;
+    if (elem) elem[i] = v;   // reduction = "none" (the training loop's positive / negative split meters)
+    acc += v;
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                        long long n, int C, const float* __restrict__ w,
+                                                        const unsigned char* __restrict__ valid, float alpha,
+                                                        float gamma, const float* __restrict__ gout,
+                                                        float* __restrict__ dx) {
+  const float g = gout ? gout[0] : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C;
+    float v = 0.f;
+    if (!valid || valid[r]) v = g * (w ? w[r] : 1.f) * focal_term(x[i], t[i], alpha, gamma).dx;
+    dx[i] = v;
+  }
+}
+
+// 1-D centre-offset DIoU loss (losses/iou.py:4-65), "sum" reduction over the rows with valid[r] != 0; off = (left, right)
+__global__ void diou_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, int n,
+                            const unsigned char* __restrict__ valid, float eps, const float* __restrict__ gout,
+                            float* __restrict__ loss, float* __restrict__ dpred) {
+  float acc = 0.f;
+  const float g = gout ? gout[0] : 1.f;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    float dl = 0.f, dr = 0.f;
+    if (!valid || valid[r]) {
+      const float lp = pred[2 * r], rp = pred[2 * r + 1], lg = tgt[2 * r], rg = tgt[2 * r + 1];
+      const float lk = fminf(lp, lg), rk = fminf(rp, rg);
+      const float I = rk + lk, U = (lp + rp) + (lg + rg) - I, Uc = fmaxf(U, eps);
+      const float lc = fmaxf(lp, lg), rc = fmaxf(rp, rg), Lc = lc + rc, Lcc = fmaxf(Lc, eps);
+      const float rho = 0.5f * (rp - lp - rg + lg), z = rho / Lcc;
+      acc += 1.f - I / Uc + z * z;
+      if (dpred) {
+        // The reference function is TorchScript (@torch.jit.script, iou.py:3): once compiled, its autodiff of min / max
+        // passes the gradient under STRICT comparison (nothing at an exact tie) and clamp(min=eps) where the input >= eps;
+        // its first (profiling) calls split ties like eager torch.  Only exact ties differ; this follows the compiled form.
+        const float dI_l = lp < lg ? 1.f : 0.f, dI_r = rp < rg ? 1.f : 0.f;
+        const float dLc_l = lp > lg ? 1.f : 0.f, dLc_r = rp > rg ? 1.f : 0.f;
+        const float uok = U >= eps ? 1.f : 0.f, lok = Lc >= eps ? 1.f : 0.f;
+        // d(I/Uc): dI/Uc - I/Uc^2 dUc ; dU/dlp = 1 - dI_l
+        const float a = 1.f / Uc, b = I / (Uc * Uc);
+        const float diou_l = dI_l * a - b * uok * (1.f - dI_l), diou_r = dI_r * a - b * uok * (1.f - dI_r);
+        // d(z^2) = 2 z (d rho / Lcc - rho / Lcc^2 dLcc)
+        const float dz_l = (-0.5f) / Lcc - rho / (Lcc * Lcc) * lok * dLc_l;
+        const float dz_r = (0.5f) / Lcc - rho / (Lcc * Lcc) * lok * dLc_r;
+        dl = g * (-diou_l + 2.f * z * dz_l);
+        dr = g * (-diou_r + 2.f * z * dz_r);
+      }
+    }
+    if (dpred) { dpred[2 * r] = dl; dpred[2 * r + 1] = dr; }
+  }
+  if (loss) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int timhip_focal_loss_fwd(const float* logits, const float* targets, int rows, int C, const float* row_weights,
+                          const uint8_t* row_valid, float alpha, float gamma, float* loss_sum, float* loss_elem,
+                          void* stream) {
+  if (!logits || !targets || !loss_sum || rows < 0 || C <= 0) return TIMHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return TIMHIP_ELAUNCH;
+  if (rows == 0) return TIMHIP_OK;
+  const long long n = (long long)rows * C;
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocks), dim3(256), 0, s, logits, targets, n, C, row_weights, row_valid, alpha,
+                     gamma, loss_sum, loss_elem);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_focal_loss_bwd(const float* logits, const float* targets, int rows, int C, const float* row_weights,
+                          const uint8_t* row_valid, float alpha, float gamma, const float* grad_out, float* dlogits,
+                          void* stream) {
+  if (!logits || !targets || !dlogits || rows < 0 || C <= 0) return TIMHIP_EINVAL;
+  if (rows == 0) return TIMHIP_OK;
+  const long long n = (long long)rows * C;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, targets, n, C, row_weights,
+                     row_valid, alpha, gamma, grad_out, dlogits);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_diou_1d(const float* pred_offsets, const float* target_offsets, int n, const uint8_t* row_valid, float eps,
+                   const float* grad_out, float* loss_sum, float* dpred, void* stream) {
+  if (!pred_offsets || !target_offsets || n < 0 || (!loss_sum && !dpred)) return TIMHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (loss_sum && hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return TIMHIP_ELAUNCH;
+  if (n == 0) return TIMHIP_OK;
+  hipLaunchKernelGGL(diou_kernel, dim3((n + 255) / 256 > 256 ? 256 : (n + 255) / 256), dim3(256), 0, s, pred_offsets,
+                     target_offsets, n, row_valid, eps, grad_out, loss_sum, dpred);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
 
 int timhip_ce_mixup_fwd(const float* logits, int rows, int C, int ld, const int64_t* target_a, const int64_t* target_b,
                         float lam, float smoothing, float* stats, float* accum, float* loss, void* stream) {

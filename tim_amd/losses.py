@@ -249,3 +249,129 @@ def dense_relative_localization_loss_crossmodal(x1, x2, model, m, positions=None
     """drloc.py:30-41 (train.py:331-336 passes output[1][:, :num_feats] and output[1][:, num_feats:])"""
     assert x1.size() == x2.size()
     return _drloc(x1, x2, model, m, positions)
+
+
+# ==================================================================================================
+# detection losses (SURVEY 8f-2)
+# ==================================================================================================
+class _FocalSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, row_weights, row_valid, alpha, gamma):
+        _require_gpu(logits, "sigmoid focal loss")
+        x = _f32c(logits)
+        t = _f32c(targets).to(x.device)
+        if x.shape != t.shape:
+            raise ValueError("Mismatch in input and target shape: %s != %s" % (tuple(x.shape), tuple(t.shape)))
+        Cn = x.shape[-1] if x.dim() > 1 else 1
+        rows = x.numel() // max(Cn, 1)
+        w = None if row_weights is None else _f32c(row_weights).to(x.device).reshape(-1)
+        v = None if row_valid is None else row_valid.to(device=x.device, dtype=torch.uint8).contiguous().reshape(-1)
+        if (w is not None and w.numel() != rows) or (v is not None and v.numel() != rows):
+            raise ValueError("one weight / valid flag per row")
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        call("timhip_focal_loss_fwd", ptr(x), ptr(t), rows, Cn, ptr(w), ptr(v), float(alpha), float(gamma), ptr(loss),
+             None, _stream())
+        ctx.alpha, ctx.gamma, ctx.rows, ctx.C = float(alpha), float(gamma), rows, Cn
+        ctx.save_for_backward(x, t, w if w is not None else x.new_empty(0), v if v is not None else x.new_empty(0, dtype=torch.uint8))
+        ctx.has = (w is not None, v is not None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, w, v = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        gout = _f32c(g).reshape(1)
+        call("timhip_focal_loss_bwd", ptr(x), ptr(t), ctx.rows, ctx.C, ptr(w) if ctx.has[0] else None,
+             ptr(v) if ctx.has[1] else None, ctx.alpha, ctx.gamma, ptr(gout), ptr(dx), _stream())
+        return dx, None, None, None, None, None
+
+
+def focal_loss_sum(logits, targets, row_weights=None, row_valid=None, alpha=0.25, gamma=2.0):
+    """sum_{r: row_valid[r]} row_weights[r] * sum_c focal(logits[r,c], targets[r,c]): the value det train.py:235-262 gets from
+    `get_loss(sigmoid_focal_loss, preds[valid], targets[valid], weights=ious, reduction="sum")`, without the filtering."""
+    return _FocalSumFn.apply(logits, targets, row_weights, row_valid, alpha, gamma)
+
+
+def sigmoid_focal_loss(inputs, targets, alpha: float = 0.25, gamma: float = 2.0, reduction: str = "none"):
+    """detection models/helpers/losses/sigmoid.py:5-52, same arguments"""
+    if reduction == "sum":
+        return focal_loss_sum(inputs, targets, None, None, alpha, gamma)
+    if reduction == "mean":
+        return focal_loss_sum(inputs, targets, None, None, alpha, gamma) / max(inputs.numel(), 1)
+    return _focal_elementwise(inputs, targets, None, alpha, gamma)
+
+
+def _focal_elementwise(inputs, targets, weights, alpha, gamma):
+    """reduction "none" (meters only: no gradient)"""
+    _require_gpu(inputs, "sigmoid focal loss")
+    x = _f32c(inputs)
+    t = _f32c(targets).to(x.device)
+    Cn = x.shape[-1] if x.dim() > 1 else 1
+    rows = x.numel() // max(Cn, 1)
+    w = None if weights is None else _f32c(weights).to(x.device).reshape(-1)
+    out = torch.empty_like(x)
+    tot = torch.empty((), dtype=torch.float32, device=x.device)
+    call("timhip_focal_loss_fwd", ptr(x), ptr(t), rows, Cn, ptr(w), None, float(alpha), float(gamma), ptr(tot), ptr(out),
+         _stream())
+    return out
+
+
+class _DiouSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, row_valid, eps):
+        _require_gpu(pred, "ctr_diou_loss_1d")
+        p = _f32c(pred).reshape(-1, 2)
+        t = _f32c(target).to(p.device).reshape(-1, 2)
+        v = None if row_valid is None else row_valid.to(device=p.device, dtype=torch.uint8).contiguous().reshape(-1)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        call("timhip_diou_1d", ptr(p), ptr(t), p.shape[0], ptr(v), float(eps), None, ptr(loss), None, _stream())
+        ctx.eps, ctx.has_v = float(eps), v is not None
+        ctx.save_for_backward(p, t, v if v is not None else p.new_empty(0, dtype=torch.uint8))
+        ctx.shape = tuple(pred.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, v = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        gout = _f32c(g).reshape(1)
+        call("timhip_diou_1d", ptr(p), ptr(t), p.shape[0], ptr(v) if ctx.has_v else None, ctx.eps, ptr(gout), None, ptr(dp),
+             _stream())
+        return dp.view(ctx.shape), None, None, None
+
+
+def diou_loss_sum(pred_offsets, target_offsets, row_valid=None, eps=1e-8):
+    """sum over the valid rows of the 1-D centre-offset DIoU loss (det train.py:277-285 without the row filtering)"""
+    return _DiouSumFn.apply(pred_offsets, target_offsets, row_valid, eps)
+
+
+def ctr_diou_loss_1d(input_offsets, target_offsets, reduction: str = "none", eps: float = 1e-8):
+    """detection models/helpers/losses/iou.py:4-65, same arguments ("none" is not needed by the training loop)"""
+    if reduction == "sum":
+        return diou_loss_sum(input_offsets, target_offsets, None, eps)
+    if reduction == "mean":
+        n = input_offsets.shape[0]
+        s = diou_loss_sum(input_offsets, target_offsets, None, eps)
+        return s / n if n > 0 else 0.0 * s
+    raise NotImplementedError('ctr_diou_loss_1d: reduction "none" is not built (the training loop uses "sum")')
+
+
+def get_loss(criterion, pred, y, weights=None, reduction="mean"):
+    """detection models/helpers/losses/loss.py:5-14, same arguments.  The focal criterion with row weights runs as one
+    fused kernel; any other criterion takes the reference's generic route."""
+    if criterion is sigmoid_focal_loss:
+        if reduction == "sum":
+            return focal_loss_sum(pred, y, weights, None)
+        if reduction == "mean":
+            return focal_loss_sum(pred, y, weights, None) / max(pred.numel(), 1)
+        return _focal_elementwise(pred, y, weights, 0.25, 2.0)
+    if criterion is ctr_diou_loss_1d and weights is None and reduction in ("sum", "mean"):
+        return ctr_diou_loss_1d(pred, y, reduction=reduction)
+    loss = criterion(pred, y)
+    if weights is not None:
+        loss = loss * weights[:, None]
+    if reduction == "mean":
+        return loss.mean()
+    elif reduction == "sum":
+        return loss.sum()
+    return loss
