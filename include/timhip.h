@@ -305,6 +305,26 @@ int timhip_focal_loss_bwd(const float* logits, const float* targets, int rows, i
 int timhip_diou_1d(const float* pred_offsets, const float* target_offsets, int n, const uint8_t* row_valid, float eps,
                    const float* grad_out, float* loss_sum, float* dpred, void* stream);
 
+/* ---------------------------------------------------------------- 1-D segment NMS */
+/* Batched soft-NMS over independent groups (one per video x class), bit-identical in its selection to
+ * detection/eval_detection/csrc/nms_cpu.cpp:69-170 (softnms_1d_cpu) run on each group:
+ *   segs [N,2], scores [N] grouped contiguously; group g = rows [group_offsets[g], group_offsets[g+1]) (int32, device copy
+ *   and host copy of the same G+1 values); method 0 vanilla / 1 linear / 2 gaussian.
+ *   dets [N,3]: for group g rows group_offsets[g] .. +count[g]-1 hold (start, end, score at selection) in selection order,
+ *   inds [N]: the selected segments' indices relative to the group's first row; count [G].
+ * workspace: timhip_softnms_1d_workspace_bytes(N, G) bytes of device memory.  Synchronises `stream` before returning
+ * (it stages per-size-class group lists from pageable host memory). */
+size_t timhip_softnms_1d_workspace_bytes(int64_t n_total, int n_groups);
+int timhip_softnms_1d(const float* segs, const float* scores, const int32_t* group_offsets,
+                      const int32_t* group_offsets_host, int n_groups, float iou_threshold, float sigma, float min_score,
+                      int method, float* dets, int32_t* inds, int32_t* count, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* Batched vanilla NMS (nms_cpu.cpp:19-60): order [N] = for each group the positions (relative to the group) sorted by
+ * descending score; keep [N] receives per group the kept positions in that order, count [G] their number;
+ * removed_scratch: N bytes. */
+int timhip_nms_1d(const float* segs, const int32_t* order, const int32_t* group_offsets, int n_groups, float iou_threshold,
+                  uint8_t* removed_scratch, int32_t* keep, int32_t* count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
