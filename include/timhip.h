@@ -325,6 +325,23 @@ int timhip_softnms_1d(const float* segs, const float* scores, const int32_t* gro
 int timhip_nms_1d(const float* segs, const int32_t* order, const int32_t* group_offsets, int n_groups, float iou_threshold,
                   uint8_t* removed_scratch, int32_t* keep, int32_t* count, void* stream);
 
+/* ---------------------------------------------------------------- sliding-window batch assembly */
+/* recognition datasets/sliding_window.py:341-421 (__getitem__) for a batch, on feature stores resident in HBM.
+ * feats [sum_v N_feat(v) * num_aug, C] fp32: every video's [N_feat, num_aug, C] array, concatenated;
+ * video_row0[w] = first feature row (before the num_aug factor) of window w's video; feat_indices [W, num_feats] (int32);
+ * windows [B] = the window ids of the batch; aug_indices [B*num_feats] in [0, num_aug) or NULL (0).
+ * out [B, num_feats, C] = feats[(video_row0[w] + feat_indices[w, j]) * num_aug + aug[b, j]]            (:352-358, :364-370) */
+int timhip_window_gather(const float* feats, int C, int num_aug, const int64_t* video_row0, const int32_t* feat_indices,
+                         int num_feats, const int32_t* windows, int B, const int32_t* aug_indices, float* out,
+                         void* stream);
+/* times [B, T, 2], T = (v ? nf : 0) + (a ? nf : 0) + max_v + max_a, rows ordered vis feats | aud feats | v queries | a queries:
+ * clamp((t - start_sec[w]) / window_size, min=0)   (:359-360, :371-372, :402-404).  *_feat_times [rows, ld >= 2] per-video
+ * feature (start, end) tables concatenated like feats (without the num_aug factor); *_queries [W, max, 2] zero padded. */
+int timhip_window_times(const float* v_feat_times, int v_ld, const int64_t* v_row0, const float* a_feat_times, int a_ld,
+                        const int64_t* a_row0, const int32_t* feat_indices, int num_feats, const int32_t* windows, int B,
+                        const float* v_queries, int max_v, const float* a_queries, int max_a, const float* start_sec,
+                        float window_size, float* times, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
