@@ -83,8 +83,13 @@ typedef struct TimDesc {
   float p_drop;      /* encoder dropout probability; 0 => evaluation mode */
   uint64_t seed;     /* Philox key for this step */
   int32_t layer;     /* layer index (part of the Philox stream id) */
-  int32_t reserved;
+  int32_t reserved;  /* flags: TIMHIP_DESC_* (0 by default) */
 } TimDesc;
+/* TimDesc.reserved flags */
+#define TIMHIP_DESC_ATTN_FP32 1        /* run the attention in fp32 arithmetic (reference kernels) */
+#define TIMHIP_DESC_ATTN_BWD_ONE_KERNEL 2 /* single-kernel MFMA attention backward */
+#define TIMHIP_DESC_WGRAD_OVERWRITE 4  /* bf16 only: timhip_layer_bwd[_weights] WRITES the weight and bias gradients of the four
+                                          Linears (dW = ..., not +=): those buffers need no zero fill and are not read */
 
 /* One encoder layer.  *_op are operand-dtype working copies made by timhip_prepare_weights:
  * w (as stored, [N,K]) and wt (transposed, [K,N]).  Biases and LayerNorm parameters are the

@@ -39,6 +39,9 @@ class TimLayerGrads(C.Structure):
     _fields_ = [(n, vp) for n in _LG]
 
 
+DESC_ATTN_FP32, DESC_ATTN_BWD_ONE_KERNEL, DESC_WGRAD_OVERWRITE = 1, 2, 4   # TimDesc.reserved flags
+
+
 class TimCastItem(C.Structure):
     _fields_ = [("src", vp), ("plain", vp), ("tr", vp), ("rows", i32), ("cols", i32), ("ldp", i32), ("ldt", i32)]
 

@@ -111,11 +111,12 @@ TimEpi epi0() {
 // Both operands are transposed into K(=M)-contiguous copies, the product runs split-K into fp32
 // slabs (plain coalesced stores, no atomics) and one reduce kernel adds the slabs into dW.
 int wgrad(int prec, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
-          void* ws, size_t ws_bytes, hipStream_t s) {
+          void* ws, size_t ws_bytes, hipStream_t s, int accumulate = 1) {
   const int Mp = round_up(M, 64);
   const WgradWs W = wgrad_ws(prec, Nout, Kout, M);
   if (ws_bytes < W.total) return TIMHIP_EWORKSPACE;
-  if (prec == TIMHIP_PREC_BF16) return tim_wgrad_tn_bf16(dY, ldy, Nout, X, ldx, Kout, M, dW, db, ws, ws_bytes, s);
+  if (prec == TIMHIP_PREC_BF16) return tim_wgrad_tn_bf16(dY, ldy, Nout, X, ldx, Kout, M, dW, db, ws, ws_bytes, s, accumulate);
+  if (!accumulate) return TIMHIP_EUNSUPPORTED;   // the fp32 / bf16x3 route accumulates into dW
   char* w = (char*)ws;
   void* tA = w + W.tA; void* tB = w + W.tB; float* slab = (float*)(w + W.slab);
   int rc;
@@ -295,10 +296,12 @@ int timhip_layer_bwd_weights(const TimDesc* dp, const void* x_in_T, const void* 
   const char* sv = (const char*)saved;
   const char* yb = (const char*)dy;
   // linear2: dW2 += df^T h ; linear1: dW1 += du^T x1 ; out-proj: dWo += da^T o ; in-proj: dWin += dqkv^T x_in
-  if ((rc = wgrad(prec, yb + Y.df, E, E, sv + L.h, FF, FF, M, g->l2_w, g->l2_b, workspace, workspace_bytes, s))) return rc;
-  if ((rc = wgrad(prec, yb + Y.du, FF, FF, sv + L.x1t, E, E, M, g->l1_w, g->l1_b, workspace, workspace_bytes, s))) return rc;
-  if ((rc = wgrad(prec, yb + Y.da, E, E, sv + L.o, E, E, M, g->out_w, g->out_b, workspace, workspace_bytes, s))) return rc;
-  return wgrad(prec, yb + Y.dqkv, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, workspace, workspace_bytes, s);
+  // (TIMHIP_DESC_WGRAD_OVERWRITE: "=" instead of "+=": the gradient buffers are neither zero-filled nor read)
+  const int acc = (d.reserved & TIMHIP_DESC_WGRAD_OVERWRITE) ? 0 : 1;
+  if ((rc = wgrad(prec, yb + Y.df, E, E, sv + L.h, FF, FF, M, g->l2_w, g->l2_b, workspace, workspace_bytes, s, acc))) return rc;
+  if ((rc = wgrad(prec, yb + Y.du, FF, FF, sv + L.x1t, E, E, M, g->l1_w, g->l1_b, workspace, workspace_bytes, s, acc))) return rc;
+  if ((rc = wgrad(prec, yb + Y.da, E, E, sv + L.o, E, E, M, g->out_w, g->out_b, workspace, workspace_bytes, s, acc))) return rc;
+  return wgrad(prec, yb + Y.dqkv, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, workspace, workspace_bytes, s, acc);
 }
 
 // single-stream form: data chain followed by the weight gradients

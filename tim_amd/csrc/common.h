@@ -237,7 +237,7 @@ int tim_transpose(int precision, const void* src, int rows, int cols, int lds, v
 int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStream_t s);
 size_t tim_wgrad_tn_ws(int Nout, int Kout, int M);
 int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
-                      void* ws, size_t ws_bytes, hipStream_t s);
+                      void* ws, size_t ws_bytes, hipStream_t s, int accumulate = 1);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,

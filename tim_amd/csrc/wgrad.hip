@@ -202,13 +202,14 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
 }
 
 // dW[i] += sum_z slab[z*n + i] (float4) and db[j] += sum_z dbs[z*nb + j]: one launch for both
+// accumulate == 0: dW / db are WRITTEN (the caller's gradient buffer need not be zeroed nor read)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n, int nslab, float* __restrict__ dW,
-                                    const float* __restrict__ dbs, int nb, float* __restrict__ db) {
+                                    const float* __restrict__ dbs, int nb, float* __restrict__ db, int accumulate) {
   const long long nq = n >> 2;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq + nb; q += (long long)gridDim.x * blockDim.x) {
     if (q < nq) {
       const long long i = q << 2;
-      float4 a = *reinterpret_cast<const float4*>(dW + i);
+      float4 a = accumulate ? *reinterpret_cast<const float4*>(dW + i) : make_float4(0.f, 0.f, 0.f, 0.f);
       for (int z = 0; z < nslab; ++z) {
         const float4 v = *reinterpret_cast<const float4*>(slab + (long long)z * n + i);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
@@ -216,7 +217,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n,
       *reinterpret_cast<float4*>(dW + i) = a;
     } else if (db) {
       const int j = (int)(q - nq);
-      float a = db[j];
+      float a = accumulate ? db[j] : 0.f;
       for (int z = 0; z < nslab; ++z) a += dbs[(long long)z * nb + j];
       db[j] = a;
     }
@@ -225,9 +226,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n,
 
 // out[i] += sum_z slab[z*stride + i]
 __global__ void slab_reduce2_kernel(const float* __restrict__ slab, long long n, long long stride, int nslab,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float a = out[i];
+    float a = accumulate ? out[i] : 0.f;
     for (int z = 0; z < nslab; ++z) a += slab[(long long)z * stride + i];
     out[i] = a;
   }
@@ -267,7 +268,7 @@ size_t tim_wgrad_tn_ws(int Nout, int Kout, int M) {
 }
 
 int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
-                      void* ws, size_t ws_bytes, hipStream_t s) {
+                      void* ws, size_t ws_bytes, hipStream_t s, int accumulate) {
   if (ws_bytes < tim_wgrad_tn_ws(Nout, Kout, M)) return TIMHIP_EWORKSPACE;
   if ((ldy % 8) || (ldx % 8) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)ws) & 15)) return TIMHIP_EALIGN;
   const int sk = tim_wgrad_splits(Nout, Kout, M);
@@ -286,14 +287,14 @@ int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx,
   if ((n & 3) == 0) {
     long long blocks = (n / 4 + Nout + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, n, sk_eff, dW, dbs, Nout, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, n, sk_eff, dW, dbs, Nout, db, accumulate);
     return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
   }
-  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(256), dim3(256), 0, s, slab, n, n, sk_eff, dW);
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(256), dim3(256), 0, s, slab, n, n, sk_eff, dW, accumulate);
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   if (db) {
     hipLaunchKernelGGL(slab_reduce2_kernel, dim3((Nout + 255) / 256), dim3(256), 0, s, dbs, (long long)Nout,
-                       (long long)Nout, sk_eff, db);
+                       (long long)Nout, sk_eff, db, accumulate);
     if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   }
   return TIMHIP_OK;

@@ -452,7 +452,9 @@ class EncoderFn(torch.autograd.Function):
         fe = "feature_encoding."
 
         # gradient buckets: one flat fp32 buffer per bucket, parameters are views into it
-        grads = model._alloc_grad_buckets(names, params, dev)
+        # bf16: the layers' Linear gradients are written, not accumulated -> their buckets are not zero-filled (nor read)
+        overwrite = rt.prec == L.PREC_BF16
+        grads = model._alloc_grad_buckets(names, params, dev, layer_overwrite=overwrite)
         G = grads.views
 
         dx = torch.zeros((M, E), dtype=torch.float32, device=dev)
@@ -501,7 +503,7 @@ class EncoderFn(torch.autograd.Function):
         # ---- layers, last to first.  Per layer: the data chain on the current stream, the four
         # weight-gradient GEMMs on a side stream (they overlap the data chain of the next layer);
         # each layer's bucket is handed to the hook as soon as its weight gradients are enqueued.
-        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, 0)
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, L.DESC_WGRAD_OVERWRITE if overwrite else 0)
         lib = L.load()
         dx2 = torch.empty_like(dx)
         stack = model._stack_prefix

@@ -147,7 +147,10 @@ class _EncoderStackParams(nn.Module):
 
 
 class _GradBuckets:
-    def __init__(self, rt, names, params, dev, bucket_of):
+    def __init__(self, rt, names, params, dev, bucket_of, layer_overwrite=False):
+        """layer_overwrite: the encoder layers' Linear weight/bias gradients are written by the kernels
+        (TIMHIP_DESC_WGRAD_OVERWRITE); their buckets are left uninitialised except the LayerNorm slices,
+        which the kernels accumulate into."""
         self.rt = rt
         self.views = {}
         self.flat = {}
@@ -156,12 +159,22 @@ class _GradBuckets:
             b = bucket_of(n)
             sizes[b] = sizes.get(b, 0) + (p.numel() + 3) // 4 * 4
         for b, sz in sizes.items():
-            self.flat[b] = torch.zeros(sz, dtype=torch.float32, device=dev)
+            lazy = layer_overwrite and b.startswith("layer")
+            self.flat[b] = (torch.empty if lazy else torch.zeros)(sz, dtype=torch.float32, device=dev)
         off = {b: 0 for b in sizes}
+        accumulated = []
         for n, p in zip(names, params):
             b = bucket_of(n)
             self.views[n] = self.flat[b][off[b]:off[b] + p.numel()].view(p.shape)
+            if layer_overwrite and b.startswith("layer"):
+                if ".norm" in n:
+                    accumulated.append(self.views[n])
+                pad = (p.numel() + 3) // 4 * 4 - p.numel()
+                if pad:                                   # alignment padding is part of the all-reduced buffer
+                    accumulated.append(self.flat[b][off[b] + p.numel():off[b] + p.numel() + pad])
             off[b] += (p.numel() + 3) // 4 * 4
+        if accumulated:
+            torch._foreach_zero_(accumulated)
 
     def done(self, bucket, ready=None):
         """`ready`: event after which the side-stream part of the bucket is complete (None: current stream)"""
@@ -276,8 +289,8 @@ class TIM(nn.Module):
             return "front"
         return "heads"
 
-    def _alloc_grad_buckets(self, names, params, dev):
-        return _GradBuckets(self.rt, names, params, dev, self._bucket_of)
+    def _alloc_grad_buckets(self, names, params, dev, layer_overwrite=False):
+        return _GradBuckets(self.rt, names, params, dev, self._bucket_of, layer_overwrite)
 
     # ---- the reference's public interface ------------------------------------------------------------
     def forward_encoder(self, inputs, time_encodings, num_v_queries, num_a_queries):
