@@ -138,10 +138,19 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
           sc[r] = p * (dp[r] * k[t] - delta) * a.scale;
           dp[r] = p * k[t];
         }
-        if (valid && !ATT_ABL(a, 1)) {  // hand dS and the dropped probabilities P~ to the key-side kernel
-          const size_t so = (size_t)row * FP + jb * 32 + 8 * q + 4 * g;
-          store4<bf16_t>(dSs + so, sc[4 * q], sc[4 * q + 1], sc[4 * q + 2], sc[4 * q + 3]);
-          store4<bf16_t>(Pts + so, dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], dp[4 * q + 3]);
+      }
+      // hand dS and the dropped probabilities P~ to the key-side kernel (16-byte stores: pair_exchange)
+#pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2) {
+        float vs[8], vp[8];
+        pair_exchange(vs, sc[8 * p2], sc[8 * p2 + 1], sc[8 * p2 + 2], sc[8 * p2 + 3], sc[8 * p2 + 4], sc[8 * p2 + 5],
+                      sc[8 * p2 + 6], sc[8 * p2 + 7], g);
+        pair_exchange(vp, dp[8 * p2], dp[8 * p2 + 1], dp[8 * p2 + 2], dp[8 * p2 + 3], dp[8 * p2 + 4], dp[8 * p2 + 5],
+                      dp[8 * p2 + 6], dp[8 * p2 + 7], g);
+        if (valid && !ATT_ABL(a, 1)) {
+          const size_t so = (size_t)row * FP + jb * 32 + 16 * p2 + 8 * g;
+          store8_bf16(dSs + so, vs);
+          store8_bf16(Pts + so, vp);
         }
       }
 #pragma unroll
@@ -154,25 +163,35 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
         }
       }
     }
-    if (valid && !ATT_ABL(a, 2)) {
+    {
+      // lanes l and l ^ 32 trade quads (mfma_tiles.h: pair_exchange) so that every store is 16 bytes per lane
       bf16_t* dq = dbase + (size_t)row * ld;
+      const bool st = valid && !ATT_ABL(a, 2);
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int dh = 32 * db + 8 * q + 4 * g;
-          float v0 = qa[db][4 * q], v1 = qa[db][4 * q + 1], v2 = qa[db][4 * q + 2], v3 = qa[db][4 * q + 3];
-          if (isq) {
-            float k0, k1, k2, k3, q0, q1, q2, q3, d0, d1, d2, d3;
-            load4<bf16_t>(qp + E + dh, k0, k1, k2, k3);
-            load4<bf16_t>(qp + dh, q0, q1, q2, q3);
-            load4<bf16_t>(dop + dh, d0, d1, d2, d3);
-            v0 = fmaf(ds_self, k0, v0); v1 = fmaf(ds_self, k1, v1); v2 = fmaf(ds_self, k2, v2); v3 = fmaf(ds_self, k3, v3);
-            // a query token's own key / value receive the self term only
-            store4<bf16_t>(dq + E + dh, ds_self * q0, ds_self * q1, ds_self * q2, ds_self * q3);
-            store4<bf16_t>(dq + 2 * E + dh, pt_self * d0, pt_self * d1, pt_self * d2, pt_self * d3);
+        for (int p2 = 0; p2 < 2; ++p2) {
+          float v[8];
+          pair_exchange(v, qa[db][8 * p2], qa[db][8 * p2 + 1], qa[db][8 * p2 + 2], qa[db][8 * p2 + 3], qa[db][8 * p2 + 4],
+                        qa[db][8 * p2 + 5], qa[db][8 * p2 + 6], qa[db][8 * p2 + 7], g);
+          const int dh = 32 * db + 16 * p2 + 8 * g;
+          if (st) {
+            if (isq) {
+              const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(qp + E + dh);
+              const bf16x8_t qf8 = *reinterpret_cast<const bf16x8_t*>(qp + dh);
+              const bf16x8_t d8 = *reinterpret_cast<const bf16x8_t*>(dop + dh);
+              float kself[8], vself[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                v[u] = fmaf(ds_self, (float)kf[u], v[u]);
+                kself[u] = ds_self * (float)qf8[u];      // a query token's own key / value receive the self term only
+                vself[u] = pt_self * (float)d8[u];
+              }
+              store8_bf16(dq + E + dh, kself);
+              store8_bf16(dq + 2 * E + dh, vself);
+            }
+            store8_bf16(dq + dh, v);
           }
-          store4<bf16_t>(dq + dh, v0, v1, v2, v3);
         }
     }
   }

@@ -182,21 +182,25 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
             oa[d2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jb][aa], oa[d2], 0, 0, 0);
             if (d2 == DBH - 1 && aa == 1) __builtin_amdgcn_sched_barrier(0);
           }
-      if (valid) {
+      // lanes l and l ^ 32 trade quads so that each stores 8 contiguous head-dim columns (16 bytes) per pair of quads;
+      // the exchange is executed by every lane (shuffles), the store only by valid rows
 #pragma unroll
-        for (int d2 = 0; d2 < DBH; ++d2)
+      for (int d2 = 0; d2 < DBH; ++d2)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int dh = 32 * (hh * DBH + d2) + 8 * q + 4 * g;
-            float v0 = oa[d2][4 * q], v1 = oa[d2][4 * q + 1], v2 = oa[d2][4 * q + 2], v3 = oa[d2][4 * q + 3];
+        for (int p2 = 0; p2 < 2; ++p2) {
+          float v[8];
+          pair_exchange(v, oa[d2][8 * p2], oa[d2][8 * p2 + 1], oa[d2][8 * p2 + 2], oa[d2][8 * p2 + 3], oa[d2][8 * p2 + 4],
+                        oa[d2][8 * p2 + 5], oa[d2][8 * p2 + 6], oa[d2][8 * p2 + 7], g);
+          const int dh = 32 * (hh * DBH + d2) + 16 * p2 + 8 * g;
+          if (valid) {
             if (isq) {
-              float s0, s1, s2, s3;
-              load4<bf16_t>(qp + 2 * E + dh, s0, s1, s2, s3);
-              v0 = fmaf(pself, s0, v0); v1 = fmaf(pself, s1, v1); v2 = fmaf(pself, s2, v2); v3 = fmaf(pself, s3, v3);
+              const bf16x8_t sv = *reinterpret_cast<const bf16x8_t*>(qp + 2 * E + dh);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) v[u] = fmaf(pself, (float)sv[u], v[u]);
             }
-            store4<bf16_t>(op + dh, v0, v1, v2, v3);
+            store8_bf16(op + dh, v);
           }
-      }
+        }
     }
   }
 }

@@ -76,3 +76,24 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int kb, int db, in
   return cat8(lo, hi);
 }
 
+
+// Row-per-lane stores.  In the 32x32 accumulator layout lane (row, g = lane >> 5) holds quad q of a 32-column block as
+// columns 8q + 4g .. +3, so a row's 16 columns 16p .. 16p+15 (quads 2p, 2p+1) are interleaved between lanes l and l ^ 32.
+// pair_exchange() trades one quad between the two lanes: afterwards g = 0 owns columns 16p .. 16p+7 and g = 1 owns
+// 16p+8 .. 16p+15, i.e. ONE 16-byte bf16 store per lane instead of two 8-byte ones (the store phase of these kernels is
+// bound by the number of store instructions, not by bytes).
+__device__ __forceinline__ void pair_exchange(float (&out)[8], float e0, float e1, float e2, float e3, float o0, float o1,
+                                              float o2, float o3, int g) {
+  const float s0 = g ? e0 : o0, s1 = g ? e1 : o1, s2 = g ? e2 : o2, s3 = g ? e3 : o3;   // what the partner needs
+  const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64), r2 = __shfl_xor(s2, 32, 64),
+              r3 = __shfl_xor(s3, 32, 64);
+  if (g == 0) { out[0] = e0; out[1] = e1; out[2] = e2; out[3] = e3; out[4] = r0; out[5] = r1; out[6] = r2; out[7] = r3; }
+  else { out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3; out[4] = o0; out[5] = o1; out[6] = o2; out[7] = o3; }
+}
+__device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
+  bf16x8_t o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  o[4] = (bf16_t)v[4]; o[5] = (bf16_t)v[5]; o[6] = (bf16_t)v[6]; o[7] = (bf16_t)v[7];
+  *reinterpret_cast<bf16x8_t*>(p) = o;
+}
+
