@@ -306,15 +306,15 @@ __global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + li;
-    if (n >= N) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = wk * 64 + i * 32 + 8 * q + 4 * g;
-        if (k + 3 < K)
-          store4<bf16_t>(out + (size_t)n * ldo + k, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                         acc[i][j][4 * q + 3]);
+      for (int p2 = 0; p2 < 2; ++p2) {      // 16-byte stores: lanes l and l ^ 32 trade quads (mfma_tiles.h)
+        float v[8];
+        pair_exchange(v, acc[i][j][8 * p2], acc[i][j][8 * p2 + 1], acc[i][j][8 * p2 + 2], acc[i][j][8 * p2 + 3],
+                      acc[i][j][8 * p2 + 4], acc[i][j][8 * p2 + 5], acc[i][j][8 * p2 + 6], acc[i][j][8 * p2 + 7], g);
+        const int k = wk * 64 + i * 32 + 16 * p2 + 8 * g;
+        if (n < N && k + 7 < K) store8_bf16(out + (size_t)n * ldo + k, v);
       }
   }
 }
