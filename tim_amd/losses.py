@@ -169,7 +169,7 @@ class DrlocFn(torch.autograd.Function):
         K0 = 2 * D
         if w0.shape[1] != K0:
             raise ValueError("drloc_mlp.0 expects %d inputs, the sampled pairs have %d" % (w0.shape[1], K0))
-        same = x2 is x1
+        same = x2 is x1 or (x1.data_ptr() == x2.data_ptr() and x1.shape == x2.shape and x1.stride() == x2.stride())
         ok = lambda t: t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(0) % 4 == 0 \
             and t.data_ptr() % 16 == 0
         a = x1.detach() if ok(x1) else x1.detach().float().contiguous()
