@@ -466,8 +466,8 @@ __global__ void assemble_fwd_kernel(const TimSeqRow* __restrict__ rows, int B, i
   }
 }
 
-// backward.  Kernel 1: one block per token row s walks all windows: writes d_e (feature rows), and
-// reduces the cls / modality gradients over the batch in registers before ONE atomic per column.
+// backward.  Kernel 1: block (s, y) walks the y-th share of the windows for token row s: writes d_e (feature rows), and
+// reduces the cls / modality gradients over its windows in registers before ONE atomic per column.
 // Kernel 2: d_te[b, t, :] = sum over the token rows that read time row t (fixed order, no atomics).
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
                                                            const float* __restrict__ dx, int n_e_rows, uint32_t thr,
@@ -477,9 +477,11 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __re
   const int s = blockIdx.x;
   const TimSeqRow r = rows[s];
   const int E = 2 * d;
+  const int bper = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
   for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < B; ++b) {
+    for (int b = b0; b < b1; ++b) {
       const size_t bs = (size_t)b * S + s;
       float4 g = *reinterpret_cast<const float4*>(dx + bs * E + c);
       if (thr != 0u) {
@@ -784,7 +786,7 @@ int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float*
   if (!rows || !dx || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
   const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
   const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows, thr,
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S, B >= 16 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows, thr,
                      scale, seed, site, d_e0, d_e1, d_cls, d_mod);
   TIM_CHECK_LAUNCH();
   if (d_te) {
