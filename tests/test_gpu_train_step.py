@@ -1,0 +1,83 @@
+"""End-to-end training steps on the HIP path the way recognition/scripts/train.py:190-366 composes them:
+time_mlp -> mixup of the inputs -> encoder -> label-smoothed mixup CE per head + cross-modal DRLoc -> backward -> AdamW.
+Checks the first loss against the oracle, that the operand copies follow the optimizer's in-place updates (the loss of a
+fixed batch goes down), and that a second model driven by the oracle's gradients stays on the same trajectory."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tim_oracle as O  # noqa: E402
+from tests import helpers as H  # noqa: E402
+from tim_amd import losses  # noqa: E402
+from tim_amd.tim import TIM  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _targets(B, nv, na, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = {"verb": torch.randint(0, 7, (B * nv,), generator=g), "noun": torch.randint(0, 11, (B * nv,), generator=g),
+         "action": torch.randint(0, 13, (B * nv,), generator=g), "class_id": torch.randint(0, 5, (B * na,), generator=g)}
+    t["action"][::5] = -1            # padded queries (train.py:223-224 masks them by target != -1)
+    t["verb"][::5] = -1
+    t["noun"][::5] = -1
+    t["class_id"][1::4] = -1
+    return t
+
+
+def _loss_hip(model, inp, ta, tb, lam, pos, nv, na, nf):
+    te = model(inp["times"], "time_mlp")
+    (verb, noun, action, audio), feats = model([inp["visual"], inp["audio"]], "encoder", te, nv, na)
+    ce = lambda x, k: losses.mixup_cross_entropy(x, ta[k].to(DEV), tb[k].to(DEV), lam, 0.2)
+    vis = (ce(verb, "verb") + ce(noun, "noun") + ce(action, "action")) / 3.0
+    dr = losses.dense_relative_localization_loss_crossmodal(feats[:, :nf], feats[:, nf:], model, pos[0].shape[1], positions=pos)
+    return vis + 1.0 * ce(audio, "class_id") + 0.3 * dr
+
+
+def _loss_oracle(sd, cfg, inp, ta, tb, lam, pos, nv, na, nf):
+    te = O.time_mlp(sd, inp["times"])
+    (verb, noun, action, audio), feats = O.encoder(sd, cfg, inp["visual"], inp["audio"], te, nv, na)
+    ce = lambda x, k: O.mixup_ce(x, ta[k], tb[k], lam, 0.2)
+    vis = (ce(verb, "verb") + ce(noun, "noun") + ce(action, "action")) / 3.0
+    dr = O.drloc_loss(sd, feats[:, :nf], feats[:, nf:], pos[0], pos[1])
+    return vis + 1.0 * ce(audio, "class_id") + 0.3 * dr
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+def test_training_steps_follow_the_oracle(prec, tol):
+    cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+    cfg.feat_drop = cfg.seq_drop = cfg.enc_dropout = 0.0          # deterministic arithmetic: comparable with the oracle
+    B, nv, na, nf = 4, 4, 2, cfg.num_feats
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=3, dtype=torch.float32)
+    ta, tb = _targets(B, nv, na, 1), _targets(B, nv, na, 2)
+    lam = 0.7
+    g = torch.Generator().manual_seed(5)
+    pos = (torch.randint(nf, (B, 5), generator=g), torch.randint(nf, (B, 5), generator=g))
+    model = TIM(cfg.num_class, visual_input_dim=cfg.visual_input_dim, audio_input_dim=cfg.audio_input_dim, feat_drop=0.0,
+                seq_drop=0.0, d_model=cfg.d_model, nhead=cfg.nhead, num_layers=cfg.num_layers, enc_dropout=0.0,
+                num_feats=nf, precision=prec)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    ref = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=1e-4)
+    opt_ref = torch.optim.AdamW(list(ref.values()), lr=2e-3, weight_decay=1e-4)
+    dinp = {k: v.to(DEV) for k, v in inp.items()}
+    rinp = {k: v.double() for k, v in inp.items()}
+    hist = []
+    for step in range(6):
+        loss = _loss_hip(model, dinp, ta, tb, lam, pos, nv, na, nf)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        lref = _loss_oracle(ref, cfg, rinp, ta, tb, lam, pos, nv, na, nf)
+        opt_ref.zero_grad()
+        lref.backward()
+        opt_ref.step()
+        hist.append((loss.item(), lref.item()))
+        assert abs(loss.item() - lref.item()) <= tol * max(1.0, abs(lref.item())), (step, hist)
+    assert hist[-1][0] < hist[0][0] - 0.05, hist        # the updates reached the kernels' operand copies
+    # parameters after 6 AdamW steps
+    worst = max((p.detach().cpu().double() - ref[n].detach()).abs().max().item() for n, p in model.named_parameters())
+    assert worst <= (5e-4 if prec == "fp32" else 2e-2), worst
