@@ -49,17 +49,26 @@ __device__ __forceinline__ float dot8(bf16x8_t a, bf16x8_t b) {
 template <int DH>
 __device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, size_t ld, int nrows, int nvalid, int tid,
                                            int nthreads) {
-  constexpr int NC = DH / 8;
-  for (int idx = tid; idx < nrows * NC; idx += nthreads) {
-    const int row = idx / NC, c = idx % NC;
-    bf16x8_t v;
-    if (row < nvalid) {
-      v = *reinterpret_cast<const bf16x8_t*>(src + (size_t)row * ld + c * 8);
-    } else {
+  constexpr int NC = DH / 8, UN = 8;
+  // all of a thread's global loads are issued before the first LDS write (one HBM latency per tile, not one per chunk)
+  for (int i0 = tid; i0 < nrows * NC; i0 += nthreads * UN) {
+    bf16x8_t v[UN];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (bf16_t)0.f;
+    for (int u = 0; u < UN; ++u) {
+      const int idx = i0 + u * nthreads;
+      const int row = idx / NC, c = idx % NC;
+      if (idx < nrows * NC && row < nvalid) {
+        v[u] = *reinterpret_cast<const bf16x8_t*>(src + (size_t)row * ld + c * 8);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = (bf16_t)0.f;
+      }
     }
-    *reinterpret_cast<bf16x8_t*>(tile + tile_off<DH>(row, c)) = v;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = i0 + u * nthreads;
+      if (idx < nrows * NC) *reinterpret_cast<bf16x8_t*>(tile + tile_off<DH>(idx / NC, idx % NC)) = v[u];
+    }
   }
 }
 
