@@ -244,6 +244,11 @@ int tim_attention_bwd_mfma(const TimDesc& d, const void* qkv, const void* o, con
 int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                             void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);
 size_t tim_attention_bwd2_ws(const TimDesc& d);
+// attention_f32.hip: exact-fp32 MFMA kernels for the fp32 / bf16x3 modes
+int tim_attention_fwd_f32(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
+int tim_attention_bwd_f32(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
+                          void* ws, size_t ws_bytes, hipStream_t s);
+size_t tim_attention_f32_bwd_ws(const TimDesc& d);
 
 int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
   int rc = check_desc(d);
@@ -251,6 +256,10 @@ int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hi
   if (!qkv || !o || !lse) return TIMHIP_EINVAL;
   if (d.precision == TIMHIP_PREC_BF16 && !(d.reserved & 1)) {  // reserved bit 0: force the fp32-arithmetic kernels
     rc = tim_attention_fwd_mfma(d, qkv, o, lse, s);
+    if (rc != TIMHIP_EUNSUPPORTED) return rc;
+  }
+  if (f32_storage(d.precision) && !(d.reserved & 1)) {   // fp32 / bf16x3: f32 matrix cores
+    rc = tim_attention_fwd_f32(d, qkv, o, lse, s);
     if (rc != TIMHIP_EUNSUPPORTED) return rc;
   }
   const size_t lds = simple_lds(d, 1);
@@ -270,7 +279,9 @@ int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hi
 size_t tim_attention_bwd_ws(const TimDesc& d) {
   const size_t simple = (size_t)d.B * d.H * 2 * d.S * (d.F + 4) * sizeof(float);
   const size_t two = tim_attention_bwd2_ws(d);
-  return simple > two ? simple : two;
+  const size_t f32 = f32_storage(d.precision) ? tim_attention_f32_bwd_ws(d) : 0;
+  const size_t m = simple > two ? simple : two;
+  return m > f32 ? m : f32;
 }
 
 int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
@@ -284,6 +295,10 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
       if (rc != TIMHIP_EUNSUPPORTED) return rc;
     }
     rc = tim_attention_bwd_mfma(d, qkv, o, lse, d_o, dqkv, s);
+    if (rc != TIMHIP_EUNSUPPORTED) return rc;
+  }
+  if (f32_storage(d.precision) && !(d.reserved & 1)) {
+    rc = tim_attention_bwd_f32(d, qkv, o, lse, d_o, dqkv, ws, ws_bytes, s);
     if (rc != TIMHIP_EUNSUPPORTED) return rc;
   }
   if (ws_bytes < tim_attention_bwd_ws(d)) return TIMHIP_EWORKSPACE;
