@@ -20,7 +20,7 @@ struct AttnArgs {
 __device__ __forceinline__ float attn_keep(const AttnArgs& a, int b, int h, int row, int j) {
   if (a.thr == 0u) return 1.f;
   const uint64_t base = (((uint64_t)b * a.H + h) * a.S + row) * (uint64_t)a.LP + (uint64_t)j;
-  Philox4 r = philox4x32_10(a.seed, a.site, base >> 2);
+  Philox4 r = philox4x32_7(a.seed, a.site, base >> 2);
   const uint32_t v = (base & 3) == 0 ? r.x : ((base & 3) == 1 ? r.y : ((base & 3) == 2 ? r.z : r.w));
   return v >= a.thr ? a.dscale : 0.f;
 }

@@ -73,7 +73,7 @@ __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
 }
 
 constexpr int PHILOX_ROUNDS = 7;
-__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t site, uint64_t ctr) {
+__host__ __device__ __forceinline__ Philox4 philox4x32_7(uint64_t seed, uint32_t site, uint64_t ctr) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = site, c3 = 0x7149u;
 #pragma unroll
@@ -98,7 +98,7 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
 // masks of the 4 consecutive elements whose linear index is 4*q .. 4*q+3
 __device__ __forceinline__ void drop_mask4(uint64_t seed, uint32_t site, uint64_t q, uint32_t thr,
                                            float scale, float& m0, float& m1, float& m2, float& m3) {
-  Philox4 r = philox4x32_10(seed, site, q);
+  Philox4 r = philox4x32_7(seed, site, q);
   m0 = r.x >= thr ? scale : 0.f;
   m1 = r.y >= thr ? scale : 0.f;
   m2 = r.z >= thr ? scale : 0.f;

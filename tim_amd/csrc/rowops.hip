@@ -211,7 +211,7 @@ __global__ void dropout_mask_kernel(uint64_t seed, uint32_t site, uint32_t thr, 
   const size_t total = (size_t)rows * colsq;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / colsq), q = (int)(i % colsq);
-    Philox4 p = philox4x32_10(seed, site, (uint64_t)r * colsq + q);
+    Philox4 p = philox4x32_7(seed, site, (uint64_t)r * colsq + q);
     const uint32_t v[4] = {p.x, p.y, p.z, p.w};
     for (int j = 0; j < 4; ++j)
       if (q * 4 + j < cols) out[(size_t)r * cols + q * 4 + j] = v[j] >= thr ? 1 : 0;
