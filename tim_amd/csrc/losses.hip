@@ -12,23 +12,41 @@ namespace {
 // ---- cross entropy --------------------------------------------------------------------------------------------------
 // stats[r] = (logsumexp_r, mean_c x_rc); accum = (sum_a, n_a, sum_b, n_b) accumulated with atomics (rows <= a few
 // thousand: the order-dependence of the fp32 sums is below 1e-7 relative)
+// RW = waves per row: 1 (four rows per block) for small heads, 4 (one row per 256-thread block) for the wide action head
+template <int RW>
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ x, int rows, int C, int ld,
                                                       const long long* __restrict__ ya,
                                                       const long long* __restrict__ yb, float eps,
                                                       float* __restrict__ stats, float* __restrict__ accum) {
+  __shared__ float red[3][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = blockIdx.x * 4 + wave;
-  if (r >= rows) return;
-  const float* xr = x + (size_t)r * ld;
+  const int r = RW == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  const bool active = r < rows;                       // whole waves (RW = 1) or whole blocks (RW = 4) are inactive together
+  const float* xr = x + (size_t)(active ? r : 0) * ld;
+  const int t0 = RW == 1 ? lane : threadIdx.x, nt = RW * 64;
   float mx = -INFINITY, sm = 0.f;
-  for (int c = lane; c < C; c += 64) { const float v = xr[c]; mx = fmaxf(mx, v); sm += v; }
+  if (active)
+    for (int c = t0; c < C; c += nt) { const float v = xr[c]; mx = fmaxf(mx, v); sm += v; }
   mx = wave_max(mx);
   sm = wave_sum(sm);
+  if (RW > 1) {
+    if (lane == 0) { red[0][wave] = mx; red[1][wave] = sm; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    sm = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
   float se = 0.f;
-  for (int c = lane; c < C; c += 64) se += __expf(xr[c] - mx);
+  if (active)
+    for (int c = t0; c < C; c += nt) se += __expf(xr[c] - mx);
   se = wave_sum(se);
+  if (RW > 1) {
+    if (lane == 0) red[2][wave] = se;
+    __syncthreads();
+    se = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+  }
+  if (!active) return;
   const float lse = mx + __logf(se), mean = sm / (float)C;
-  if (lane == 0) {
+  if (t0 == 0) {
     stats[2 * r] = lse;
     stats[2 * r + 1] = mean;
     const long long a = ya[r], b = yb ? yb[r] : -1;
@@ -243,8 +261,12 @@ int timhip_ce_mixup_fwd(const float* logits, int rows, int C, int ld, const int6
   if (smoothing < 0.f || smoothing >= 1.f) return TIMHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(accum, 0, 4 * sizeof(float), s) != hipSuccess) return TIMHIP_ELAUNCH;
-  hipLaunchKernelGGL(ce_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, rows, C, ld,
-                     (const long long*)target_a, (const long long*)target_b, smoothing, stats, accum);
+  if (C >= 1024)
+    hipLaunchKernelGGL(ce_rows_kernel<4>, dim3(rows), dim3(256), 0, s, logits, rows, C, ld, (const long long*)target_a,
+                       (const long long*)target_b, smoothing, stats, accum);
+  else
+    hipLaunchKernelGGL(ce_rows_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, s, logits, rows, C, ld,
+                       (const long long*)target_a, (const long long*)target_b, smoothing, stats, accum);
   TIM_CHECK_LAUNCH();
   hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1), 0, s, accum, lam, loss);
   TIM_CHECK_LAUNCH();
