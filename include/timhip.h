@@ -275,7 +275,7 @@ int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, in
 /* Label-smoothed cross entropy under mixup, as recognition/scripts/train.py:46-49,218-316 applies it through
  * utils/mixup.py:24-39:  loss = lam * mean_{r: ta[r] != -1} CE(logits[r], ta[r]) + (1-lam) * mean_{r: tb[r] != -1}
  * CE(logits[r], tb[r]),  CE with label smoothing `smoothing` (torch.nn.CrossEntropyLoss(label_smoothing, ignore_index=-1)).
- * target_b may be NULL (plain criterion, lam = 1).  stats [rows,2] and accum [4] are scratch kept for the backward;
+ * target_b may be NULL (plain criterion, lam = 1).  stats [rows,4] and accum [4] are scratch kept for the backward;
  * loss is a device scalar.  dlogits = grad_out[0] * d loss / d logits (grad_out: device scalar or NULL = 1). */
 int timhip_ce_mixup_fwd(const float* logits, int rows, int C, int ld, const int64_t* target_a, const int64_t* target_b,
                         float lam, float smoothing, float* stats, float* accum, float* loss, void* stream);

@@ -39,7 +39,7 @@ class _MixupCEFn(torch.autograd.Function):
             ctx.empty = True
             ctx.shape = tuple(x.shape)
             return loss.zero_()
-        stats = torch.empty((rows, 2), dtype=torch.float32, device=dev)
+        stats = torch.empty((rows, 4), dtype=torch.float32, device=dev)
         accum = torch.empty(4, dtype=torch.float32, device=dev)
         call("timhip_ce_mixup_fwd", ptr(x), rows, Cn, x.stride(0), ptr(ta), ptr(tb), float(lam), float(smoothing),
              ptr(stats), ptr(accum), ptr(loss), _stream())
