@@ -240,7 +240,7 @@ int timhip_focal_loss_fwd(const float* logits, const float* targets, int rows, i
   if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return TIMHIP_ELAUNCH;
   if (rows == 0) return TIMHIP_OK;
   const long long n = (long long)rows * C;
-  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  const int blocks = (int)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256);   // one atomic per block on a single address
   hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocks), dim3(256), 0, s, logits, targets, n, C, row_weights, row_valid, alpha,
                      gamma, loss_sum, loss_elem);
   TIM_CHECK_LAUNCH();
