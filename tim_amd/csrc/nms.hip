@@ -2,8 +2,8 @@
 // detection/eval_detection/csrc/nms_cpu.cpp (nms_1d_cpu :19-60, softnms_1d_cpu :69-170), which the evaluation drives
 // once per (video, class) from joblib workers (format_predictions_epic.py:146-156, nms.py:97-180).
 //
-// Parallelism: the groups (one per video x class) are independent -> one wavefront per group (four for groups of more
-// than 1024 segments), thousands in flight.
+// Parallelism: the groups (one per video x class) are independent -> one wavefront per group (8 for groups of more
+// than 1024 segments, 16 beyond 4096), thousands in flight.
 // Inside a group soft-NMS is a sequential selection (pick the current maximum, decay the rest, prune), so the wave runs
 // the outer loop and its 64 lanes share each inner pass (arg-max, decay, compaction).  The result is BIT-IDENTICAL to
 // the CPU routine, including its order-dependent details:
@@ -62,13 +62,14 @@ __device__ __forceinline__ void flag_rank(bool flag, int* wtot, int& rank, int& 
   }
 }
 
-// NT = 64: one wave per group (small groups: many groups per CU); NT = 256: four waves share the passes of a large group
+// NT = 64: one wave per group (small groups: many groups per CU); NT = 512 / 1024: 8 / 16 waves share the passes of a
+// large group (its selection loop is sequential, so the largest groups set the makespan of the whole call)
 template <int NT>
 __global__ __launch_bounds__(NT) void softnms_kernel(NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int wtot[4];
-  __shared__ float wbest[4];
-  __shared__ int wbpos[4];
+  __shared__ int wtot[16];
+  __shared__ float wbest[16];
+  __shared__ int wbpos[16];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.ngroups) return;
   const int g = a.glist ? a.glist[blockIdx.x] : (int)blockIdx.x;
@@ -263,10 +264,12 @@ int timhip_softnms_1d(const float* segs, const float* scores, const int32_t* gro
     a.iou_thr = iou_threshold; a.sigma = sigma; a.min_score = min_score; a.method = method;
     a.scratch_f = sf; a.scratch_i = si; a.N = N; a.dets = dets; a.inds = inds; a.count = count; a.lds_cap = caps[c];
     const size_t shmem = (size_t)caps[c] * 24;
-    if (c >= 2) {   // more than 1024 segments: four waves per group
+    if (c == 3) {          // more than 4096 segments (global scratch): sixteen waves per group
+      hipLaunchKernelGGL(softnms_kernel<1024>, dim3(cnt[c]), dim3(1024), shmem, s, a);
+    } else if (c == 2) {   // 1025 .. 4096 segments: eight waves per group (96 KB of LDS: one group per CU anyway)
       if (shmem > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)softnms_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      hipLaunchKernelGGL(softnms_kernel<256>, dim3(cnt[c]), dim3(256), shmem, s, a);
+        (void)hipFuncSetAttribute((const void*)softnms_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL(softnms_kernel<512>, dim3(cnt[c]), dim3(512), shmem, s, a);
     } else {
       hipLaunchKernelGGL(softnms_kernel<64>, dim3(cnt[c]), dim3(64), shmem, s, a);
     }
