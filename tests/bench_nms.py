@@ -1,7 +1,8 @@
 """Batched soft-NMS throughput: one timhip_softnms_1d call over all (video, class) groups of a synthetic evaluation vs the
-C oracle (the reference's algorithm, one core) on a sample of the same groups.  Timing tool."""
+C oracle (the reference's algorithm, one core) on a sample of the same groups.  Timing script (not a pytest module);
+it lives under tests/ because it loads the oracle as its CPU baseline."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np, torch
 from oracle import nms_oracle as N
 from tim_amd import nms as hnms
