@@ -561,14 +561,17 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(const float* __restrict
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fhalf = lane >> 5;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    float4 ra[4], rb[4];
+  float4 ra[4], rb[4];
+  auto fetch = [&](int kt) {   // the fp32 operand tiles of K-step kt -> registers
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256, row = idx >> 3, c4 = idx & 7;  // 8 float4 per 32-float row
       ra[i] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + row, M - 1) * lda + kt * XBK + c4 * 4);
       rb[i] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + row, N - 1) * ldb + kt * XBK + c4 * 4);
     }
+  };
+  if (kt0 < kt1) fetch(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
     __syncthreads();  // previous step's fragments consumed
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -587,6 +590,7 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(const float* __restrict
       *reinterpret_cast<bf16x4_t*>(sm + 3 * TILE + off) = l;
     }
     __syncthreads();
+    if (kt + 1 < kt1) fetch(kt + 1);   // in flight while this step's MFMAs run
 #pragma unroll
     for (int kk = 0; kk < XBK / 16; ++kk) {
       const int c = kk * 2 + fhalf;
