@@ -472,14 +472,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fhalf = lane >> 5;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    float4 ra[2], rb[2];
+  float4 ra[2], rb[2];
+  auto fetch = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + i * 256, row = idx >> 2, c4 = idx & 3;
       ra[i] = *reinterpret_cast<const float4*>(A + (size_t)min(m0 + row, M - 1) * lda + kt * FBK + c4 * 4);
       rb[i] = *reinterpret_cast<const float4*>(B + (size_t)min(n0 + row, N - 1) * ldb + kt * FBK + c4 * 4);
     }
+  };
+  if (kt0 < kt1) fetch(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
       pb[0] = rb[i].x; pb[1] = rb[i].y; pb[2] = rb[i].z; pb[3] = rb[i].w;
     }
     __syncthreads();
+    if (kt + 1 < kt1) fetch(kt + 1);   // in flight while this step's MFMAs run
 #pragma unroll
     for (int kk = 0; kk < FBK / 2; ++kk) {
       float xa[2], wb[2];
