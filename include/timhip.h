@@ -347,6 +347,13 @@ int timhip_window_times(const float* v_feat_times, int v_ld, const int64_t* v_ro
                         const float* v_queries, int max_v, const float* a_queries, int max_a, const float* start_sec,
                         float window_size, float* times, void* stream);
 
+/* ---------------------------------------------------------------- measurement hook (bench.py roofline) */
+/* While armed, every NT / TN GEMM launch of at least min_flops algorithmic FLOPs (2*M*N*K) is bracketed by two HIP events
+ * recorded on the stream it is launched on (up to `capacity` launches).  stop() waits for them and returns the summed
+ * durations [ms], the summed FLOPs and the number of launches.  Not thread-safe against concurrent start/stop. */
+int timhip_gemm_timing_start(int capacity, double min_flops);
+int timhip_gemm_timing_stop(double* total_ms, double* total_flops, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

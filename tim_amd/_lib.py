@@ -99,6 +99,8 @@ _SIGS = {
     "timhip_nms_1d": (C.c_int, [vp, vp, vp, i32, f32, vp, vp, vp, vp]),
     "timhip_window_gather": (C.c_int, [vp, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp]),
     "timhip_window_times": (C.c_int, [vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, f32, vp, vp]),
+    "timhip_gemm_timing_start": (C.c_int, [i32, C.c_double]),
+    "timhip_gemm_timing_stop": (C.c_int, [vp, vp, vp]),
     "timhip_drloc_gather": (C.c_int, [i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
     "timhip_drloc_scatter_add": (C.c_int, [vp, i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp]),
     "timhip_scatter_rows_add": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),

@@ -230,6 +230,14 @@ __device__ __forceinline__ void glds_wait() {
 // ----------------------------------------------------------------------------
 // internal C++ launchers shared between translation units
 // ----------------------------------------------------------------------------
+// timing.hip: brackets a GEMM-family launch with HIP events while timhip_gemm_timing_start() is armed (bench.py roofline)
+struct TimGemmScope {
+  TimGemmScope(double flops, hipStream_t s);
+  ~TimGemmScope();
+  int slot;
+  hipStream_t stream;
+};
+
 int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
                 int K, const TimEpi& e, int splitk, hipStream_t s);
 int tim_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,

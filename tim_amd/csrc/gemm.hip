@@ -760,6 +760,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return TIMHIP_EUNSUPPORTED;  // 32-bit lane offsets
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && epi != TIMHIP_EPI_ATOMIC_F32 && epi != TIMHIP_EPI_STORE_F32) return TIMHIP_EINVAL;
+  TimGemmScope timing(2.0 * M * N * K, s);
   EpiDev e;
   e.out0 = te.out0; e.out1 = te.out1; e.bias = te.bias; e.res = te.res; e.aux = te.aux;
   e.ld0 = te.ld0; e.ld1 = te.ld1; e.ldres = te.ldres; e.ldaux = te.ldaux;

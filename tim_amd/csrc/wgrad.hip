@@ -272,6 +272,7 @@ int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx,
   if (ws_bytes < tim_wgrad_tn_ws(Nout, Kout, M)) return TIMHIP_EWORKSPACE;
   if ((ldy % 8) || (ldx % 8) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)ws) & 15)) return TIMHIP_EALIGN;
   const int sk = tim_wgrad_splits(Nout, Kout, M);
+  TimGemmScope timing(2.0 * M * Nout * Kout, s);   // kernel + slab reduce
   char* w = (char*)ws;
   float* slab = (float*)w;
   float* dbs = (float*)(w + align_up((size_t)sk * Nout * Kout * 4, 256));
