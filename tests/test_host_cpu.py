@@ -69,6 +69,21 @@ def test_load_state_dict_roundtrip_with_reference_named_weights():
         assert torch.equal(v, sd[k])
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/timhip.h is the drop-in boundary: it must compile as C99 (and C++) on its own, no torch / HIP types"""
+    import shutil
+    import subprocess
+    inc = os.path.join(os.path.dirname(H.GOLDEN), "..", "include")
+    src = tmp_path / "t.c"
+    src.write_text('#include "timhip.h"\nint main(void) { TimDesc d; (void)d; return TIMHIP_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    if shutil.which("g++"):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
+    hdr = open(os.path.join(inc, "timhip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)            # comments may cite torch / HIP names
+    assert "#include <hip" not in code and "torch" not in code and "hipStream_t" not in code and "at::" not in code
+
+
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(os.path.dirname(H.GOLDEN), "..", "include", "timhip.h")).read()
     declared = set(re.findall(r"\b(timhip_[a-z0-9_]+)\s*\(", hdr))
