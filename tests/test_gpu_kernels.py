@@ -251,7 +251,7 @@ def _attn_case(prec, B, S, F, H, Dh, p=0.0, seed=11):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B,S,F,H,Dh", [(2, 22, 12, 2, 32), (2, 155, 100, 2, 128), (1, 80, 50, 1, 128),
-                                        (1, 12, 12, 2, 64), (1, 205, 150, 1, 128)])
+                                        (1, 12, 12, 2, 64), (1, 205, 150, 1, 128), (1, 300, 100, 2, 128)])  # last: 10 row blocks on 8 waves
 def test_attention_structured(prec, B, S, F, H, Dh):
     _attn_case(prec, B, S, F, H, Dh)
 
