@@ -71,3 +71,15 @@ print("NT + wgrad at once: halves %.1f us ; all/all %.1f us ; serial %.1f us"
       % (both(lo128, nt, hi128, wg), both(allc, nt, masked_stream(full), wg), timeit(allc, nt) + timeit(allc, wg)), flush=True)
 print("ln_bwd (high 64) + wgrad (low 192) at once: %.1f us ; all/all %.1f us ; serial %.1f us"
       % (both(lo192, wg, hi64, ln), both(allc, wg, masked_stream(full), ln), timeit(allc, ln) + timeit(allc, wg)), flush=True)
+
+# ---- one full-batch GEMM vs two half-batch GEMMs on two streams (would a two-half-batch pipeline pay?)
+Mh = M // 2
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+for (N_, K_, name) in ((3 * E, E, "in_proj fwd"), (E, E, "out_proj dgrad"), (E, 2 * E, "ffn1 dgrad K2048")):
+    A_ = torch.randn(M, K_, generator=g).to(dev).bfloat16(); B_ = (torch.randn(N_, K_, generator=g) / 32).to(dev).bfloat16()
+    o_ = torch.zeros((M, N_), dtype=torch.bfloat16, device=dev); b_ = torch.zeros(N_, device=dev)
+    fullf = lambda: rt.gemm(L.EPI_STORE_T, A_, B_, M, N_, K_, o_, N_, bias=b_)
+    h1 = lambda: rt.gemm(L.EPI_STORE_T, A_[:Mh], B_, Mh, N_, K_, o_[:Mh], N_, bias=b_)
+    h2 = lambda: rt.gemm(L.EPI_STORE_T, A_[Mh:], B_, Mh, N_, K_, o_[Mh:], N_, bias=b_)
+    print("%-18s full %.1f us ; two halves concurrently %.1f us ; two halves back to back %.1f us"
+          % (name, timeit(s1, fullf), both(s1, h1, s2, h2), timeit(s1, h1) + timeit(s1, h2)), flush=True)
