@@ -211,6 +211,14 @@ int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const
 int timhip_dropout_mask(uint64_t seed, uint32_t site, float p, int rows, int cols, uint8_t* out,
                         void* stream);
 
+/* Graph-safe dropout.  Every entry point that takes a `seed` passes it to its kernels by value, so a step captured in a
+ * HIP graph would replay the masks of the captured step.  After timhip_dropout_salt(p) (p: one 64-bit word in device
+ * memory, owned by the caller, alive while registered) every dropout kernel launched from this library draws with
+ * seed + *p, read on the device when the kernel runs: bump the word between replays (or with a node inside the graph) and
+ * forward and backward of one replay still agree.  NULL restores plain launch-time seeds.  Process-wide (one process per
+ * GPU).  The reference has no counterpart: torch's CUDA-graph-safe Philox offsets play this role there. */
+int timhip_dropout_salt(const unsigned long long* dev_salt);
+
 /* ---------------------------------------------------------------- stages ---- */
 /* One post-norm encoder layer.  x_in (fp32 [M,E]) and x_in_T (T [M,E]) are the layer input,
  * x_out / x_out_T the output.  `saved` (timhip_layer_saved_bytes) is read back by the backward. */

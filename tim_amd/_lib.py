@@ -76,6 +76,7 @@ _SIGS = {
     "timhip_time_l1_fwd": (C.c_int, [i32, vp, i32, i32, vp, vp, vp, i32, vp]),
     "timhip_time_l1_bwd": (C.c_int, [i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
     "timhip_dropout_mask": (C.c_int, [u64, u32, f32, i32, i32, vp, vp]),
+    "timhip_dropout_salt": (C.c_int, [vp]),
     "timhip_layer_fwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp, vp, vp, sz, vp]),
     "timhip_layer_bwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp,
                                    C.POINTER(TimLayerGrads), vp, sz, vp]),

@@ -135,9 +135,16 @@ int wgrad(int prec, const void* dY, int ldy, int Nout, const void* X, int ldx, i
 
 }  // namespace
 
+const unsigned long long* tim_salt_ptr = nullptr;
+
 extern "C" {
 
 int timhip_version(void) { return TIMHIP_VERSION; }
+
+int timhip_dropout_salt(const unsigned long long* dev_salt) {
+  tim_salt_ptr = dev_salt;
+  return TIMHIP_OK;
+}
 
 const char* timhip_strerror(int code) {
   switch (code) {

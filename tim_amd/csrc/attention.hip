@@ -14,7 +14,7 @@ namespace {
 struct AttnArgs {
   int S, F, E, H, Dh, LP;  // LP = round_up(F + 1, 4): row pitch of the probability dropout stream
   float scale;
-  uint32_t thr; float dscale; uint64_t seed; uint32_t site;
+  uint32_t thr; float dscale; TimSeed seed; uint32_t site;
 };
 
 __device__ __forceinline__ float attn_keep(const AttnArgs& a, int b, int h, int row, int j) {

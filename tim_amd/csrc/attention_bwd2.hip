@@ -16,7 +16,7 @@ namespace {
 struct AttnArgsM {
   int S, F, E, H, LP;
   float scale;
-  uint32_t thr; float dscale; uint64_t seed; uint32_t site;
+  uint32_t thr; float dscale; TimSeed seed; uint32_t site;
   int abl;  // tuning builds only (TimDesc.reserved >> 8): 1 no scratch stores, 2 no dqkv stores, 4 operand rows alias row 0
 };
 #ifdef TIMHIP_TUNING

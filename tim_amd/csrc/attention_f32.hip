@@ -19,7 +19,7 @@ namespace {
 struct AttnArgsF {
   int S, F, E, H, LP;
   float scale;
-  uint32_t thr; float dscale; uint64_t seed; uint32_t site;
+  uint32_t thr; float dscale; TimSeed seed; uint32_t site;
 };
 
 __device__ __forceinline__ void keep4f(const AttnArgsF& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,

@@ -23,7 +23,7 @@ namespace {
 struct AttnArgsM {
   int S, F, E, H, LP;
   float scale;
-  uint32_t thr; float dscale; uint64_t seed; uint32_t site;
+  uint32_t thr; float dscale; TimSeed seed; uint32_t site;
 };
 
 __device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,

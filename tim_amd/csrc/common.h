@@ -87,6 +87,18 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_7(uint64_t seed, uint32_t
   return Philox4{c0, c1, c2, c3};
 }
 
+// Dropout seed as the kernels see it: the launch-time seed plus, when the caller registered one (timhip_dropout_salt), a
+// 64-bit salt read from device memory at run time.  A step captured in a HIP graph bakes its launch arguments in; the salt
+// is what lets every replay draw fresh masks (the host bumps the device word between replays, or inside the graph).
+extern const unsigned long long* tim_salt_ptr;  // host variable holding a device pointer (api.hip)
+struct TimSeed {
+  uint64_t base;
+  const unsigned long long* salt;
+  __host__ __device__ TimSeed() : base(0), salt(nullptr) {}
+  __host__ TimSeed(uint64_t s) : base(s), salt(tim_salt_ptr) {}
+  __device__ __forceinline__ operator uint64_t() const { return salt ? base + (uint64_t)*salt : base; }
+};
+
 // keep-threshold: element kept iff rnd >= thr  (P[drop] = thr / 2^32 = p)
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
   double t = (double)p * 4294967296.0;

@@ -30,7 +30,7 @@ struct EpiDev {
   void* out0; void* out1;
   const float* bias; const float* res; const void* aux;
   int ld0, ld1, ldres, ldaux;
-  uint32_t thr; float scale; uint32_t site; uint64_t seed;
+  uint32_t thr; float scale; uint32_t site; TimSeed seed;
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
   int vec8; // the operand-dtype outputs / aux of this epilogue also allow 8-element (16-byte) accesses
   long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)

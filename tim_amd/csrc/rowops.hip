@@ -164,7 +164,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, long long n, 
 // fp32 rows -> T rows with optional dropout and zero padding
 template <typename T>
 __global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int cols, int lds_, T* __restrict__ dst,
-                                 int ld, uint32_t thr, float scale, uint64_t seed, uint32_t site) {
+                                 int ld, uint32_t thr, float scale, TimSeed seed, uint32_t site) {
   const int r = blockIdx.y;
   const int colsq = (cols + 3) >> 2;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < ld; q += gridDim.x * blockDim.x) {
@@ -180,7 +180,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int co
 
 // d_x[r, c] = g[r, c] * mask  (backward of the feature dropout on raw inputs)
 __global__ void drop_bwd_rows_kernel(const float* __restrict__ g, int rows, int cols, int ldg, float* __restrict__ dx,
-                                     int ldx, uint32_t thr, float scale, uint64_t seed, uint32_t site) {
+                                     int ldx, uint32_t thr, float scale, TimSeed seed, uint32_t site) {
   const int r = blockIdx.y;
   const int colsq = (cols + 3) >> 2;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < colsq; q += gridDim.x * blockDim.x) {
@@ -206,7 +206,7 @@ __global__ void colsum_kernel(const T* __restrict__ src, int rows, int cols, int
   atomicAdd(out + c, s);
 }
 
-__global__ void dropout_mask_kernel(uint64_t seed, uint32_t site, uint32_t thr, int rows, int cols, uint8_t* out) {
+__global__ void dropout_mask_kernel(TimSeed seed, uint32_t site, uint32_t thr, int rows, int cols, uint8_t* out) {
   const int colsq = (cols + 3) >> 2;
   const size_t total = (size_t)rows * colsq;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ stats, int rows, int cols, int act,
                                                      const float* __restrict__ w, float* __restrict__ dyf, int lddy,
                                                      T* __restrict__ dyt, int ldt, uint32_t thr, float scale,
-                                                     uint64_t seed, uint32_t site, float* __restrict__ dgamma,
+                                                     TimSeed seed, uint32_t site, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows_pb,
                                                      float* __restrict__ partial) {
   extern __shared__ float red[];  // [4][2][cols]
@@ -443,7 +443,7 @@ template <typename T>
 __global__ void assemble_fwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
                                     const float* __restrict__ e0, const float* __restrict__ e1, int n_e_rows,
                                     const float* __restrict__ cls, const float* __restrict__ te, int Trows,
-                                    const float* __restrict__ mod, uint32_t thr, float scale, uint64_t seed,
+                                    const float* __restrict__ mod, uint32_t thr, float scale, TimSeed seed,
                                     uint32_t site, float* __restrict__ x, T* __restrict__ xt) {
   const int bs = blockIdx.x;  // b*S + s
   const int b = bs / S, s = bs % S;
@@ -471,7 +471,7 @@ __global__ void assemble_fwd_kernel(const TimSeqRow* __restrict__ rows, int B, i
 // Kernel 2: d_te[b, t, :] = sum over the token rows that read time row t (fixed order, no atomics).
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
                                                            const float* __restrict__ dx, int n_e_rows, uint32_t thr,
-                                                           float scale, uint64_t seed, uint32_t site,
+                                                           float scale, TimSeed seed, uint32_t site,
                                                            float* __restrict__ d_e0, float* __restrict__ d_e1,
                                                            float* __restrict__ d_cls, float* __restrict__ d_mod) {
   const int s = blockIdx.x;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __re
 
 __global__ __launch_bounds__(128) void assemble_bwd_te_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
                                                               const float* __restrict__ dx, int Trows, uint32_t thr,
-                                                              float scale, uint64_t seed, uint32_t site,
+                                                              float scale, TimSeed seed, uint32_t site,
                                                               float* __restrict__ d_te) {
   const int bt = blockIdx.x;
   const int b = bt / Trows, t = bt % Trows;

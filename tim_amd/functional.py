@@ -23,6 +23,31 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# graph-safe dropout (include/timhip.h: timhip_dropout_salt): one 64-bit word in device memory that every dropout kernel adds
+# to its launch-time seed.  Process-wide, like the library's pointer to it (one process per GPU).
+_SALT = {"word": None, "epoch": 0}
+_SALT_STEP = 0x51B54A32D192ED03  # < 2^63: int64 adds wrap on the device, which is all a salt needs
+
+
+def graph_safe_dropout(dev, enable=True):
+    """Register (or drop) the device-side dropout salt.  While registered, `Runtime.next_seed` advances the salt on the
+    device instead of changing the seed it hands to the launches - the form a captured HIP graph needs.  One encoder
+    forward must be followed by its own backward before the next training forward (the usual step structure): the
+    backward regenerates its masks from the salt the forward left behind."""
+    if not enable:
+        call("timhip_dropout_salt", None)
+        _SALT["word"] = None
+        return None
+    w = _SALT["word"]
+    if w is not None and w.device != torch.device(dev):
+        raise RuntimeError("the dropout salt lives on %s; one process drives one GPU" % w.device)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int64, device=dev)
+        call("timhip_dropout_salt", ptr(w))
+        _SALT["word"] = w
+    return w
+
+
 class Runtime:
     """Per-model state that is not a parameter: precision, operand-dtype working copies of
     the weights (plain and transposed, refreshed when a parameter's version changes),
@@ -111,6 +136,12 @@ class Runtime:
 
     def next_seed(self):
         self.step += 1
+        if _SALT["word"] is not None:
+            # graph-safe mode: the launch-time seed stays fixed, the per-step part lives in device memory and is advanced
+            # by a (capturable) device-side add, so a replayed graph draws fresh masks every time
+            _SALT["word"].add_(_SALT_STEP)
+            _SALT["epoch"] += 1
+            return (self.seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         return (self.seed * 0x9E3779B97F4A7C15 + self.step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
     # ---- thin op wrappers ------------------------------------------------------------------------
@@ -428,6 +459,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.model, ctx.plan, ctx.P_names = model, plan, model._encoder_param_names
         ctx.dims = (B, T, d, S, F, M, nv, na)
         ctx.drop = (p_feat, p_seq, p_enc, seed)
+        ctx.salt_epoch = _SALT["epoch"] if training else None
         ctx.emb_saved, ctx.layer_saved, ctx.head_saved, ctx.reg_saved = emb_saved, layer_saved, head_saved, reg_saved
         ctx.xs_t, ctx.lparams = xs_t, lparams
         ctx.in_shapes = (tuple(visual.shape), tuple(audio.shape))
@@ -445,6 +477,9 @@ class EncoderFn(torch.autograd.Function):
         P = dict(zip(names, params))
         B, T, d, S, F, M, nv, na = ctx.dims
         p_feat, p_seq, p_enc, seed = ctx.drop
+        if _SALT["word"] is not None and ctx.salt_epoch is not None and ctx.salt_epoch != _SALT["epoch"]:
+            raise RuntimeError("graph-safe dropout: another training forward ran between this forward and its backward; "
+                               "the masks are regenerated from the device-side salt, so each forward needs its backward first")
         E, FF, H, Lyr, nf = cfg.E, cfg.FF, cfg.nhead, cfg.num_layers, cfg.num_feats
         dev = params[0].device
         st = _stream()

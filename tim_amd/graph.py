@@ -1,0 +1,72 @@
+"""Whole-step HIP graphs for the TIM hot path.
+
+The reference leaves launch overhead to eager PyTorch (and, on NVIDIA, to whatever the user wraps around it); on MI355X the
+encoder step of a small model (C1: d_model 256, 2 layers) is launch-bound - ~330 kernels at ~5 us of host time each - so this
+module captures one full step (time MLP, encoder forward, loss, backward and optionally the optimizer) into a single
+`hipGraph` through `torch.cuda.graph` and replays it: one host call per step.
+
+What makes the HIP path capturable:
+  * every `timhip_*` launch goes to torch's current stream (the capture stream); the weight-gradient side stream forks from
+    and joins back into it with events, which capture as graph edges;
+  * workspaces / saved activations come from torch's allocator, so they land in the graph's private pool;
+  * dropout seeds are launch arguments, which a graph would freeze - `functional.graph_safe_dropout` moves the per-step part
+    of the seed into a device word that a node of the graph advances (include/timhip.h: timhip_dropout_salt);
+  * the operand-dtype weight copies are rebuilt by a cast kernel at the head of the captured step, so an optimizer update
+    between (or inside) replays is always picked up.
+
+Usage (the shape of the reference's train loop, scripts/train.py:250-330):
+
+    static = {k: torch.empty_like(v) for k, v in first_batch.items()}
+    def step():
+        optimizer.zero_grad(set_to_none=False)
+        loss = criterion(model(...static...))
+        loss.backward()
+        return loss
+    graphed = GraphedStep(model, step)
+    for batch in loader:
+        for k in static: static[k].copy_(batch[k])
+        loss = graphed()          # replay; `loss` is the captured output tensor, refreshed in place
+        optimizer.step()
+"""
+import torch
+
+from . import functional as F
+
+
+class GraphedStep:
+    """Capture `fn()` - a closure over static input tensors - once and replay it.
+
+    fn      callable without arguments running forward + backward (+ anything else that is capturable) of `model`
+    warmup  eager runs on a side stream before capture (allocator warm-up, weight copies, gradient buckets)
+    """
+
+    def __init__(self, model, fn, warmup=3):
+        inner = model.module if hasattr(model, "module") else model
+        self.rt = inner.rt
+        dev = next(inner.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedStep needs the model on a GPU; the HIP path has no CPU fallback")
+        self.salt = F.graph_safe_dropout(dev)  # kept alive: the captured kernels hold its address
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.rt.invalidate_weights()
+                fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        self.rt.invalidate_weights()  # the cast of every weight is part of the captured step
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+        # the gradient tensors the captured backward writes: re-attached on every replay, so eager steps in between (which
+        # may re-allocate .grad) do not detach the parameters from the graph's results
+        self._grads = [(p, p.grad) for p in inner.parameters() if p.grad is not None]
+        self.replays = 0
+
+    def __call__(self):
+        self.graph.replay()
+        for p, g in self._grads:
+            p.grad = g
+        self.replays += 1
+        return self.out
