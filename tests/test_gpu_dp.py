@@ -16,3 +16,14 @@ def test_dp_bucket_allreduce_path_on_one_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_single_gpu_check.py")], env=env,
                          capture_output=True, text=True, timeout=600)
     assert "RESULT params 102 mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_two_ranks_sharing_one_gpu_average_their_gradients():
+    """two real processes, each with its half of the windows, gradient buckets reduced over gloo on the device buffers
+    through tim_amd/dp.py's hooks and streams: result = half the gradients of one process run on all the windows"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "tools", "dp_two_rank_check.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert "RESULT params 102 mismatches 0 ranks_agree True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "RANK1 ranks_agree True" in out.stdout
