@@ -90,6 +90,7 @@ typedef struct TimDesc {
 #define TIMHIP_DESC_ATTN_BWD_ONE_KERNEL 2 /* single-kernel MFMA attention backward */
 #define TIMHIP_DESC_WGRAD_OVERWRITE 4  /* bf16 only: timhip_layer_bwd[_weights] WRITES the weight and bias gradients of the four
                                           Linears (dW = ..., not +=): those buffers need no zero fill and are not read */
+#define TIMHIP_DESC_WGRAD_SEPARATE 8   /* bf16 only: four timhip_wgrad launches per layer instead of the grouped one (A/B knob) */
 
 /* One encoder layer.  *_op are operand-dtype working copies made by timhip_prepare_weights:
  * w (as stored, [N,K]) and wt (transposed, [K,N]).  Biases and LayerNorm parameters are the
@@ -195,6 +196,23 @@ size_t timhip_attention_bwd_workspace_bytes(const TimDesc* d);
 size_t timhip_wgrad_workspace_bytes(int precision, int Nout, int Kout, int M);
 int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout,
                  int M, float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same for n <= 8 Linear layers that share M (the four of one encoder layer), as ONE launch: their tile lists are
+ * concatenated and the number of splits of the contraction is chosen for the total - at E = 1024, FF = 2048 the layer has
+ * exactly 512 tiles = the chip's 512 block slots, the contraction is not split and dW / db are written directly, with no
+ * partial slabs and no reduce.  accumulate = 0 writes dW / db instead of adding to them.  bf16 operands only (the fp32 and
+ * bf16x3 modes go through timhip_wgrad); every Nout*Kout must be a multiple of 4.  items is a HOST array, copied into the
+ * kernel arguments.  workspace may be NULL when timhip_wgrad_group_workspace_bytes returns 0. */
+typedef struct TimWgradItem {
+  const void* dY;   /* [M, ldy] */
+  const void* X;    /* [M, ldx] */
+  float* dW;        /* [Nout, Kout] */
+  float* db;        /* [Nout] or NULL */
+  int32_t ldy, ldx, Nout, Kout;
+} TimWgradItem;
+size_t timhip_wgrad_group_workspace_bytes(int precision, const TimWgradItem* items, int n, int M);
+int timhip_wgrad_group(int precision, const TimWgradItem* items, int n, int M, int accumulate, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* dx[r,c] = g[r,c] * keep-mask/(1-p): backward of the feature dropout applied by timhip_cast_rows */
 int timhip_dropout_rows_bwd(const float* g, int rows, int cols, int ldg, float* dx, int ldx,

@@ -179,6 +179,33 @@ def test_wgrad_and_colsum(prec):
     assert (db.cpu().double() - refb).abs().max().item() <= tol(prec, refb) * 4
 
 
+@pytest.mark.parametrize("accumulate", [True, False])
+@pytest.mark.parametrize("M,shapes", [
+    (523, [(200, 72), (64, 136), (130, 128)]),                       # ragged tiles, few tiles: the contraction is split
+    (155 * 8, [(256, 512), (512, 256), (256, 256), (768, 256)]),      # an encoder layer (E 256, FF 512): 48 tiles, split
+    (9920, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # C2a: 512 tiles, no split, direct writes
+    (4100, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # same, ragged last step of 64 rows
+])
+def test_wgrad_group(M, shapes, accumulate):
+    """several Linear weight gradients sharing M in one launch == the per-layer reference; biases optional"""
+    rt = Runtime("bf16")
+    items, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dY, dYr = to_op(rt, rnd(M, N, seed=20 + i) * 0.25)
+        X, Xr = to_op(rt, rnd(M, K, seed=40 + i) * 0.25)
+        dW = torch.full((N, K), 0.5, device=DEV)
+        db = None if i == 1 else torch.full((N,), 0.5, device=DEV)
+        items.append((dY, N, X, K, dW, db))
+        base = 0.5 if accumulate else 0.0
+        refs.append((base + dYr.to(DEV).double().t() @ Xr.to(DEV).double(), base + dYr.double().sum(0)))
+    rt.wgrad_group(items, M, accumulate=accumulate)
+    torch.cuda.synchronize()
+    for (dY, N, X, K, dW, db), (rw, rb) in zip(items, refs):
+        assert (dW.double() - rw).abs().max().item() <= 2e-5 * max(1.0, rw.abs().max().item()) * (M / 512) ** 0.5 + 1e-4
+        if db is not None:
+            assert (db.cpu().double() - rb).abs().max().item() <= 2e-5 * max(1.0, rb.abs().max().item()) + 1e-4
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("cols,act", [(1024, 0), (512, 2), (64, 1), (32, 2), (256, 0)])
 def test_layernorm_fwd_bwd(prec, cols, act):

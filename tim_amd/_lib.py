@@ -39,11 +39,15 @@ class TimLayerGrads(C.Structure):
     _fields_ = [(n, vp) for n in _LG]
 
 
-DESC_ATTN_FP32, DESC_ATTN_BWD_ONE_KERNEL, DESC_WGRAD_OVERWRITE = 1, 2, 4   # TimDesc.reserved flags
+DESC_ATTN_FP32, DESC_ATTN_BWD_ONE_KERNEL, DESC_WGRAD_OVERWRITE, DESC_WGRAD_SEPARATE = 1, 2, 4, 8   # TimDesc.reserved flags
 
 
 class TimCastItem(C.Structure):
     _fields_ = [("src", vp), ("plain", vp), ("tr", vp), ("rows", i32), ("cols", i32), ("ldp", i32), ("ldt", i32)]
+
+
+class TimWgradItem(C.Structure):
+    _fields_ = [("dY", vp), ("X", vp), ("dW", vp), ("db", vp), ("ldy", i32), ("ldx", i32), ("Nout", i32), ("Kout", i32)]
 
 
 class TimEpi(C.Structure):
@@ -63,6 +67,8 @@ _SIGS = {
     "timhip_gemm_nt": (C.c_int, [i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(TimEpi), i32, vp]),
     "timhip_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "timhip_wgrad_group_workspace_bytes": (sz, [i32, vp, i32, i32]),
+    "timhip_wgrad_group": (C.c_int, [i32, vp, i32, i32, i32, vp, sz, vp]),
     "timhip_transpose": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, vp]),
     "timhip_colsum": (C.c_int, [i32, vp, i32, i32, i32, vp, vp]),
     "timhip_cast_rows": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, f32, u64, u32, vp]),

@@ -80,6 +80,14 @@ WsLayout ws_layout(const TimDesc& d) {
     size_t w3 = wgrad_ws(d.precision, d.FF, d.E, (int)M).total;
     if (w2 > wg) wg = w2;
     if (w3 > wg) wg = w3;
+    if (d.precision == TIMHIP_PREC_BF16) {   // the grouped launch of timhip_layer_bwd_weights (slabs only when it splits)
+      const TimWgradItem it[4] = {{nullptr, nullptr, nullptr, nullptr, d.E, d.FF, d.E, d.FF},
+                                  {nullptr, nullptr, nullptr, nullptr, d.FF, d.E, d.FF, d.E},
+                                  {nullptr, nullptr, nullptr, nullptr, d.E, d.E, d.E, d.E},
+                                  {nullptr, nullptr, nullptr, nullptr, 3 * d.E, d.E, 3 * d.E, d.E}};
+      const size_t wgp = tim_wgrad_group_ws(it, 4, (int)M);
+      if (wgp > wg) wg = wgp;
+    }
     L.tA = take(wg);
     L.tB = L.tA;
     L.wg_bytes = wg;
@@ -169,6 +177,16 @@ int timhip_gemm_nt(int precision, int epi, const void* A, int lda, const void* B
 
 size_t timhip_wgrad_workspace_bytes(int precision, int Nout, int Kout, int M) {
   return wgrad_ws(precision, Nout, Kout, M).total;
+}
+
+size_t timhip_wgrad_group_workspace_bytes(int precision, const TimWgradItem* items, int n, int M) {
+  return (precision == TIMHIP_PREC_BF16 && items && n > 0) ? tim_wgrad_group_ws(items, n, M) : 0;
+}
+
+int timhip_wgrad_group(int precision, const TimWgradItem* items, int n, int M, int accumulate, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  if (precision != TIMHIP_PREC_BF16) return TIMHIP_EUNSUPPORTED;
+  return tim_wgrad_group_bf16(items, n, M, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M,
@@ -305,6 +323,15 @@ int timhip_layer_bwd_weights(const TimDesc* dp, const void* x_in_T, const void* 
   // linear2: dW2 += df^T h ; linear1: dW1 += du^T x1 ; out-proj: dWo += da^T o ; in-proj: dWin += dqkv^T x_in
   // (TIMHIP_DESC_WGRAD_OVERWRITE: "=" instead of "+=": the gradient buffers are neither zero-filled nor read)
   const int acc = (d.reserved & TIMHIP_DESC_WGRAD_OVERWRITE) ? 0 : 1;
+  if (prec == TIMHIP_PREC_BF16 && !(d.reserved & TIMHIP_DESC_WGRAD_SEPARATE) && ((size_t)E * E) % 4 == 0 && ((size_t)E * FF) % 4 == 0) {
+    // one grouped launch (wgrad.hip): 12 E^2 / 128^2 tiles with FF = 2E, i.e. 512 at E = 1024 - the contraction is not split
+    const TimWgradItem it[4] = {
+        {yb + Y.df, sv + L.h, g->l2_w, g->l2_b, E, FF, E, FF},
+        {yb + Y.du, sv + L.x1t, g->l1_w, g->l1_b, FF, E, FF, E},
+        {yb + Y.da, sv + L.o, g->out_w, g->out_b, E, E, E, E},
+        {yb + Y.dqkv, x_in_T, g->in_w, g->in_b, 3 * E, E, 3 * E, E}};
+    return tim_wgrad_group_bf16(it, 4, M, acc, workspace, workspace_bytes, s);
+  }
   if ((rc = wgrad(prec, yb + Y.df, E, E, sv + L.h, FF, FF, M, g->l2_w, g->l2_b, workspace, workspace_bytes, s, acc))) return rc;
   if ((rc = wgrad(prec, yb + Y.du, FF, FF, sv + L.x1t, E, E, M, g->l1_w, g->l1_b, workspace, workspace_bytes, s, acc))) return rc;
   if ((rc = wgrad(prec, yb + Y.da, E, E, sv + L.o, E, E, M, g->out_w, g->out_b, workspace, workspace_bytes, s, acc))) return rc;

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ 
   const int ldy = FP;
   const bf16_t* X = prod ? d_o + (size_t)b * S * E + (size_t)h * DH : qkv + (size_t)b * S * 3 * E + (size_t)h * DH;
   const int ldx = prod ? E : 3 * E;
+  const int xcols = prod ? E - h * DH : 3 * E - h * DH;   // columns of the row that lie at or after X's first column
   bf16_t* out = dqkv + (size_t)b * S * 3 * E + (prod ? 2 * E : E) + (size_t)h * DH;
   const int ldo = 3 * E;
   const int n0 = blockIdx.x * WT, k0 = 0, M = S, N = F, K = DH;
@@ -228,7 +229,9 @@ __global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ 
     const int c = lc ^ swz<128>(row);
     srow[i] = row;
     yoff[i] = (uint32_t)(((size_t)row * ldy + min(n0 + c * 8, ldy - 8)) * 2);
-    xoff[i] = (uint32_t)(((size_t)row * ldx + min(k0 + c * 8, ldx - 8)) * 2);
+    // the tile is 128 columns wide whatever DH is: chunks past this head's columns are clamped INSIDE the row (X starts
+    // h*DH columns into it), so that the last row of the last head never reads past the end of the buffer
+    xoff[i] = (uint32_t)(((size_t)row * ldx + min(k0 + c * 8, xcols - 8)) * 2);
   }
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int step, int buf) {

@@ -258,6 +258,9 @@ int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStr
 size_t tim_wgrad_tn_ws(int Nout, int Kout, int M);
 int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
                       void* ws, size_t ws_bytes, hipStream_t s, int accumulate = 1);
+size_t tim_wgrad_group_ws(const TimWgradItem* it, int n, int M);
+int tim_wgrad_group_splits(const TimWgradItem* it, int n, int M);
+int tim_wgrad_group_bf16(const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,

@@ -27,32 +27,26 @@ __device__ __forceinline__ int xcd_remap_w(int b, int nb) {  // bijective for an
 constexpr int WT = 128;   // output tile: 128 (n) x 128 (k)
 constexpr int WM = 64;    // contraction rows per step
 
-__global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __restrict__ dY, int ldy,
-                                                            const bf16_t* __restrict__ X, int ldx, int M, int N,
-                                                            int K, int steps_per_split, float* __restrict__ slab,
-                                                            long long slab_stride, float* __restrict__ db_slab) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][sY 16 KB | sX 16 KB]
+// One work item: the 128 x 128 tile (n0, k0) of dW over the contraction steps [s0, s1) of 64 rows.  `out` is an [N, K] fp32
+// matrix (a slab of partial sums, or dW itself when the contraction is not split), `db_out` an [N] vector (first k-tile
+// column only).  accumulate: out += / db_out += instead of =.
+struct WgTile {
+  const bf16_t* dY; const bf16_t* X; float* out; float* db_out;
+  int ldy, ldx, M, N, K, n0, k0, s0, s1, do_bias, accumulate;
+};
+
+__device__ __forceinline__ void wgrad_tile(const WgTile& a, char* lds) {
   constexpr int TILE_BYTES = WM * WT * 2;
+  const bf16_t* __restrict__ dY = a.dY;
+  const bf16_t* __restrict__ X = a.X;
+  const int ldy = a.ldy, ldx = a.ldx, M = a.M, N = a.N, K = a.K, n0 = a.n0, k0 = a.k0, s0 = a.s0, s1 = a.s1;
+  const bool do_bias = a.do_bias != 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave >> 1, wn = wave & 1;
-  const int tiles_k = (K + WT - 1) / WT, tiles_n = (N + WT - 1) / WT;
-  // 1-D grid over (split, tile) work items, split-major.  Block b runs on XCD b % 8 (observed), so every XCD
-  // is given a CONTIGUOUS range of work items: one split's row range of dY / X and a few n-tile rows, instead
-  // of every XCD's L2 streaming all of dY and X (fabric reads 245 MB -> ~1.5x the operand bytes).
-  const int ntiles = tiles_k * tiles_n;
-  const int w = xcd_remap_w(blockIdx.x, gridDim.x);
-  const int zsplit = w / ntiles;
-  const int t = w - zsplit * ntiles;
-  // consecutive work items share the dY panel (same n-tile): k-tile fastest
-  const int n0 = (t / tiles_k) * WT, k0 = (t % tiles_k) * WT;
-  const bool do_bias = db_slab != nullptr && (t % tiles_k) == 0;
-  const int nsteps = (M + WM - 1) / WM;
-  const int s0 = zsplit * steps_per_split;
-  const int s1 = min(nsteps, s0 + steps_per_split);
 
   // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; lane -> (row, chunk').  Column chunks beyond the
-  // leading dimension are clamped (they only feed output columns that are never stored); rows beyond M
+  // operand's own columns (rounded up to 8: the leading dimensions are multiples of 8) are clamped (they only feed output columns that are never stored); rows beyond M
   // (last step only) must contribute zeros: that stage reads clamped rows and the padding rows of both LDS tiles
   // are zeroed before the fragments are read.
   const int lrow = lane >> 4, lc = lane & 15;
@@ -63,8 +57,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
     const int row = (wave * 4 + i) * 4 + lrow;
     const int c = lc ^ swz<128>(row);
     srow[i] = row;
-    yoff[i] = (uint32_t)(((size_t)row * ldy + min(n0 + c * 8, ldy - 8)) * 2);
-    xoff[i] = (uint32_t)(((size_t)row * ldx + min(k0 + c * 8, ldx - 8)) * 2);
+    yoff[i] = (uint32_t)(((size_t)row * ldy + min(n0 + c * 8, ((N + 7) & ~7) - 8)) * 2);
+    xoff[i] = (uint32_t)(((size_t)row * ldx + min(k0 + c * 8, ((K + 7) & ~7) - 8)) * 2);
   }
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int step, int buf) {
@@ -159,7 +153,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
   }
 
   const int li = lane & 31, g = lane >> 5;
-  float* out = slab + (long long)zsplit * slab_stride;
+  float* __restrict__ out = a.out;
   // transpose the accumulators through a wave-private LDS region so that 16 lanes store one contiguous
   // 64-column row segment of the slab (same scheme as the NT GEMM epilogue)
   constexpr int EP_LD = 64 + 4;
@@ -183,12 +177,18 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
       const int k = k0 + wk * 64 + ch * 4;
       if (n < N) {
         if (k + 3 < K) {
-          *reinterpret_cast<float4*>(out + (size_t)n * K + k) = v;
+          float4* dst = reinterpret_cast<float4*>(out + (size_t)n * K + k);
+          if (a.accumulate) {
+            const float4 o = *dst;
+            *dst = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+          } else {
+            *dst = v;
+          }
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int tt = 0; tt < 4; ++tt)
-            if (k + tt < K) out[(size_t)n * K + k + tt] = vv[tt];
+            if (k + tt < K) out[(size_t)n * K + k + tt] = a.accumulate ? out[(size_t)n * K + k + tt] + vv[tt] : vv[tt];
         }
       }
     }
@@ -196,7 +196,118 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
     if (do_bias && wk == 0) {
       const int n = n0 + wn * 64 + j * 32 + li;
       const float t2 = bsum[j] + __shfl_xor(bsum[j], 32, 64);
-      if (g == 0 && n < N) db_slab[(size_t)zsplit * N + n] = t2;
+      if (g == 0 && n < N) a.db_out[n] = a.accumulate ? a.db_out[n] + t2 : t2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __restrict__ dY, int ldy,
+                                                            const bf16_t* __restrict__ X, int ldx, int M, int N,
+                                                            int K, int steps_per_split, float* __restrict__ slab,
+                                                            long long slab_stride, float* __restrict__ db_slab) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][sY 16 KB | sX 16 KB]
+  const int tiles_k = (K + WT - 1) / WT, tiles_n = (N + WT - 1) / WT;
+  // 1-D grid over (split, tile) work items, split-major.  Block b runs on XCD b % 8 (observed), so every XCD
+  // is given a CONTIGUOUS range of work items: one split's row range of dY / X and a few n-tile rows, instead
+  // of every XCD's L2 streaming all of dY and X (fabric reads 245 MB -> ~1.5x the operand bytes).
+  const int ntiles = tiles_k * tiles_n;
+  const int w = xcd_remap_w(blockIdx.x, gridDim.x);
+  const int zsplit = w / ntiles;
+  const int t = w - zsplit * ntiles;
+  const int nsteps = (M + WM - 1) / WM;
+  WgTile a;
+  a.dY = dY; a.X = X; a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  // consecutive work items share the dY panel (same n-tile): k-tile fastest
+  a.n0 = (t / tiles_k) * WT; a.k0 = (t % tiles_k) * WT;
+  a.do_bias = db_slab != nullptr && (t % tiles_k) == 0;
+  a.s0 = zsplit * steps_per_split;
+  a.s1 = min(nsteps, a.s0 + steps_per_split);
+  a.out = slab + (long long)zsplit * slab_stride;
+  a.db_out = db_slab ? db_slab + (size_t)zsplit * N : nullptr;
+  a.accumulate = 0;
+  wgrad_tile(a, lds);
+}
+
+// ---- grouped form: the weight gradients of several Linear layers that share the contraction length M (one encoder
+// layer: linear2, linear1, out-proj, in-proj) as ONE grid.  All work items cost the same (same M), so the tile lists are
+// simply concatenated and the number of splits is chosen for the total: at C2a the four gradients are 128 + 128 + 64 + 192 =
+// 512 tiles = exactly the 512 block slots, so the contraction is not split at all - every block runs the whole M and writes
+// (or accumulates into) dW / db directly: no slabs (was 330 MB of slab writes + reads per layer), no reduce launches, one
+// tail instead of four.
+constexpr int WG_MAX = 8;
+struct WgGroup {
+  const bf16_t* dY[WG_MAX]; const bf16_t* X[WG_MAX]; float* dW[WG_MAX]; float* db[WG_MAX];
+  int ldy[WG_MAX], ldx[WG_MAX], N[WG_MAX], K[WG_MAX];
+  int tile0[WG_MAX + 1];          // first work tile of every item (prefix sums), tile0[n] = total
+  long long off[WG_MAX + 1];      // element offset of every item's [N, K] block inside one slab
+  int boff[WG_MAX + 1];           // same for the bias slabs
+  int n, M, steps_per_split, splits, accumulate;
+  float* slab; float* db_slab;    // [splits][off[n]] and [splits][boff[n]] (splits > 1 only)
+};
+
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int ntiles = g.tile0[g.n];
+  const int w = xcd_remap_w(blockIdx.x, gridDim.x);
+  const int zsplit = w / ntiles;
+  const int t = w - zsplit * ntiles;
+  WgTile a;
+  int tl = t, tiles_k = 1;
+  long long off = 0;
+  int boff = 0;
+  float* dW = nullptr;
+  float* db = nullptr;
+#pragma unroll
+  for (int i = 0; i < WG_MAX; ++i) {   // static indexing of the kernel-argument arrays (uniform select)
+    if (i < g.n && t >= g.tile0[i]) {
+      a.dY = g.dY[i]; a.X = g.X[i]; a.ldy = g.ldy[i]; a.ldx = g.ldx[i]; a.N = g.N[i]; a.K = g.K[i];
+      tl = t - g.tile0[i]; tiles_k = (g.K[i] + WT - 1) / WT;
+      off = g.off[i]; boff = g.boff[i]; dW = g.dW[i]; db = g.db[i];
+    }
+  }
+  a.M = g.M;
+  a.n0 = (tl / tiles_k) * WT; a.k0 = (tl % tiles_k) * WT;
+  a.do_bias = db != nullptr && (tl % tiles_k) == 0;
+  const int nsteps = (g.M + WM - 1) / WM;
+  a.s0 = zsplit * g.steps_per_split;
+  a.s1 = min(nsteps, a.s0 + g.steps_per_split);
+  if (g.splits == 1) {
+    a.out = dW; a.db_out = db; a.accumulate = g.accumulate;
+  } else {
+    a.out = g.slab + (long long)zsplit * g.off[g.n] + off;
+    a.db_out = g.db_slab + (long long)zsplit * g.boff[g.n] + boff;
+    a.accumulate = 0;
+  }
+  wgrad_tile(a, lds);
+}
+
+// splits > 1: dW_i (+)= sum_z slab[z][off_i + .], db_i (+)= sum_z db_slab[z][boff_i + .], all items in one launch
+__global__ void wgrad_group_reduce_kernel(const WgGroup g) {
+  const long long nq = g.off[g.n] >> 2;           // every N*K is a multiple of 4 (checked by the launcher)
+  const int nb = g.boff[g.n];
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq + nb; q += (long long)gridDim.x * blockDim.x) {
+    if (q < nq) {
+      const long long i = q << 2;
+      float* dst = nullptr;
+#pragma unroll
+      for (int it = 0; it < WG_MAX; ++it)
+        if (it < g.n && i >= g.off[it]) dst = g.dW[it] + (i - g.off[it]);
+      float4 acc = g.accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int z = 0; z < g.splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(g.slab + (long long)z * g.off[g.n] + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(dst) = acc;
+    } else {
+      const int j = (int)(q - nq);
+      float* dst = nullptr;
+#pragma unroll
+      for (int it = 0; it < WG_MAX; ++it)
+        if (it < g.n && j >= g.boff[it]) dst = g.db[it] + (j - g.boff[it]);   // items without a bias have an empty range
+      if (!dst) continue;
+      float acc = g.accumulate ? *dst : 0.f;
+      for (int z = 0; z < g.splits; ++z) acc += g.db_slab[(long long)z * nb + j];
+      *dst = acc;
     }
   }
 }
@@ -240,8 +351,7 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ slab, long long n,
 // Cost model in units of one 64-row K-step of one block, fitted to tools/wgrad_splits.py on the C2a shapes:
 //   steps per item x (full rounds + a partial round priced at 0.5 + 0.5 x its fill) + slab traffic per split
 // e.g. in-proj (192 tiles): 3 splits = 576 items (1.125 rounds) 108 us, 5 splits = 960 items 100 us.
-int tim_wgrad_splits(int Nout, int Kout, int M) {
-  const int tiles = ((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT);
+static int splits_for_tiles(int tiles, int M) {
   const int nsteps = (M + WM - 1) / WM;
 #ifdef TIMHIP_TUNING
   if (const char* v = getenv("TIMHIP_WGRAD_SPLITS")) { int sk = atoi(v); if (sk >= 1 && sk <= nsteps) return sk; }
@@ -259,6 +369,74 @@ int tim_wgrad_splits(int Nout, int Kout, int M) {
     if (sk == 1 || cost < best_cost) { best = sk; best_cost = cost; }
   }
   return best;
+}
+
+int tim_wgrad_splits(int Nout, int Kout, int M) {
+  return splits_for_tiles(((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT), M);
+}
+
+// ---- grouped launch (one encoder layer's four weight gradients) ------------------------------------------------------
+static int group_tiles(const TimWgradItem* it, int n) {
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += ((it[i].Nout + WT - 1) / WT) * ((it[i].Kout + WT - 1) / WT);
+  return tiles;
+}
+
+int tim_wgrad_group_splits(const TimWgradItem* it, int n, int M) { return splits_for_tiles(group_tiles(it, n), M); }
+
+size_t tim_wgrad_group_ws(const TimWgradItem* it, int n, int M) {
+  const int sk = tim_wgrad_group_splits(it, n, M);
+  if (sk == 1) return 0;
+  size_t elems = 0, bias = 0;
+  for (int i = 0; i < n; ++i) { elems += (size_t)it[i].Nout * it[i].Kout; bias += (size_t)it[i].Nout; }
+  return align_up(sk * elems * 4, 256) + align_up(sk * bias * 4, 256);
+}
+
+int tim_wgrad_group_bf16(const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!it || n < 1 || n > WG_MAX || M <= 0) return TIMHIP_EINVAL;
+  WgGroup g;
+  g.n = n; g.M = M; g.accumulate = accumulate ? 1 : 0;
+  g.tile0[0] = 0; g.off[0] = 0; g.boff[0] = 0;
+  double flops = 0.0;
+  for (int i = 0; i < WG_MAX; ++i) {
+    if (i >= n) {
+      g.dY[i] = g.X[i] = nullptr; g.dW[i] = g.db[i] = nullptr; g.ldy[i] = g.ldx[i] = g.N[i] = g.K[i] = 0;
+      g.tile0[i + 1] = g.tile0[i]; g.off[i + 1] = g.off[i]; g.boff[i + 1] = g.boff[i];
+      continue;
+    }
+    const TimWgradItem& t = it[i];
+    if (!t.dY || !t.X || !t.dW || t.Nout <= 0 || t.Kout <= 0) return TIMHIP_EINVAL;
+    if ((t.ldy % 8) || (t.ldx % 8) || (((uintptr_t)t.dY | (uintptr_t)t.X | (uintptr_t)t.dW) & 15)) return TIMHIP_EALIGN;
+    if (((long long)t.Nout * t.Kout) & 3) return TIMHIP_EUNSUPPORTED;
+    g.dY[i] = (const bf16_t*)t.dY; g.X[i] = (const bf16_t*)t.X; g.dW[i] = t.dW; g.db[i] = t.db;
+    g.ldy[i] = t.ldy; g.ldx[i] = t.ldx; g.N[i] = t.Nout; g.K[i] = t.Kout;
+    g.tile0[i + 1] = g.tile0[i] + ((t.Nout + WT - 1) / WT) * ((t.Kout + WT - 1) / WT);
+    g.off[i + 1] = g.off[i] + (long long)t.Nout * t.Kout;
+    g.boff[i + 1] = g.boff[i] + (t.db ? t.Nout : 0);
+    flops += 2.0 * M * t.Nout * t.Kout;
+  }
+  const int sk = splits_for_tiles(g.tile0[n], M);
+  const int nsteps = (M + WM - 1) / WM;
+  const int per = (nsteps + sk - 1) / sk;
+  const int sk_eff = (nsteps + per - 1) / per;  // no empty splits
+  g.steps_per_split = per; g.splits = sk_eff;
+  g.slab = nullptr; g.db_slab = nullptr;
+  if (sk_eff > 1) {
+    if (ws_bytes < tim_wgrad_group_ws(it, n, M) || !ws || ((uintptr_t)ws & 15)) return TIMHIP_EWORKSPACE;
+    g.slab = (float*)ws;
+    g.db_slab = (float*)((char*)ws + align_up((size_t)sk * g.off[n] * 4, 256));
+  }
+  TimGemmScope timing(flops, s);   // kernel (+ reduce)
+  const size_t shmem = 2 * 2 * WM * WT * 2;
+  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)(g.tile0[n] * sk_eff)), dim3(256), shmem, s, g);
+  if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
+  if (sk_eff > 1) {
+    long long blocks = ((g.off[n] >> 2) + g.boff[n] + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g);
+    if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
+  }
+  return TIMHIP_OK;
 }
 
 // workspace: [slab sk*N*K fp32][db slab sk*N fp32]

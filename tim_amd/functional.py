@@ -67,6 +67,7 @@ class Runtime:
         self.finish_hook = None  # callable() -> None, called at the end of the encoder backward
         # weight-gradient GEMMs of layer l run on a side stream, overlapping the data chain of layer l-1
         self.overlap_wgrad = os.environ.get("TIM_AMD_SERIAL_BWD", "0") != "1"  # 1: single-stream (profiling)
+        self.separate_wgrad = os.environ.get("TIM_AMD_WGRAD_SEPARATE", "0") == "1"  # A/B: per-Linear weight-gradient launches
         self._aux = {}
 
     def aux_stream(self, dev):
@@ -162,6 +163,16 @@ class Runtime:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dY.device)
         call("timhip_wgrad", self.prec, ptr(dY), dY.stride(0), Nout, ptr(X), X.stride(0), Kout, M, ptr(dW),
              ptr(db), ptr(ws), nbytes, _stream())
+
+    def wgrad_group(self, items, M, accumulate=True):
+        """items: [(dY, Nout, X, Kout, dW, db|None), ...] sharing M - the weight gradients of several Linear layers as one
+        launch (bf16; timhip_wgrad_group)"""
+        arr = (L.TimWgradItem * len(items))(*[L.TimWgradItem(ptr(dY), ptr(X), ptr(dW), ptr(db), dY.stride(0), X.stride(0),
+                                                             Nout, Kout) for dY, Nout, X, Kout, dW, db in items])
+        pa = C.cast(arr, C.c_void_p)
+        nbytes = L.load().timhip_wgrad_group_workspace_bytes(self.prec, pa, len(items), M)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=items[0][0].device)
+        call("timhip_wgrad_group", self.prec, pa, len(items), M, 1 if accumulate else 0, ptr(ws), nbytes, _stream())
 
     def ln_fwd(self, y, rows, cols, act, w, b, xf=None, ldx=0, xt=None, ldt=0, stats=None):
         call("timhip_layernorm_fwd", self.prec, ptr(y), rows, cols, y.stride(0), act, ptr(w), ptr(b), ptr(xf), ldx,
@@ -538,7 +549,8 @@ class EncoderFn(torch.autograd.Function):
         # ---- layers, last to first.  Per layer: the data chain on the current stream, the four
         # weight-gradient GEMMs on a side stream (they overlap the data chain of the next layer);
         # each layer's bucket is handed to the hook as soon as its weight gradients are enqueued.
-        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, L.DESC_WGRAD_OVERWRITE if overwrite else 0)
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0,
+                         (L.DESC_WGRAD_OVERWRITE if overwrite else 0) | (L.DESC_WGRAD_SEPARATE if rt.separate_wgrad else 0))
         lib = L.load()
         dx2 = torch.empty_like(dx)
         stack = model._stack_prefix
