@@ -11,7 +11,7 @@ import collections, csv, glob, json, sys
 root, out = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: {"fetch_kib": 0.0, "write_kib": 0.0, "n_f": 0, "n_w": 0})
 def fam(name):
-    for k in ("gemm_nt_bf16_kernel", "wgrad_tn_bf16_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "ln_fwd_kernel",
+    for k in ("gemm_nt_bf16_kernel", "wgrad_group_kernel", "wgrad_tn_bf16_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "ln_fwd_kernel",
               "ln_bwd_kernel", "wgrad_reduce_kernel", "cast_weights_kernel", "attn_bwd_rows", "attn_bwd_keys"):
         if k in name:
             return k
