@@ -38,27 +38,6 @@ for name in names:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             bench.step_fn(model, batch, nv, na, R)
-        # do HIP events recorded during capture (event-record nodes) carry valid timestamps after a replay?
-        import ctypes as C
-        from tim_amd import _lib as L
-        L.call("timhip_gemm_timing_start", 256, 1.0e10)
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2):
-            bench.step_fn(model, batch, nv, na, R)
-        for _ in range(3):
-            g2.replay()
-        torch.cuda.synchronize()
-        ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int(0)
-        try:
-            L.call("timhip_gemm_timing_stop", C.byref(ms_), C.byref(fl_), C.byref(n_))
-            print("  event nodes: %d launches, %.3f ms, %.1f TF" % (n_.value, ms_.value, fl_.value / max(ms_.value, 1e-9) / 1e9))
-        except Exception as e:
-            print("  event nodes: timing_stop failed:", e)
-        t0 = time.perf_counter()
-        for _ in range(30):
-            g2.replay()
-        torch.cuda.synchronize()
-        print("  graph with event nodes: %.3f ms/step" % ((time.perf_counter() - t0) / 30 * 1e3))
         for _ in range(5):
             g.replay()
         torch.cuda.synchronize()
@@ -72,4 +51,32 @@ for name in names:
         traceback.print_exc()
         t_graph = float("nan")
     print("%-4s B=%d eager %.3f ms/step (host enqueue %.3f) ; graph replay %.3f ms/step" % (name, B, t_eager, t_host, t_graph),
+          flush=True)
+    # the other stream configuration of the backward
+    model.rt.overlap_wgrad = not model.rt.overlap_wgrad
+    for _ in range(3):
+        bench.step_fn(model, batch, nv, na, R)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        bench.step_fn(model, batch, nv, na, R)
+    torch.cuda.synchronize()
+    t_eager1 = (time.perf_counter() - t0) / 30 * 1e3
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        bench.step_fn(model, batch, nv, na, R)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        bench.step_fn(model, batch, nv, na, R)
+    for _ in range(5):
+        g1.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        g1.replay()
+    torch.cuda.synchronize()
+    print("     other stream configuration: eager %.3f ms/step ; graph replay %.3f ms/step" % (t_eager1, (time.perf_counter() - t0) / 30 * 1e3),
           flush=True)
