@@ -466,43 +466,56 @@ __global__ void assemble_fwd_kernel(const TimSeqRow* __restrict__ rows, int B, i
   }
 }
 
-// backward.  Kernel 1: block (s, y) walks the y-th share of the windows for token row s: writes d_e (feature rows), and
-// reduces the cls / modality gradients over its windows in registers before ONE atomic per column.
+// backward.  Kernel 1: block (s, y) owns 256 columns of token row s for ALL windows: 4 row lanes x 64 column quads, each row
+// lane walks every 4th window (16-byte loads), writes d_e (feature rows) and keeps the cls / modality sums in registers; the
+// row lanes are combined through LDS and the block issues ONE atomic per column (device-scope float atomics are resolved
+// at the memory side on this part - an earlier version with 8 window groups per row spent most of its 110 us in them).
 // Kernel 2: d_te[b, t, :] = sum over the token rows that read time row t (fixed order, no atomics).
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
                                                            const float* __restrict__ dx, int n_e_rows, uint32_t thr,
                                                            float scale, TimSeed seed, uint32_t site,
                                                            float* __restrict__ d_e0, float* __restrict__ d_e1,
                                                            float* __restrict__ d_cls, float* __restrict__ d_mod) {
+  __shared__ float4 red[4][64];
   const int s = blockIdx.x;
   const TimSeqRow r = rows[s];
   const int E = 2 * d;
-  const int bper = (B + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
-  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  for (int c0 = blockIdx.y * 256; c0 < E; c0 += gridDim.y * 256) {
+    const int c = c0 + q * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = b0; b < b1; ++b) {
-      const size_t bs = (size_t)b * S + s;
-      float4 g = *reinterpret_cast<const float4*>(dx + bs * E + c);
-      if (thr != 0u) {
-        float k0, k1, k2, k3;
-        drop_mask4(seed, site, (bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
-        g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+    if (c < E) {
+#pragma unroll 4
+      for (int b = rl; b < B; b += 4) {
+        const size_t bs = (size_t)b * S + s;
+        float4 g = *reinterpret_cast<const float4*>(dx + bs * E + c);
+        if (thr != 0u) {
+          float k0, k1, k2, k3;
+          drop_mask4(seed, site, (bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
+          g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+        }
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        if (c < d && r.kind != 1) {
+          float* d_e = r.kind == 0 ? d_e0 : d_e1;
+          if (d_e) store4<float>(d_e + ((size_t)b * n_e_rows + r.src) * d + c, g.x, g.y, g.z, g.w);
+        }
       }
-      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-      if (c < d && r.kind != 1) {
-        float* d_e = r.kind == 0 ? d_e0 : d_e1;
-        if (d_e) store4<float>(d_e + ((size_t)b * n_e_rows + r.src) * d + c, g.x, g.y, g.z, g.w);
+    }
+    red[rl][q] = acc;
+    __syncthreads();
+    if (rl == 0 && c < E) {
+      const float4 a1 = red[1][q], a2 = red[2][q], a3 = red[3][q];
+      acc.x += a1.x + a2.x + a3.x; acc.y += a1.y + a2.y + a3.y; acc.z += a1.z + a2.z + a3.z; acc.w += a1.w + a2.w + a3.w;
+      if (r.mod >= 0 && d_mod) {
+        float* p = d_mod + (size_t)r.mod * E + c;
+        atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
+      }
+      if (c < d && r.kind == 1 && d_cls) {
+        float* p = d_cls + (size_t)r.src * d + c;
+        atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
       }
     }
-    if (r.mod >= 0 && d_mod) {
-      float* p = d_mod + (size_t)r.mod * E + c;
-      atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
-    }
-    if (c < d && r.kind == 1 && d_cls) {
-      float* p = d_cls + (size_t)r.src * d + c;
-      atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
-    }
+    __syncthreads();
   }
 }
 
@@ -786,7 +799,7 @@ int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float*
   if (!rows || !dx || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
   const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
   const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S, B >= 16 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows, thr,
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S, (2 * d + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows, thr,
                      scale, seed, site, d_e0, d_e1, d_cls, d_mod);
   TIM_CHECK_LAUNCH();
   if (d_te) {

@@ -167,6 +167,26 @@ class Runtime:
         call("timhip_wgrad", self.prec, ptr(dY), dY.stride(0), Nout, ptr(X), X.stride(0), Kout, M, ptr(dW),
              ptr(db), ptr(ws), nbytes, _stream())
 
+    def wgrad_many(self, items):
+        """items: [(dY, Nout, X, Kout, M, dW, db), ...] - accumulate every weight gradient; in bf16 the items that share M go
+        out as one grouped launch (front end, heads: many small GEMMs that each would need their own split-K + reduce)"""
+        if self.prec != L.PREC_BF16:
+            for dY, Nout, X, Kout, M, dW, db in items:
+                self.wgrad(dY, Nout, X, Kout, M, dW, db)
+            return
+        by_m = {}
+        for it in items:
+            dY, Nout, X, Kout, M, dW, db = it
+            if M == 0:
+                continue
+            if (Nout * Kout) % 4:
+                self.wgrad(dY, Nout, X, Kout, M, dW, db)
+            else:
+                by_m.setdefault(M, []).append((dY, Nout, X, Kout, dW, db))
+        for M, grp in by_m.items():
+            for i in range(0, len(grp), 8):
+                self.wgrad_group(grp[i:i + 8], M, accumulate=True)
+
     def wgrad_group(self, items, M, accumulate=True):
         """items: [(dY, Nout, X, Kout, dW, db|None), ...] sharing M - the weight gradients of several Linear layers as one
         launch (bf16; timhip_wgrad_group)"""
@@ -240,10 +260,9 @@ class TimeMlpFn(torch.autograd.Function):
         dw0, db0, dw2, db2, dw4, db4, dlnw, dlnb = z(d, 2), z(d), z(d, d), z(d), z(d, d), z(d), z(d), z(d)
         du3 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
         rt.ln_bwd(g, u3, stats, R, d, 1, _f32c(lnw), dyt=du3, dgamma=dlnw, dbeta=dlnb)
-        rt.wgrad(du3, d, h2, d, R, dw4, db4)
         du2 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
         rt.gemm(L.EPI_DRELU_T, du3, rt.weight(w4, True), R, d, d, du2, ldd, aux=h2, ldaux=ldd)
-        rt.wgrad(du2, d, h1, d, R, dw2, db2)
+        rt.wgrad_many([(du3, d, h2, d, R, dw4, db4), (du2, d, h1, d, R, dw2, db2)])
         du1 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
         rt.gemm(L.EPI_DRELU_T, du2, rt.weight(w2, True), R, d, d, du1, ldd, aux=h1, ldaux=ldd)
         d_times = torch.empty((R, 2), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
@@ -511,7 +530,8 @@ class EncoderFn(torch.autograd.Function):
             dx.view(B, S, E)[:, :F] += g["feats"]  # tiny add of an incoming cotangent (plumbing)
         xL_t = ctx.xs_t[Lyr]
 
-        # ---- heads
+        # ---- heads (their weight gradients are collected and launched grouped by row count)
+        wg_items = []
         for slot, pname, s0, n, rows in ctx.head_saved:
             go = g[slot]
             if go is None or n == 0:
@@ -521,7 +541,7 @@ class EncoderFn(torch.autograd.Function):
             go = _f32c(go)
             gT = torch.empty((B * n, _ru(Cn)), dtype=rt.op_dtype, device=dev)
             call("timhip_cast_rows", rt.prec, ptr(go), B * n, Cn, Cn, ptr(gT), gT.shape[1], 0.0, 0, 0, st)
-            rt.wgrad(gT, Cn, rows, E, B * n, G["cls_head." + pname + ".weight"], G["cls_head." + pname + ".bias"])
+            wg_items.append((gT, Cn, rows, E, B * n, G["cls_head." + pname + ".weight"], G["cls_head." + pname + ".bias"]))
             d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
             rt.gemm(L.EPI_ADD_F32, gT, rt.weight(w, True), B * n, E, Cn, d_rows, E)
             call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
@@ -535,18 +555,20 @@ class EncoderFn(torch.autograd.Function):
             gz = _f32c(go) * y * (1.0 - y)
             gzT = torch.empty((B * n, 64), dtype=rt.op_dtype, device=dev)
             call("timhip_cast_rows", rt.prec, ptr(gz), B * n, 2, 2, ptr(gzT), 64, 0.0, 0, 0, st)
-            rt.wgrad(gzT, 2, h2, hid, B * n, G[pre + "4.weight"], G[pre + "4.bias"])
+            wg_items.append((gzT, 2, h2, hid, B * n, G[pre + "4.weight"], G[pre + "4.bias"]))
             dh2 = torch.zeros_like(h2)
             rt.gemm(L.EPI_DRELU_T, gzT, rt.weight(P[pre + "4.weight"], True), B * n, hid, 2, dh2, dh2.shape[1],
                     aux=h2, ldaux=h2.shape[1])
-            rt.wgrad(dh2, hid, h1, hid, B * n, G[pre + "2.weight"], G[pre + "2.bias"])
+            wg_items.append((dh2, hid, h1, hid, B * n, G[pre + "2.weight"], G[pre + "2.bias"]))
             dh1 = torch.zeros_like(h1)
             rt.gemm(L.EPI_DRELU_T, dh2, rt.weight(P[pre + "2.weight"], True), B * n, hid, hid, dh1, dh1.shape[1],
                     aux=h1, ldaux=h1.shape[1])
-            rt.wgrad(dh1, hid, rows, E, B * n, G[pre + "0.weight"], G[pre + "0.bias"])
+            wg_items.append((dh1, hid, rows, E, B * n, G[pre + "0.weight"], G[pre + "0.bias"]))
             d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
             rt.gemm(L.EPI_ADD_F32, dh1, rt.weight(P[pre + "0.weight"], True), B * n, E, hid, d_rows, E)
             call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
+        rt.wgrad_many(wg_items)
+        del wg_items
         grads.done("heads")
 
         # ---- layers, last to first.  Per layer: the data chain on the current stream, the four
@@ -617,6 +639,7 @@ class EncoderFn(torch.autograd.Function):
 
         # ---- embedders backward
         d_inputs = {"visual": None, "audio": None}
+        emb_items = []
         need_in = {"visual": ctx.needs_input_grad[3], "audio": ctx.needs_input_grad[4]}
         for name, slot, xT, u, stats, Cin, site in ctx.emb_saved:
             R = B * nf
@@ -624,13 +647,15 @@ class EncoderFn(torch.autograd.Function):
             duT = torch.zeros((R, _ru(d)), dtype=rt.op_dtype, device=dev)
             rt.ln_bwd(d_e[slot], u, stats, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), dyt=duT,
                       dgamma=G[fe + name + "_embedder.3.weight"], dbeta=G[fe + name + "_embedder.3.bias"])
-            rt.wgrad(duT, d, xT, Cin, R, G[fe + name + "_embedder.1.weight"], G[fe + name + "_embedder.1.bias"])
+            emb_items.append((duT, d, xT, Cin, R, G[fe + name + "_embedder.1.weight"], G[fe + name + "_embedder.1.bias"]))
             if need_in[name]:
                 gx = torch.empty((R, Cin), dtype=torch.float32, device=dev)
                 rt.gemm(L.EPI_ADD_F32, duT, rt.weight(w, True), R, Cin, d, gx, Cin)
                 dxin = torch.empty((R, Cin), dtype=torch.float32, device=dev)
                 call("timhip_dropout_rows_bwd", ptr(gx), R, Cin, Cin, ptr(dxin), Cin, p_feat, seed, site, st)
                 d_inputs[name] = dxin.view(B, nf, Cin)
+        rt.wgrad_many(emb_items)
+        del emb_items
         grads.done("front")
         if overlap:
             main.wait_stream(aux)  # all weight gradients are complete before autograd sees them

@@ -119,13 +119,11 @@ def _mlp_bwd(rt, gy, xT, h1, h2, w0, w2, w4, need_dx):
     g = _f32c(gy).reshape(R, 1)
     gT = torch.empty((R, 64), dtype=rt.op_dtype, device=dev)
     call("timhip_cast_rows", rt.prec, ptr(g), R, 1, 1, ptr(gT), 64, 0.0, 0, 0, st)
-    rt.wgrad(gT, 1, h2, d, R, dw4, db4)
     dh2 = torch.zeros_like(h2)
     rt.gemm(L.EPI_DRELU_T, gT, rt.weight(w4, True), R, d, 1, dh2, dh2.shape[1], aux=h2, ldaux=h2.shape[1])
-    rt.wgrad(dh2, d, h1, d, R, dw2, db2)
     dh1 = torch.zeros_like(h1)
     rt.gemm(L.EPI_DRELU_T, dh2, rt.weight(w2, True), R, d, d, dh1, dh1.shape[1], aux=h1, ldaux=h1.shape[1])
-    rt.wgrad(dh1, d, xT, K0, R, dw0, db0)
+    rt.wgrad_many([(gT, 1, h2, d, R, dw4, db4), (dh2, d, h1, d, R, dw2, db2), (dh1, d, xT, K0, R, dw0, db0)])
     dpts = None
     if need_dx:
         dpts = torch.empty((R, K0), dtype=torch.float32, device=dev)
