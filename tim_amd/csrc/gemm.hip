@@ -736,7 +736,13 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
 #endif
     {
       (void)variant;
-      if (tall_tile_wins(M, N, splitk))
+      // small problems (front end, heads: a few hundred to a few thousand rows): when 128-row tiles would fill at most
+      // half of the 512 block slots, 64 x 128 tiles (1 x 4 waves of 64 x 32, 48 KB of LDS: three blocks per CU) double
+      // the number of blocks - these launches are occupancy-bound, not staging-bound
+      const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
+      if (t128 <= 256 && M > 64)
+        launch_bf16<EPI, 64, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+      else if (tall_tile_wins(M, N, splitk))
         launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
       else
         launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);

@@ -412,16 +412,61 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
                                                           const float* __restrict__ w, const T* __restrict__ dh,
                                                           int ld, float* __restrict__ dw, float* __restrict__ db,
                                                           float* __restrict__ dt, int rows_pb) {
-  // one block: rows [r0, r1); thread j-loop over columns accumulates dw/db; per-row dt via wave reduction
+  // one block: rows [r0, r1).  dw/db: a thread owns 4 consecutive columns (one vector load per row) and every RL-th row;
+  // the row lanes are combined through LDS before the block's atomics (3 per column).  per-row dt via wave reduction
   const int r0 = blockIdx.x * rows_pb, r1 = min(rows, r0 + rows_pb);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = threadIdx.x; j < d; j += 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const float g = OpT<T>::to_f(dh[(size_t)r * ld + j]);
-      a0 += g * times[2 * r]; a1 += g * times[2 * r + 1]; a2 += g;
+  if ((d & 3) == 0 && (ld & 3) == 0) {
+    __shared__ float4 red[3][256];
+    const int nq = d >> 2;
+    const int RL = nq >= 256 ? 1 : (nq > 128 ? 1 : (nq > 64 ? 2 : 4));
+    const int W = 256 / RL;
+    const int ql = threadIdx.x % W, rl = threadIdx.x / W;
+    for (int q0 = 0; q0 < nq; q0 += W) {
+      const int q = q0 + ql;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+      if (q < nq) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += RL) {
+          float g0, g1, g2, g3;
+          load4<T>(dh + (size_t)r * ld + 4 * q, g0, g1, g2, g3);
+          const float t0 = times[2 * r], t1 = times[2 * r + 1];
+          a0.x += g0 * t0; a0.y += g1 * t0; a0.z += g2 * t0; a0.w += g3 * t0;
+          a1.x += g0 * t1; a1.y += g1 * t1; a1.z += g2 * t1; a1.w += g3 * t1;
+          a2.x += g0; a2.y += g1; a2.z += g2; a2.w += g3;
+        }
+      }
+      if (RL > 1) {
+        red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2;
+        __syncthreads();
+        if (rl == 0) {
+          for (int o = 1; o < RL; ++o) {
+            const float4 b0 = red[0][o * W + ql], b1 = red[1][o * W + ql], b2 = red[2][o * W + ql];
+            a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+            a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+            a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+          }
+        }
+        __syncthreads();
+      }
+      if (rl == 0 && q < nq) {
+        const float v0[4] = {a0.x, a0.y, a0.z, a0.w}, v1[4] = {a1.x, a1.y, a1.z, a1.w}, v2[4] = {a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = 4 * q + u;
+          atomicAdd(dw + 2 * j, v0[u]); atomicAdd(dw + 2 * j + 1, v1[u]); atomicAdd(db + j, v2[u]);
+        }
+      }
     }
-    atomicAdd(dw + 2 * j, a0); atomicAdd(dw + 2 * j + 1, a1); atomicAdd(db + j, a2);
+  } else {
+    for (int j = threadIdx.x; j < d; j += 256) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int r = r0; r < r1; ++r) {
+        const float g = OpT<T>::to_f(dh[(size_t)r * ld + j]);
+        a0 += g * times[2 * r]; a1 += g * times[2 * r + 1]; a2 += g;
+      }
+      atomicAdd(dw + 2 * j, a0); atomicAdd(dw + 2 * j + 1, a1); atomicAdd(db + j, a2);
+    }
   }
   if (dt) {
     for (int r = r0 + wave; r < r1; r += 4) {
@@ -772,7 +817,7 @@ int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const
 int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const float* w, const void* dh, int ld,
                        float* dw, float* db, float* dt, void* stream) {
   if (!times || !w || !dh || !dw || !db || rows <= 0) return TIMHIP_EINVAL;
-  const int rpb = 32;
+  const int rpb = rows > 4096 ? 64 : 32;   // every block ends with 3*d memory-side atomics onto the same addresses
   dim3 grid((rows + rpb - 1) / rpb);
   DISPATCH_T(precision, hipLaunchKernelGGL(time_l1_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, times,
                                            rows, d, w, (const T*)dh, ld, dw, db, dt, rpb));

@@ -84,6 +84,13 @@ class Runtime:
     def zeros_op(self, rows, cols, dev):
         return torch.zeros((rows, _ru(cols)), dtype=self.op_dtype, device=dev)
 
+    def out_op(self, rows, cols, dev):
+        """operand buffer [rows, ru(cols)] that a kernel is about to fill completely in its first `cols` columns: only a
+        padded buffer (cols not a multiple of 64) needs the zero fill, for its padding columns"""
+        if cols % 64 == 0:
+            return torch.empty((rows, cols), dtype=self.op_dtype, device=dev)
+        return torch.zeros((rows, _ru(cols)), dtype=self.op_dtype, device=dev)
+
     def empty_op(self, rows, cols, dev):
         assert cols % 64 == 0
         return torch.empty((rows, cols), dtype=self.op_dtype, device=dev)
@@ -234,9 +241,9 @@ class TimeMlpFn(torch.autograd.Function):
         R = t2.shape[0]
         ldd = _ru(d)
         w0c, b0c, b2c, b4c, lnwc, lnbc = [_f32c(t) for t in (w0, b0, b2, b4, lnw, lnb)]
-        h1 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        h1 = rt.out_op(R, d, dev)
         call("timhip_time_l1_fwd", rt.prec, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(h1), ldd, _stream())
-        h2 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        h2 = rt.out_op(R, d, dev)
         rt.gemm(L.EPI_RELU_T, h1, rt.weight(w2), R, d, d, h2, ldd, bias=b2c)
         u3 = torch.empty((R, d), dtype=torch.float32, device=dev)
         rt.gemm(L.EPI_STORE_F32, h2, rt.weight(w4), R, d, d, u3, d, bias=b4c)
@@ -256,14 +263,21 @@ class TimeMlpFn(torch.autograd.Function):
         R, d = u3.shape
         ldd = _ru(d)
         g = _f32c(d_te).reshape(R, d)
-        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
-        dw0, db0, dw2, db2, dw4, db4, dlnw, dlnb = z(d, 2), z(d), z(d, d), z(d), z(d, d), z(d), z(d), z(d)
-        du3 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        # the eight (accumulated-into) gradient tensors as views of ONE zero-filled buffer
+        shapes = [(d, 2), (d,), (d, d), (d,), (d, d), (d,), (d,), (d,)]
+        sizes = [(int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for sh, n in zip(shapes, sizes):
+            views.append(flat[off:off + int(torch.Size(sh).numel())].view(sh))
+            off += n
+        dw0, db0, dw2, db2, dw4, db4, dlnw, dlnb = views
+        du3 = rt.out_op(R, d, dev)
         rt.ln_bwd(g, u3, stats, R, d, 1, _f32c(lnw), dyt=du3, dgamma=dlnw, dbeta=dlnb)
-        du2 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        du2 = rt.out_op(R, d, dev)
         rt.gemm(L.EPI_DRELU_T, du3, rt.weight(w4, True), R, d, d, du2, ldd, aux=h2, ldaux=ldd)
         rt.wgrad_many([(du3, d, h2, d, R, dw4, db4), (du2, d, h1, d, R, dw2, db2)])
-        du1 = torch.zeros((R, ldd), dtype=rt.op_dtype, device=dev)
+        du1 = rt.out_op(R, d, dev)
         rt.gemm(L.EPI_DRELU_T, du2, rt.weight(w2, True), R, d, d, du1, ldd, aux=h1, ldaux=ldd)
         d_times = torch.empty((R, 2), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         call("timhip_time_l1_bwd", rt.prec, ptr(t2), R, d, ptr(_f32c(w0)), ptr(du1), ldd, ptr(dw0), ptr(db0),
@@ -627,15 +641,17 @@ class EncoderFn(torch.autograd.Function):
         d_e = [None, None]
         for name, slot, *_ in ctx.emb_saved:
             d_e[slot] = torch.empty((B * nf, d), dtype=torch.float32, device=dev)
-        d_cls = torch.zeros((max(ncls, 1), d), dtype=torch.float32, device=dev)
-        d_mod = torch.zeros((max(nmod, 1), E), dtype=torch.float32, device=dev)
-        d_te = torch.zeros((B, T, d), dtype=torch.float32, device=dev)
+        cm = torch.zeros(max(ncls, 1) * d + max(nmod, 1) * E, dtype=torch.float32, device=dev)   # atomics accumulate into both
+        d_cls = cm[:max(ncls, 1) * d].view(max(ncls, 1), d)
+        d_mod = cm[max(ncls, 1) * d:].view(max(nmod, 1), E)
+        d_te = torch.empty((B, T, d), dtype=torch.float32, device=dev)   # written in full by the kernel
         call("timhip_assemble_bwd", ptr(plan.table(dev)), B, S, d, ptr(dx), nf, T, p_seq, seed, L.SITE_SEQ,
              ptr(d_e[0]), ptr(d_e[1]), ptr(d_cls), ptr(d_te), ptr(d_mod), st)
-        for i, n in enumerate(plan.cls_names):
-            G[fe + n].copy_(d_cls[i].view_as(G[fe + n]))
-        for i, n in enumerate(plan.mod_names):
-            G[fe + n].copy_(d_mod[i].view_as(G[fe + n]))
+        dst = [G[fe + n] for n in plan.cls_names] + [G[fe + n] for n in plan.mod_names]
+        src = [d_cls[i].view_as(G[fe + n]) for i, n in enumerate(plan.cls_names)] + \
+              [d_mod[i].view_as(G[fe + n]) for i, n in enumerate(plan.mod_names)]
+        if dst:
+            torch._foreach_copy_(dst, src)   # one launch for the handful of token / modality parameters
 
         # ---- embedders backward
         d_inputs = {"visual": None, "audio": None}
@@ -644,7 +660,7 @@ class EncoderFn(torch.autograd.Function):
         for name, slot, xT, u, stats, Cin, site in ctx.emb_saved:
             R = B * nf
             w = P[fe + name + "_embedder.1.weight"]
-            duT = torch.zeros((R, _ru(d)), dtype=rt.op_dtype, device=dev)
+            duT = rt.out_op(R, d, dev)
             rt.ln_bwd(d_e[slot], u, stats, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), dyt=duT,
                       dgamma=G[fe + name + "_embedder.3.weight"], dbeta=G[fe + name + "_embedder.3.bias"])
             emb_items.append((duT, d, xT, Cin, R, G[fe + name + "_embedder.1.weight"], G[fe + name + "_embedder.1.bias"]))
