@@ -149,6 +149,10 @@ typedef struct TimEpi {
   float p_drop;
   uint32_t site;   /* Philox stream id of the dropout site */
   uint64_t seed;
+  const void* mask; /* optional: the site's keep-bits drawn ahead of time (bit c%8 of byte [r*ldmask + c/8] = element (r,c)
+                       kept; what timhip_layer_fwd has LayerNorm-1 write for the FFN dropout).  NULL: drawn in the epilogue */
+  int32_t ldmask;   /* row stride of mask in bytes */
+  int32_t reserved;
 } TimEpi;
 
 /* C[M,N] = A[M,K] * B[N,K]^T through epilogue `epi` (TIMHIP_EPI_*).  A, B operand dtype,

@@ -53,7 +53,7 @@ class TimWgradItem(C.Structure):
 class TimEpi(C.Structure):
     _fields_ = [("out0", vp), ("out1", vp), ("bias", vp), ("res", vp), ("aux", vp),
                 ("ld0", i32), ("ld1", i32), ("ldres", i32), ("ldaux", i32),
-                ("p_drop", f32), ("site", u32), ("seed", u64)]
+                ("p_drop", f32), ("site", u32), ("seed", u64), ("mask", vp), ("ldmask", i32), ("reserved", i32)]
 
 
 _SIGS = {

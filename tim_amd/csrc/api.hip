@@ -6,7 +6,7 @@
 namespace {
 
 struct SavedLayout {
-  size_t qkv, o, lse, y1, st1, x1t, u, h, y2, st2, total;
+  size_t qkv, o, lse, y1, st1, x1t, u, h, y2, st2, ffn_mask, total;
 };
 
 SavedLayout saved_layout(const TimDesc& d) {
@@ -24,6 +24,7 @@ SavedLayout saved_layout(const TimDesc& d) {
   L.h = take(M * d.FF * ts);
   L.y2 = take(M * d.E * 4);
   L.st2 = take(M * 2 * 4);
+  L.ffn_mask = take(M * d.FF / 8);   // keep-bits of the FFN dropout (FF % 64 == 0): written by norm1, read by both FFN epilogues
   L.total = off;
   return L;
 }
@@ -112,6 +113,7 @@ TimEpi epi0() {
   TimEpi e;
   e.out0 = e.out1 = nullptr; e.bias = e.res = nullptr; e.aux = nullptr;
   e.ld0 = e.ld1 = e.ldres = e.ldaux = 0; e.p_drop = 0.f; e.site = 0; e.seed = 0;
+  e.mask = nullptr; e.ldmask = 0; e.reserved = 0;
   return e;
 }
 
@@ -222,12 +224,16 @@ int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_
   e.out0 = y1; e.ld0 = E; e.bias = w->out_b; e.res = x_in; e.ldres = E;
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP1);
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, E, M, E, E, e, 1, s))) return rc;
-  // 4. norm1
-  if ((rc = tim_layernorm_fwd(prec, y1, M, E, E, 0, w->n1_w, w->n1_b, x1, E, x1t, E, st1, s))) return rc;
+  // 4. norm1.  The kernel is HBM-bound with idle VALU: it also draws the keep-bits of the FFN dropout (same Philox
+  //    stream as the epilogues would use), which the linear1 epilogue and, in the backward, the gelu' epilogue read
+  uint8_t* fmask = d.p_drop > 0.f ? (uint8_t*)(sv + L.ffn_mask) : nullptr;
+  if ((rc = tim_layernorm_fwd(prec, y1, M, E, E, 0, w->n1_w, w->n1_b, x1, E, x1t, E, st1, s, fmask, FF, d.p_drop, d.seed,
+                              layer_site(d.layer, SITE_L_FFN)))) return rc;
   // 5. linear1 + GELU(erf) + dropout
   e = epi0();
   e.out0 = h; e.ld0 = FF; e.out1 = u; e.ld1 = FF; e.bias = w->l1_b;
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
+  e.mask = fmask; e.ldmask = FF / 8;
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_T2, x1t, E, w->l1_w, E, M, FF, E, e, 1, s))) return rc;
   // 6. linear2 + dropout2 + residual
   e = epi0();
@@ -288,6 +294,7 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
   TimEpi e = epi0();
   e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
+  e.mask = d.p_drop > 0.f ? (const uint8_t*)saved + saved_layout(d).ffn_mask : nullptr; e.ldmask = FF / 8;
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DGELU_T, df, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
   // dx1 = du W1 + dy2   (residual branch)
   e = epi0();

@@ -78,8 +78,10 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_7(uint64_t seed, uint32_t
   uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = site, c3 = 0x7149u;
 #pragma unroll
   for (int r = 0; r < PHILOX_ROUNDS; ++r) {
-    uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 64-bit product per multiplier: v_mad_u64_u32 yields the high and the low word together (separate mul_hi / mul_lo
+    // are two quarter-rate instructions; tools/px/philox_mad.hip: 590 -> 780 G Philox/s, same bits)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -115,6 +117,26 @@ __device__ __forceinline__ void drop_mask4(uint64_t seed, uint32_t site, uint64_
   m1 = r.y >= thr ? scale : 0.f;
   m2 = r.z >= thr ? scale : 0.f;
   m3 = r.w >= thr ? scale : 0.f;
+}
+
+// keep-bits of the 32 consecutive elements 4*q0 .. 4*q0+31 (bit i = element 4*q0 + i kept): the packed form of drop_mask4,
+// produced ahead of time by a memory-bound kernel with idle VALU (LayerNorm forward) for a GEMM epilogue that would
+// otherwise spend 15-18 us per launch drawing the same numbers while the matrix pipes wait
+__device__ __forceinline__ uint32_t drop_bits32(uint64_t seed, uint32_t site, uint64_t q0, uint32_t thr) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const Philox4 r = philox4x32_7(seed, site, q0 + j);
+    bits |= ((r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u)) << (4 * j);
+  }
+  return bits;
+}
+// factors of 4 consecutive elements from their keep-bits (low 4 bits of `nib`)
+__device__ __forceinline__ void drop_mask4_bits(uint32_t nib, float scale, float& m0, float& m1, float& m2, float& m3) {
+  m0 = (nib & 1u) ? scale : 0.f;
+  m1 = (nib & 2u) ? scale : 0.f;
+  m2 = (nib & 4u) ? scale : 0.f;
+  m3 = (nib & 8u) ? scale : 0.f;
 }
 
 // dropout site ids (stream id = site; per-layer sites add 16*layer)
@@ -262,9 +284,12 @@ size_t tim_wgrad_group_ws(const TimWgradItem* it, int n, int M);
 int tim_wgrad_group_splits(const TimWgradItem* it, int n, int M);
 int tim_wgrad_group_bf16(const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
+// mask_out != NULL: additionally writes the dropout keep-bits of a [rows, mask_cols] site (1 bit per element, row stride
+// mask_cols / 8 bytes, element index r * mask_cols + c as in the GEMM epilogues) - see drop_bits32
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,
-                      float* stats, hipStream_t s);
+                      float* stats, hipStream_t s, uint8_t* mask_out = nullptr, int mask_cols = 0, float mask_p = 0.f,
+                      uint64_t mask_seed = 0, uint32_t mask_site = 0);
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
                       const float* stats, int rows, int cols, int act, const float* w, float* dy_f32,
                       int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,

@@ -31,6 +31,7 @@ struct EpiDev {
   const float* bias; const float* res; const void* aux;
   int ld0, ld1, ldres, ldaux;
   uint32_t thr; float scale; uint32_t site; TimSeed seed;
+  const uint8_t* mask; int ldmask;   // precomputed keep-bits of the dropout site (row stride in bytes), or NULL: draw here
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
   int vec8; // the operand-dtype outputs / aux of this epilogue also allow 8-element (16-byte) accesses
   long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)
@@ -82,7 +83,10 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
   float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
     // element index m*N + n, N % 4 == 0 wherever dropout is applied
-    drop_mask4(e.seed, e.site, ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2, e.thr, e.scale, k0, k1, k2, k3);
+    if (e.mask)
+      drop_mask4_bits((uint32_t)e.mask[(size_t)m * e.ldmask + (n >> 3)] >> (n & 4), e.scale, k0, k1, k2, k3);
+    else
+      drop_mask4(e.seed, e.site, ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2, e.thr, e.scale, k0, k1, k2, k3);
   }
   if (e.vec && n + 3 < N) {
     size_t i0 = (size_t)m * e.ld0 + n;
@@ -173,12 +177,17 @@ __device__ __forceinline__ float4 epi_math4(float4 v, float4 a, float4 k) {
 // 8 consecutive columns n..n+7 of row m for the epilogues that write bf16: ONE 16-byte store (and 16-byte aux load)
 // per lane instead of two 8-byte ones.  Caller guarantees e.vec8 and n + 7 < N.
 template <int EPI>
-__device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, float4 lo, float4 hi) {
+__device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, float4 lo, float4 hi, uint32_t byte) {
   float4 klo = make_float4(1.f, 1.f, 1.f, 1.f), khi = klo;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
-    const uint64_t q = ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2;
-    drop_mask4(e.seed, e.site, q, e.thr, e.scale, klo.x, klo.y, klo.z, klo.w);
-    drop_mask4(e.seed, e.site, q + 1, e.thr, e.scale, khi.x, khi.y, khi.z, khi.w);
+    if (e.mask) {   // byte = e.mask[m * ldmask + n / 8], fetched by the caller ahead of the stores (n % 8 == 0 here)
+      drop_mask4_bits(byte, e.scale, klo.x, klo.y, klo.z, klo.w);
+      drop_mask4_bits(byte >> 4, e.scale, khi.x, khi.y, khi.z, khi.w);
+    } else {
+      const uint64_t q = ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2;
+      drop_mask4(e.seed, e.site, q, e.thr, e.scale, klo.x, klo.y, klo.z, klo.w);
+      drop_mask4(e.seed, e.site, q + 1, e.thr, e.scale, khi.x, khi.y, khi.z, khi.w);
+    }
   }
   const size_t i0 = (size_t)m * e.ld0 + n;
   if ((EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_RELU_T || EPI == TIMHIP_EPI_GELU_DROP_T2) && e.bias) {
@@ -288,6 +297,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
     for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // precomputed dropout keep-bits (e.mask): all of this lane's bytes are fetched here, ahead of the main loop - a load issued
+  // between the epilogue's stores could not be moved ahead of them (possible aliasing) and would cost a memory latency per chunk
+  constexpr int MB_COLS = TN * 32, NIT8 = 32 * (MB_COLS / 8) / 64;
+  uint32_t mbyte[TM][NIT8 > 0 ? NIT8 : 1];
+  if (epi_uses_dropout(EPI) && epi_has_oct(EPI) && e.vec8 && e.mask && e.thr != 0u) {
+    static_for<TM>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int it = 0; it < NIT8; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / (MB_COLS / 8), ch = idx % (MB_COLS / 8);
+        const int m = m0 + wm * (BM / WM) + j * 32 + row;
+        const int n = n0 + wn * (BN / WN) + ch * 8;
+        mbyte[j][it] = (m < M && n + 7 < N) ? (uint32_t)e.mask[(size_t)m * e.ldmask + (n >> 3)] : 0u;
+      }
+    });
+  }
 
   // fragment addresses: row = lane & 31, 16-B chunk = kk*2 + (lane >> 5), swizzled
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 8;
         if (m < M && n + 7 < N) {
-          epi_oct<EPI>(e, m, n, N, lo, hi);
+          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it]);
         } else if (m < M) {
           if (n < N) epi_quad<EPI, bf16_t>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
           if (n + 4 < N) epi_quad<EPI, bf16_t>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
@@ -773,6 +800,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   e.thr = te.p_drop > 0.f ? drop_threshold(te.p_drop) : 0u;
   e.scale = te.p_drop > 0.f ? 1.f / (1.f - te.p_drop) : 1.f;
   e.site = te.site; e.seed = te.seed;
+  e.mask = (const uint8_t*)te.mask; e.ldmask = te.ldmask;
   e.slab_stride = splitk > 1 ? (long long)M * te.ld0 : 0;
 
   bool vec = (e.ld0 % 4 == 0) && (((uintptr_t)e.out0 & 15) == 0);

@@ -234,10 +234,16 @@ template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ y, int rows, int cols, int ldy,
                                                      int act, const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ xf, int ldx,
-                                                     T* __restrict__ xt, int ldt, float* __restrict__ stats) {
+                                                     T* __restrict__ xt, int ldt, float* __restrict__ stats,
+                                                     uint32_t* __restrict__ mbits, int mwords, uint32_t mthr,
+                                                     TimSeed mseed, uint32_t msite) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (mbits) {   // dropout keep-bits for the GEMM that consumes this row (common.h: drop_bits32): VALU work under the row's loads
+    for (int wd = lane; wd < mwords; wd += 64)
+      mbits[(size_t)row * mwords + wd] = drop_bits32(mseed, msite, ((uint64_t)row * mwords + wd) * 8, mthr);
+  }
   const int nv = (cols + 255) >> 8;  // float4 slots per lane (cols % 4 == 0)
   float4 v[LN_MAXV];
   float s = 0.f;
@@ -655,12 +661,20 @@ int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float
 }
 
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w,
-                      const float* b, float* xf, int ldx, void* xt, int ldt, float* stats, hipStream_t s) {
+                      const float* b, float* xf, int ldx, void* xt, int ldt, float* stats, hipStream_t s,
+                      uint8_t* mask_out, int mask_cols, float mask_p, uint64_t mask_seed, uint32_t mask_site) {
   if (!y || !w || !b || rows <= 0) return TIMHIP_EINVAL;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || (xf && ldx % 4) || (xt && ldt % 4)) return TIMHIP_EUNSUPPORTED;
   dim3 grid((rows + 3) / 4);
+  uint32_t* mbits = nullptr;
+  int mwords = 0;
+  uint32_t mthr = 0u;
+  if (mask_out && mask_p > 0.f) {
+    if (mask_cols % 32 || ((uintptr_t)mask_out & 3)) return TIMHIP_EUNSUPPORTED;
+    mbits = (uint32_t*)mask_out; mwords = mask_cols / 32; mthr = drop_threshold(mask_p);
+  }
 #define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, dim3(256), 0, s, y, rows, cols, ldy, act, w, b, \
-                                   xf, ldx, (T*)xt, ldt, stats)
+                                   xf, ldx, (T*)xt, ldt, stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site)
   const int nv = (cols + 255) / 256;
   DISPATCH_T(precision, if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 4) LN_FWD(4); else LN_FWD(8));
 #undef LN_FWD

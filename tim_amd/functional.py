@@ -157,11 +157,11 @@ class Runtime:
 
     # ---- thin op wrappers ------------------------------------------------------------------------
     def gemm(self, epi, A, B, M, N, K, out0, ld0, out1=None, ld1=0, bias=None, res=None, ldres=0, aux=None,
-             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1):
+             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0):
         if M == 0 or N == 0:
             return
         e = L.TimEpi(ptr(out0), ptr(out1), ptr(bias), ptr(res), ptr(aux), ld0, ld1, ldres, ldaux,
-                     float(p_drop), site, seed)
+                     float(p_drop), site, seed, ptr(mask), ldmask, 0)
         call("timhip_gemm_nt", self.prec, epi, ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K,
              C.byref(e), splitk, _stream())
 
