@@ -79,7 +79,8 @@ constexpr bool epi_uses_dropout(int EPI) {
 // 4 consecutive columns n..n+3 of row m
 template <int EPI, typename T>
 __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, float v0, float v1,
-                                         float v2, float v3) {
+                                         float v2, float v3, bool has_pre = false,
+                                         float4 pre = make_float4(0.f, 0.f, 0.f, 0.f)) {
   float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
     // element index m*N + n, N % 4 == 0 wherever dropout is applied
@@ -105,11 +106,13 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
       store4<T>((T*)e.out1 + (size_t)m * e.ld1 + n, v0, v1, v2, v3);
       store4<T>((T*)e.out0 + i0, gelu_f(v0) * k0, gelu_f(v1) * k1, gelu_f(v2) * k2, gelu_f(v3) * k3);
     } else if (EPI == TIMHIP_EPI_DROP_RES_F32) {
-      float4 r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+      float4 r = pre;   // fetched by the caller ahead of the stores, or here
+      if (!has_pre) r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
       store4<float>((float*)e.out0 + i0, r.x + v0 * k0, r.y + v1 * k1, r.z + v2 * k2, r.w + v3 * k3);
     } else if (EPI == TIMHIP_EPI_ADD_F32) {
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e.res) r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+      if (has_pre) r = pre;
+      else if (e.res) r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
       store4<float>((float*)e.out0 + i0, r.x + v0, r.y + v1, r.z + v2, r.w + v3);
     } else if (EPI == TIMHIP_EPI_DGELU_T) {
       float u0, u1, u2, u3;
@@ -177,7 +180,8 @@ __device__ __forceinline__ float4 epi_math4(float4 v, float4 a, float4 k) {
 // 8 consecutive columns n..n+7 of row m for the epilogues that write bf16: ONE 16-byte store (and 16-byte aux load)
 // per lane instead of two 8-byte ones.  Caller guarantees e.vec8 and n + 7 < N.
 template <int EPI>
-__device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, float4 lo, float4 hi, uint32_t byte) {
+__device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, float4 lo, float4 hi, uint32_t byte,
+                                        bool has_pre = false, bf16x8_t pre = bf16x8_t{}) {
   float4 klo = make_float4(1.f, 1.f, 1.f, 1.f), khi = klo;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
     if (e.mask) {   // byte = e.mask[m * ldmask + n / 8], fetched by the caller ahead of the stores (n % 8 == 0 here)
@@ -196,7 +200,8 @@ __device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, fl
   }
   float4 alo = make_float4(0.f, 0.f, 0.f, 0.f), ahi = alo;
   if (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T) {
-    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)e.aux + (size_t)m * e.ldaux + n);
+    bf16x8_t a = pre;
+    if (!has_pre) a = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)e.aux + (size_t)m * e.ldaux + n);
     alo = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
     ahi = make_float4((float)a[4], (float)a[5], (float)a[6], (float)a[7]);
   }
@@ -412,8 +417,49 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   }
   __syncthreads();  // every wave is done with the main-loop tiles
   float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
+  // Operands the epilogue READS per output chunk (fp32 residual; bf16 pre-activations for gelu' / relu') are fetched one
+  // row block ahead, into registers, BEFORE the stores of the current row block: a load placed after a store cannot be
+  // moved ahead of it by the compiler (possible aliasing), so without this every chunk paid a full memory latency.
+  constexpr bool PRE_RES = (EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_ADD_F32) && !(epi_has_oct(EPI));
+  constexpr bool PRE_AUX = (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T);
+  constexpr int NITQ = 32 * CPR / 64, NITO = 32 * (EP_COLS / 8) / 64;
+  float4 rbuf[2][PRE_RES ? NITQ : 1];
+  bf16x8_t abuf[2][PRE_AUX ? (NITO > 0 ? NITO : 1) : 1];
+  const bool pre_res = PRE_RES && e.vec && e.res != nullptr;
+  const bool pre_aux = PRE_AUX && e.vec8;
+  auto fetch = [&](auto jc, auto slotc) {
+    constexpr int j = decltype(jc)::value, slot = decltype(slotc)::value;
+    if constexpr (PRE_RES) {
+      if (pre_res) {
+#pragma unroll
+        for (int it = 0; it < NITQ; ++it) {
+          const int idx = it * 64 + lane;
+          const int row = idx / CPR, ch = idx % CPR;
+          const int m = m0 + wm * (BM / WM) + j * 32 + row;
+          const int n = n0 + wn * (BN / WN) + ch * 4;
+          rbuf[slot][it] = (m < M && n + 3 < N) ? *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+    if constexpr (PRE_AUX) {
+      if (pre_aux) {
+#pragma unroll
+        for (int it = 0; it < NITO; ++it) {
+          const int idx = it * 64 + lane;
+          const int row = idx / (EP_COLS / 8), ch = idx % (EP_COLS / 8);
+          const int m = m0 + wm * (BM / WM) + j * 32 + row;
+          const int n = n0 + wn * (BN / WN) + ch * 8;
+          if (m < M && n + 7 < N)
+            abuf[slot][it] = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)e.aux + (size_t)m * e.ldaux + n);
+        }
+      }
+    }
+  };
+  fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   static_for<TM>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
+    if constexpr (j + 1 < TM) fetch(std::integral_constant<int, j + 1>{}, std::integral_constant<int, (j + 1) & 1>{});
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -432,7 +478,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 8;
         if (m < M && n + 7 < N) {
-          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it]);
+          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j & 1][PRE_AUX ? it : 0]);
         } else if (m < M) {
           if (n < N) epi_quad<EPI, bf16_t>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
           if (n + 4 < N) epi_quad<EPI, bf16_t>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
@@ -446,7 +492,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 4;
-        if (m < M && n < N) epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w);
+        if (m < M && n < N)
+          epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j & 1][PRE_RES ? it : 0]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block of rows overwrites
