@@ -423,8 +423,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   constexpr bool PRE_RES = (EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_ADD_F32) && !(epi_has_oct(EPI));
   constexpr bool PRE_AUX = (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T);
   constexpr int NITQ = 32 * CPR / 64, NITO = 32 * (EP_COLS / 8) / 64;
-  float4 rbuf[2][PRE_RES ? NITQ : 1];
-  bf16x8_t abuf[2][PRE_AUX ? (NITO > 0 ? NITO : 1) : 1];
+  constexpr int PD = TM <= 5 ? TM : 2;   // row blocks in flight: all of the tile's (<= 5: 80 VGPRs of fp32 residual), else 2
+  float4 rbuf[PD][PRE_RES ? NITQ : 1];
+  bf16x8_t abuf[PD][PRE_AUX ? (NITO > 0 ? NITO : 1) : 1];
   const bool pre_res = PRE_RES && e.vec && e.res != nullptr;
   const bool pre_aux = PRE_AUX && e.vec8;
   auto fetch = [&](auto jc, auto slotc) {
@@ -456,10 +457,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
       }
     }
   };
-  fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  static_for<PD - 1>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    fetch(std::integral_constant<int, j>{}, std::integral_constant<int, j % PD>{});
+  });
   static_for<TM>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    if constexpr (j + 1 < TM) fetch(std::integral_constant<int, j + 1>{}, std::integral_constant<int, (j + 1) & 1>{});
+    if constexpr (j + PD - 1 < TM)
+      fetch(std::integral_constant<int, j + PD - 1>{}, std::integral_constant<int, (j + PD - 1) % PD>{});
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 8;
         if (m < M && n + 7 < N) {
-          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j & 1][PRE_AUX ? it : 0]);
+          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j % PD][PRE_AUX ? it : 0]);
         } else if (m < M) {
           if (n < N) epi_quad<EPI, bf16_t>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
           if (n + 4 < N) epi_quad<EPI, bf16_t>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 4;
         if (m < M && n < N)
-          epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j & 1][PRE_RES ? it : 0]);
+          epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PD][PRE_RES ? it : 0]);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block of rows overwrites
