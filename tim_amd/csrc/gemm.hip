@@ -80,7 +80,8 @@ constexpr bool epi_uses_dropout(int EPI) {
 template <int EPI, typename T>
 __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, float v0, float v1,
                                          float v2, float v3, bool has_pre = false,
-                                         float4 pre = make_float4(0.f, 0.f, 0.f, 0.f)) {
+                                         float4 pre = make_float4(0.f, 0.f, 0.f, 0.f), bool has_b = false,
+                                         float4 pb = make_float4(0.f, 0.f, 0.f, 0.f)) {
   float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
     // element index m*N + n, N % 4 == 0 wherever dropout is applied
@@ -93,7 +94,8 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
     size_t i0 = (size_t)m * e.ld0 + n;
     if (EPI != TIMHIP_EPI_ADD_F32 && EPI != TIMHIP_EPI_DGELU_T && EPI != TIMHIP_EPI_DRELU_T &&
         EPI != TIMHIP_EPI_ATOMIC_F32 && EPI != TIMHIP_EPI_DRELU_F32IN_T && e.bias) {
-      float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+      float4 b = pb;   // this lane's bias columns are the same for every row: fetched once by the caller, or here
+      if (!has_b) b = *reinterpret_cast<const float4*>(e.bias + n);
       v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
     }
     if (EPI == TIMHIP_EPI_STORE_T) {
@@ -181,7 +183,9 @@ __device__ __forceinline__ float4 epi_math4(float4 v, float4 a, float4 k) {
 // per lane instead of two 8-byte ones.  Caller guarantees e.vec8 and n + 7 < N.
 template <int EPI>
 __device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, float4 lo, float4 hi, uint32_t byte,
-                                        bool has_pre = false, bf16x8_t pre = bf16x8_t{}) {
+                                        bool has_pre = false, bf16x8_t pre = bf16x8_t{}, bool has_b = false,
+                                        float4 pb0 = make_float4(0.f, 0.f, 0.f, 0.f),
+                                        float4 pb1 = make_float4(0.f, 0.f, 0.f, 0.f)) {
   float4 klo = make_float4(1.f, 1.f, 1.f, 1.f), khi = klo;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
     if (e.mask) {   // byte = e.mask[m * ldmask + n / 8], fetched by the caller ahead of the stores (n % 8 == 0 here)
@@ -195,7 +199,8 @@ __device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, fl
   }
   const size_t i0 = (size_t)m * e.ld0 + n;
   if ((EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_RELU_T || EPI == TIMHIP_EPI_GELU_DROP_T2) && e.bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(e.bias + n), b1 = *reinterpret_cast<const float4*>(e.bias + n + 4);
+    float4 b0 = pb0, b1 = pb1;
+    if (!has_b) { b0 = *reinterpret_cast<const float4*>(e.bias + n); b1 = *reinterpret_cast<const float4*>(e.bias + n + 4); }
     lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w; hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
   }
   float4 alo = make_float4(0.f, 0.f, 0.f, 0.f), ahi = alo;
@@ -457,6 +462,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
       }
     }
   };
+  // bias: a lane's output columns are the same in every row chunk it handles (64 lanes cover whole rows of the 32- or
+  // 64-column wave tile), so its bias values are fetched once
+  float4 bias8[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, bias4 = bias8[0];
+  bool pre_b8 = false, pre_b4 = false;
+  if (e.bias && e.vec) {
+    if constexpr (64 % (EP_COLS / 8) == 0) {
+      const int n = n0 + wn * (BN / WN) + (lane % (EP_COLS / 8)) * 8;
+      if (epi_has_oct(EPI) && e.vec8 && n + 7 < N) {
+        bias8[0] = *reinterpret_cast<const float4*>(e.bias + n);
+        bias8[1] = *reinterpret_cast<const float4*>(e.bias + n + 4);
+        pre_b8 = true;
+      }
+    }
+    if constexpr (64 % CPR == 0) {
+      const int n = n0 + wn * (BN / WN) + (lane % CPR) * 4;
+      if (n + 3 < N) { bias4 = *reinterpret_cast<const float4*>(e.bias + n); pre_b4 = true; }
+    }
+  }
   static_for<PD - 1>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     fetch(std::integral_constant<int, j>{}, std::integral_constant<int, j % PD>{});
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 8;
         if (m < M && n + 7 < N) {
-          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j % PD][PRE_AUX ? it : 0]);
+          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j % PD][PRE_AUX ? it : 0], pre_b8, bias8[0], bias8[1]);
         } else if (m < M) {
           if (n < N) epi_quad<EPI, bf16_t>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
           if (n + 4 < N) epi_quad<EPI, bf16_t>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
@@ -498,7 +521,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 4;
         if (m < M && n < N)
-          epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PD][PRE_RES ? it : 0]);
+          epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PD][PRE_RES ? it : 0],
+                                pre_b4 && n + 3 < N, bias4);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block of rows overwrites
