@@ -10,7 +10,14 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests a
 import collections, csv, glob, json, sys
 root, out = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: {"fetch_kib": 0.0, "write_kib": 0.0, "n_f": 0, "n_w": 0})
-def fam(name):
+def fam(name, row=None):
+    # the encoder layers' launches only: their NT GEMMs run the 160 x 128 tile, their grouped weight gradient is the
+    # 512-block grid; the front end / heads use the same kernels on small problems and are kept apart
+    if "gemm_nt_bf16_kernel" in name:
+        return "gemm_nt_bf16_kernel" if "160, 128" in name or "ELi160ELi128" in name else "gemm_nt_bf16_kernel(small tiles)"
+    if "wgrad_group_kernel" in name and row is not None:
+        g = int(float(row.get("Grid_Size", row.get("Grid_Size_X", 0)) or 0))
+        return "wgrad_group_kernel" if g == 512 * 256 else "wgrad_group_kernel(small)"
     for k in ("gemm_nt_bf16_kernel", "wgrad_group_kernel", "wgrad_tn_bf16_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "ln_fwd_kernel",
               "ln_bwd_kernel", "wgrad_reduce_kernel", "cast_weights_kernel", "attn_bwd_rows", "attn_bwd_keys"):
         if k in name:
@@ -19,7 +26,7 @@ def fam(name):
 for sub, key, cnt in (("f", "fetch_kib", "n_f"), ("w", "write_kib", "n_w")):
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (root, sub), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = fam(r["Kernel_Name"])
+            k = fam(r["Kernel_Name"], r)
             if k and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[k][key] += float(r["Counter_Value"]); acc[k][cnt] += 1
 res = {}
