@@ -117,11 +117,24 @@ class TIM(_TIMBase):
         dev = feature_times.device
         Bsz = feature_times.shape[0]
 
+        def on_dev(name):
+            # the query pyramids are plain CPU tensors in the reference (moved on every call, det tim.py:296-300); here each is
+            # copied to the device once - no per-step host-to-device copy, and the forward stays capturable in a HIP graph
+            cache = self.__dict__.setdefault("_pyramid_dev", {})
+            t = cache.get((name, dev))
+            if t is None:
+                t = getattr(self, name).to(device=dev)
+                cache[(name, dev)] = t
+            return t
+
         def draw():
             if train:
-                sel = torch.randperm(self.train_pool.shape[1])[:self.num_queries]
-                return self.train_pool[:, sel.long()].repeat(Bsz, 1, 1).to(device=dev)
-            return self.inference_queries.repeat(Bsz, 1, 1).to(device=dev)
+                if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    sel = torch.randperm(self.train_pool.shape[1], device=dev)[:self.num_queries]   # graph-safe generator
+                else:
+                    sel = torch.randperm(self.train_pool.shape[1])[:self.num_queries].to(dev)     # the reference's CPU draw
+                return on_dev("train_pool")[:, sel.long()].repeat(Bsz, 1, 1)
+            return on_dev("inference_queries").repeat(Bsz, 1, 1)
 
         if "visual" in self.data_modality:
             v_queries = draw()
