@@ -153,6 +153,12 @@ typedef struct TimEpi {
                        kept; what timhip_layer_fwd has LayerNorm-1 write for the FFN dropout).  NULL: drawn in the epilogue */
   int32_t ldmask;   /* row stride of mask in bytes */
   int32_t reserved;
+  /* TIMHIP_EPI_DROP_RES_F32 only, optional: the residual is LayerNorm(res).  res then holds the PRE-norm fp32 rows, ln_stats
+   * the (mean, rstd) pair of every row as timhip_layernorm_fwd writes them, ln_w / ln_b the affine parameters; the epilogue
+   * normalises what it reads, so the normalised fp32 rows need not exist in memory.  NULL: res is used as it is. */
+  const float* ln_stats;
+  const float* ln_w;
+  const float* ln_b;
 } TimEpi;
 
 /* C[M,N] = A[M,K] * B[N,K]^T through epilogue `epi` (TIMHIP_EPI_*).  A, B operand dtype,
@@ -243,10 +249,19 @@ int timhip_dropout_salt(const unsigned long long* dev_salt);
 
 /* ---------------------------------------------------------------- stages ---- */
 /* One post-norm encoder layer.  x_in (fp32 [M,E]) and x_in_T (T [M,E]) are the layer input,
- * x_out / x_out_T the output.  `saved` (timhip_layer_saved_bytes) is read back by the backward. */
+ * x_out / x_out_T the output.  `saved` (timhip_layer_saved_bytes) is read back by the backward.
+ * x_out may be NULL when nobody reads the fp32 output rows (the next layer then runs timhip_layer_fwd_chained).
+ * workspace / workspace_bytes are not used any more (kept for binary compatibility). */
 int timhip_layer_fwd(const TimDesc* d, const TimLayerParams* w, const float* x_in,
                      const void* x_in_T, float* x_out, void* x_out_T, void* saved, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same for a layer that follows another one of the same shape: its fp32 input rows are not read from memory but
+ * recomputed where they are needed (the residual of the out-projection epilogue) as LayerNorm-2 of the previous layer's
+ * pre-norm rows, taken from prev_saved with prev_w's norm2 parameters; x_in_T is still the previous layer's x_out_T.
+ * Together with x_out = NULL on the inner layers the fp32 stream between layers never exists in memory. */
+int timhip_layer_fwd_chained(const TimDesc* d, const TimLayerParams* w, const TimLayerParams* prev_w,
+                             const void* prev_saved, const void* x_in_T, float* x_out, void* x_out_T, void* saved,
+                             void* stream);
 /* dx_out: gradient w.r.t. the layer output (fp32 [M,E], clobbered).  dx_in: gradient w.r.t. the
  * layer input (fp32 [M,E]).  Parameter gradients are accumulated (+=) into *g. */
 int timhip_layer_bwd(const TimDesc* d, const TimLayerParams* w, const void* x_in_T,

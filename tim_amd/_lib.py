@@ -53,7 +53,8 @@ class TimWgradItem(C.Structure):
 class TimEpi(C.Structure):
     _fields_ = [("out0", vp), ("out1", vp), ("bias", vp), ("res", vp), ("aux", vp),
                 ("ld0", i32), ("ld1", i32), ("ldres", i32), ("ldaux", i32),
-                ("p_drop", f32), ("site", u32), ("seed", u64), ("mask", vp), ("ldmask", i32), ("reserved", i32)]
+                ("p_drop", f32), ("site", u32), ("seed", u64), ("mask", vp), ("ldmask", i32), ("reserved", i32),
+                ("ln_stats", vp), ("ln_w", vp), ("ln_b", vp)]
 
 
 _SIGS = {
@@ -84,6 +85,8 @@ _SIGS = {
     "timhip_dropout_mask": (C.c_int, [u64, u32, f32, i32, i32, vp, vp]),
     "timhip_dropout_salt": (C.c_int, [vp]),
     "timhip_layer_fwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp, vp, vp, sz, vp]),
+    "timhip_layer_fwd_chained": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), C.POINTER(TimLayerParams), vp, vp, vp,
+                                           vp, vp, vp]),
     "timhip_layer_bwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp,
                                    C.POINTER(TimLayerGrads), vp, sz, vp]),
     "timhip_layer_dy_bytes": (sz, [C.POINTER(TimDesc)]),

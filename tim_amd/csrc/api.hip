@@ -114,6 +114,7 @@ TimEpi epi0() {
   e.out0 = e.out1 = nullptr; e.bias = e.res = nullptr; e.aux = nullptr;
   e.ld0 = e.ld1 = e.ldres = e.ldaux = 0; e.p_drop = 0.f; e.site = 0; e.seed = 0;
   e.mask = nullptr; e.ldmask = 0; e.reserved = 0;
+  e.ln_stats = e.ln_w = e.ln_b = nullptr;
   return e;
 }
 
@@ -197,21 +198,20 @@ int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X
   return wgrad(precision, dY, ldy, Nout, X, ldx, Kout, M, dW, db, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_in, const void* x_in_T, float* x_out,
-                     void* x_out_T, void* saved, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!dp || !w || !x_in || !x_in_T || !x_out || !x_out_T || !saved || !workspace) return TIMHIP_EINVAL;
-  const TimDesc& d = *dp;
-  int rc = check_layer_desc(d);
-  if (rc) return rc;
+// The fp32 residual stream is only ever READ by the "+ residual" epilogues, and each of them can normalise on the fly
+// (TimEpi.ln_*): a layer's input rows are LayerNorm-2 of the previous layer's y2, its inner residual LayerNorm-1 of its own
+// y1.  So the normalised fp32 rows are written only where someone else needs them (x_out of the last layer -> feats);
+// LayerNorm writes its bf16 operand copy and the statistics, 60 instead of 100 MB per launch.
+static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float* x_in, const float* x_in_prenorm,
+                          const float* x_in_stats, const float* x_in_lnw, const float* x_in_lnb, const void* x_in_T,
+                          float* x_out, void* x_out_T, void* saved, hipStream_t s) {
+  int rc;
   const int M = d.B * d.S, E = d.E, FF = d.FF, prec = d.precision;
-  if (workspace_bytes < (size_t)M * E * 4) return TIMHIP_EWORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
   const SavedLayout L = saved_layout(d);
   char* sv = (char*)saved;
   void* qkv = sv + L.qkv; void* o = sv + L.o; float* lse = (float*)(sv + L.lse);
   float* y1 = (float*)(sv + L.y1); float* st1 = (float*)(sv + L.st1); void* x1t = sv + L.x1t;
   void* u = sv + L.u; void* h = sv + L.h; float* y2 = (float*)(sv + L.y2); float* st2 = (float*)(sv + L.st2);
-  float* x1 = (float*)workspace;
 
   // 1. packed in-projection (F._in_projection_packed)
   TimEpi e = epi0();
@@ -221,13 +221,18 @@ int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_
   if ((rc = tim_attention_fwd(d, qkv, o, lse, s))) return rc;
   // 3. out-projection + dropout1 + residual
   e = epi0();
-  e.out0 = y1; e.ld0 = E; e.bias = w->out_b; e.res = x_in; e.ldres = E;
+  e.out0 = y1; e.ld0 = E; e.bias = w->out_b; e.ldres = E;
+  if (x_in) {
+    e.res = x_in;
+  } else {   // the input rows as LayerNorm-2 of the previous layer's y2
+    e.res = x_in_prenorm; e.ln_stats = x_in_stats; e.ln_w = x_in_lnw; e.ln_b = x_in_lnb;
+  }
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP1);
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, E, M, E, E, e, 1, s))) return rc;
   // 4. norm1.  The kernel is HBM-bound with idle VALU: it also draws the keep-bits of the FFN dropout (same Philox
   //    stream as the epilogues would use), which the linear1 epilogue and, in the backward, the gelu' epilogue read
   uint8_t* fmask = d.p_drop > 0.f ? (uint8_t*)(sv + L.ffn_mask) : nullptr;
-  if ((rc = tim_layernorm_fwd(prec, y1, M, E, E, 0, w->n1_w, w->n1_b, x1, E, x1t, E, st1, s, fmask, FF, d.p_drop, d.seed,
+  if ((rc = tim_layernorm_fwd(prec, y1, M, E, E, 0, w->n1_w, w->n1_b, nullptr, 0, x1t, E, st1, s, fmask, FF, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_FFN)))) return rc;
   // 5. linear1 + GELU(erf) + dropout
   e = epi0();
@@ -237,11 +242,32 @@ int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_T2, x1t, E, w->l1_w, E, M, FF, E, e, 1, s))) return rc;
   // 6. linear2 + dropout2 + residual
   e = epi0();
-  e.out0 = y2; e.ld0 = E; e.bias = w->l2_b; e.res = x1; e.ldres = E;
+  e.out0 = y2; e.ld0 = E; e.bias = w->l2_b; e.ldres = E;
+  e.res = y1; e.ln_stats = st1; e.ln_w = w->n1_w; e.ln_b = w->n1_b;   // residual = norm1(y1), normalised by the epilogue
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP2);
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, FF, M, E, FF, e, 1, s))) return rc;
-  // 7. norm2
+  // 7. norm2 (x_out == NULL: only the operand copy and the statistics)
   return tim_layernorm_fwd(prec, y2, M, E, E, 0, w->n2_w, w->n2_b, x_out, E, x_out_T, E, st2, s);
+}
+
+int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_in, const void* x_in_T, float* x_out,
+                     void* x_out_T, void* saved, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;   // kept in the signature: earlier versions staged norm1's fp32 rows there
+  if (!dp || !w || !x_in || !x_in_T || !x_out_T || !saved) return TIMHIP_EINVAL;
+  int rc = check_layer_desc(*dp);
+  if (rc) return rc;
+  return layer_fwd_impl(*dp, w, x_in, nullptr, nullptr, nullptr, nullptr, x_in_T, x_out, x_out_T, saved, (hipStream_t)stream);
+}
+
+int timhip_layer_fwd_chained(const TimDesc* dp, const TimLayerParams* w, const TimLayerParams* prev_w, const void* prev_saved,
+                             const void* x_in_T, float* x_out, void* x_out_T, void* saved, void* stream) {
+  if (!dp || !w || !prev_w || !prev_saved || !x_in_T || !x_out_T || !saved) return TIMHIP_EINVAL;
+  int rc = check_layer_desc(*dp);
+  if (rc) return rc;
+  const SavedLayout L = saved_layout(*dp);   // the previous layer has the same shape
+  const char* ps = (const char*)prev_saved;
+  return layer_fwd_impl(*dp, w, nullptr, (const float*)(ps + L.y2), (const float*)(ps + L.st2), prev_w->n2_w, prev_w->n2_b,
+                        x_in_T, x_out, x_out_T, saved, (hipStream_t)stream);
 }
 
 // gradient operands handed from the data chain to the weight-gradient part: df[M,E] | du[M,FF] | da[M,E] | dqkv[M,3E]

@@ -32,6 +32,9 @@ struct EpiDev {
   int ld0, ld1, ldres, ldaux;
   uint32_t thr; float scale; uint32_t site; TimSeed seed;
   const uint8_t* mask; int ldmask;   // precomputed keep-bits of the dropout site (row stride in bytes), or NULL: draw here
+  // DROP_RES_F32 only: the residual is LayerNorm(res) - res holds the PRE-norm rows, ln_stats their (mean, rstd) pairs, ln_w /
+  // ln_b the affine parameters - so the normalised fp32 rows never have to exist in memory (NULL: res is used as it is)
+  const float* ln_stats; const float* ln_w; const float* ln_b;
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
   int vec8; // the operand-dtype outputs / aux of this epilogue also allow 8-element (16-byte) accesses
   long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)
@@ -53,7 +56,9 @@ __device__ __forceinline__ void epi_one(const EpiDev& e, int m, int n, int N, fl
     ((T*)e.out1)[(size_t)m * e.ld1 + n] = OpT<T>::from_f(v);
     ((T*)e.out0)[i0] = OpT<T>::from_f(gelu_f(v) * mask);
   } else if (EPI == TIMHIP_EPI_DROP_RES_F32) {
-    ((float*)e.out0)[i0] = e.res[(size_t)m * e.ldres + n] + v * mask;
+    float r = e.res[(size_t)m * e.ldres + n];
+    if (e.ln_stats) r = (r - e.ln_stats[2 * m]) * e.ln_stats[2 * m + 1] * e.ln_w[n] + e.ln_b[n];
+    ((float*)e.out0)[i0] = r + v * mask;
   } else if (EPI == TIMHIP_EPI_ADD_F32) {
     ((float*)e.out0)[i0] = v + (e.res ? e.res[(size_t)m * e.ldres + n] : 0.f);
   } else if (EPI == TIMHIP_EPI_DGELU_T) {
@@ -81,7 +86,10 @@ template <int EPI, typename T>
 __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, float v0, float v1,
                                          float v2, float v3, bool has_pre = false,
                                          float4 pre = make_float4(0.f, 0.f, 0.f, 0.f), bool has_b = false,
-                                         float4 pb = make_float4(0.f, 0.f, 0.f, 0.f)) {
+                                         float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), bool has_ln = false,
+                                         float2 pst = make_float2(0.f, 1.f),
+                                         float4 pg = make_float4(1.f, 1.f, 1.f, 1.f),
+                                         float4 pbe = make_float4(0.f, 0.f, 0.f, 0.f)) {
   float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
     // element index m*N + n, N % 4 == 0 wherever dropout is applied
@@ -110,6 +118,17 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
     } else if (EPI == TIMHIP_EPI_DROP_RES_F32) {
       float4 r = pre;   // fetched by the caller ahead of the stores, or here
       if (!has_pre) r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+      if (e.ln_stats) {   // residual = LayerNorm of the fetched pre-norm values
+        float2 st = pst;
+        float4 g = pg, be = pbe;
+        if (!has_ln) {
+          st = *reinterpret_cast<const float2*>(e.ln_stats + 2 * (size_t)m);
+          g = *reinterpret_cast<const float4*>(e.ln_w + n);
+          be = *reinterpret_cast<const float4*>(e.ln_b + n);
+        }
+        r.x = (r.x - st.x) * st.y * g.x + be.x; r.y = (r.y - st.x) * st.y * g.y + be.y;
+        r.z = (r.z - st.x) * st.y * g.z + be.z; r.w = (r.w - st.x) * st.y * g.w + be.w;
+      }
       store4<float>((float*)e.out0 + i0, r.x + v0 * k0, r.y + v1 * k1, r.z + v2 * k2, r.w + v3 * k3);
     } else if (EPI == TIMHIP_EPI_ADD_F32) {
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -430,6 +449,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   constexpr int NITQ = 32 * CPR / 64, NITO = 32 * (EP_COLS / 8) / 64;
   constexpr int PD = TM <= 5 ? TM : 2;   // row blocks in flight: all of the tile's (<= 5: 80 VGPRs of fp32 residual), else 2
   float4 rbuf[PD][PRE_RES ? NITQ : 1];
+  float2 sbuf[PD][PRE_RES ? NITQ : 1];   // (mean, rstd) of the rows in rbuf when the residual is LayerNorm(res)
+  const bool pre_ln = PRE_RES && EPI == TIMHIP_EPI_DROP_RES_F32 && e.vec && e.res != nullptr && e.ln_stats != nullptr;
   bf16x8_t abuf[PD][PRE_AUX ? (NITO > 0 ? NITO : 1) : 1];
   const bool pre_res = PRE_RES && e.vec && e.res != nullptr;
   const bool pre_aux = PRE_AUX && e.vec8;
@@ -445,6 +466,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
           const int n = n0 + wn * (BN / WN) + ch * 4;
           rbuf[slot][it] = (m < M && n + 3 < N) ? *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n)
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pre_ln) sbuf[slot][it] = m < M ? *reinterpret_cast<const float2*>(e.ln_stats + 2 * (size_t)m) : make_float2(0.f, 1.f);
         }
       }
     }
@@ -478,6 +500,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
     if constexpr (64 % CPR == 0) {
       const int n = n0 + wn * (BN / WN) + (lane % CPR) * 4;
       if (n + 3 < N) { bias4 = *reinterpret_cast<const float4*>(e.bias + n); pre_b4 = true; }
+    }
+  }
+  float4 lng = make_float4(1.f, 1.f, 1.f, 1.f), lnb = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool pre_gb = false;
+  if constexpr (64 % CPR == 0) {
+    if (pre_ln) {
+      const int n = n0 + wn * (BN / WN) + (lane % CPR) * 4;
+      if (n + 3 < N) {
+        lng = *reinterpret_cast<const float4*>(e.ln_w + n);
+        lnb = *reinterpret_cast<const float4*>(e.ln_b + n);
+        pre_gb = true;
+      }
     }
   }
   static_for<PD - 1>([&](auto jc) {
@@ -522,7 +556,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
         const int n = n0 + wn * (BN / WN) + ch * 4;
         if (m < M && n < N)
           epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PD][PRE_RES ? it : 0],
-                                pre_b4 && n + 3 < N, bias4);
+                                pre_b4 && n + 3 < N, bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j % PD][PRE_RES ? it : 0],
+                                lng, lnb);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block of rows overwrites
@@ -877,6 +912,8 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   e.scale = te.p_drop > 0.f ? 1.f / (1.f - te.p_drop) : 1.f;
   e.site = te.site; e.seed = te.seed;
   e.mask = (const uint8_t*)te.mask; e.ldmask = te.ldmask;
+  e.ln_stats = te.ln_stats; e.ln_w = te.ln_w; e.ln_b = te.ln_b;
+  if (e.ln_stats && (epi != TIMHIP_EPI_DROP_RES_F32 || !e.res || !e.ln_w || !e.ln_b)) return TIMHIP_EINVAL;
   e.slab_stride = splitk > 1 ? (long long)M * te.ld0 : 0;
 
   bool vec = (e.ld0 % 4 == 0) && (((uintptr_t)e.out0 & 15) == 0);

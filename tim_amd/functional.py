@@ -441,7 +441,11 @@ class EncoderFn(torch.autograd.Function):
         # ---- sequence assembly (encodings.py:190-250)
         cls = torch.cat([_f32c(P[fe + n]).reshape(1, d) for n in plan.cls_names], 0) if plan.cls_names else None
         mod = torch.cat([_f32c(P[fe + n]).reshape(1, E) for n in plan.mod_names], 0) if plan.mod_names else None
-        xs_f = [torch.empty((M, E), dtype=torch.float32, device=dev) for _ in range(Lyr + 1)]
+        # fp32 rows exist only at the two ends of the stack: the assembled input and the last layer's output (-> feats);
+        # between layers every reader normalises the previous layer's pre-norm rows itself (timhip_layer_fwd_chained)
+        xs_f = [None] * (Lyr + 1)
+        xs_f[0] = torch.empty((M, E), dtype=torch.float32, device=dev)
+        xs_f[Lyr] = torch.empty((M, E), dtype=torch.float32, device=dev)
         xs_t = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(Lyr + 1)]
         tab = plan.table(dev)
         call("timhip_assemble_fwd", rt.prec, ptr(tab), B, S, d, ptr(e_bufs[0]), ptr(e_bufs[1]), nf, ptr(cls),
@@ -461,11 +465,13 @@ class EncoderFn(torch.autograd.Function):
             lparams.append(lp)
             sv = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
             desc.layer = l
-            call("timhip_layer_fwd", C.byref(desc), C.byref(lp[0]), ptr(xs_f[l]), ptr(xs_t[l]), ptr(xs_f[l + 1]),
-                 ptr(xs_t[l + 1]), ptr(sv), ptr(ws), ws_bytes, st)
+            if l == 0:
+                call("timhip_layer_fwd", C.byref(desc), C.byref(lp[0]), ptr(xs_f[0]), ptr(xs_t[0]), ptr(xs_f[1]),
+                     ptr(xs_t[1]), ptr(sv), ptr(ws), ws_bytes, st)
+            else:
+                call("timhip_layer_fwd_chained", C.byref(desc), C.byref(lp[0]), C.byref(lparams[l - 1][0]),
+                     ptr(layer_saved[l - 1]), ptr(xs_t[l]), ptr(xs_f[l + 1]), ptr(xs_t[l + 1]), ptr(sv), st)
             layer_saved.append(sv)
-            if l > 0:
-                xs_f[l] = None  # the fp32 stream of inner layers is not needed by the backward
 
         # ---- heads (head.py:17-38)
         xL_t = xs_t[Lyr]
