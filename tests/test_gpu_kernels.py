@@ -179,6 +179,63 @@ def test_wgrad_and_colsum(prec):
     assert (db.cpu().double() - refb).abs().max().item() <= tol(prec, refb) * 4
 
 
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K,p", [(333, 256, 128, 0.0), (9925, 1024, 64, 0.25), (70, 136, 192, 0.25)])
+def test_gemm_residual_is_layernorm(prec, M, N, K, p):
+    """DROP_RES_F32 with TimEpi.ln_* (residual = LayerNorm(res), normalised by the epilogue) == LayerNorm kernel first, then
+    the plain residual epilogue"""
+    rt = Runtime(prec)
+    A, _ = to_op(rt, rnd(M, K, seed=1))
+    B, _ = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))
+    y = (rnd(M, N, seed=3) * 2 + 0.5).to(DEV)
+    g = (1 + 0.1 * rnd(N, seed=4)).to(DEV)
+    b = (0.1 * rnd(N, seed=5)).to(DEV)
+    bias = (0.1 * rnd(N, seed=6)).to(DEV)
+    xf = torch.empty((M, N), device=DEV)
+    stats = torch.empty((M, 2), device=DEV)
+    rt.ln_fwd(y, M, N, 0, g, b, xf=xf, ldx=N, stats=stats)
+    ref = torch.empty((M, N), device=DEV)
+    out = torch.empty((M, N), device=DEV)
+    kw = dict(bias=bias, ldres=N, p_drop=p, seed=77, site=5)
+    rt.gemm(L.EPI_DROP_RES_F32, A, B, M, N, K, ref, N, res=xf, **kw)
+    rt.gemm(L.EPI_DROP_RES_F32, A, B, M, N, K, out, N, res=y, ln=(stats, g, b), **kw)
+    torch.cuda.synchronize()
+    assert (out - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("epi", ["gelu_drop", "dgelu"])
+@pytest.mark.parametrize("M,N", [(9925, 2048), (130, 72), (64, 256)])
+def test_gemm_dropout_keep_bits(epi, M, N):
+    """the FFN epilogues with the keep-bits drawn ahead of time (TimEpi.mask: what LayerNorm-1 writes inside the layer) ==
+    the same epilogues drawing Philox themselves; the bits here come from the timhip_dropout_mask test hook"""
+    rt = Runtime("bf16")
+    K, p, seed, site = 128, 0.3, 1234, 16 + 8 + 3
+    A, _ = to_op(rt, rnd(M, K, seed=1))
+    B, _ = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = (0.1 * rnd(N, seed=6)).to(DEV)
+    ld = _ru(N)
+    keep = torch.empty((M, (N + 3) // 4 * 4), dtype=torch.uint8, device=DEV)
+    L.call("timhip_dropout_mask", seed, site, p, M, N, L.ptr(keep), st())
+    ldm = (N + 7) // 8
+    padded = torch.zeros((M, ldm * 8), dtype=torch.uint8, device=DEV)
+    padded[:, :N] = keep[:, :N]
+    bits = (padded.view(M, ldm, 8).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    outs = []
+    for mask in (None, bits):
+        o0 = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV)
+        o1 = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV)
+        aux = (rnd(M, ld, seed=9)).to(DEV).bfloat16()
+        kw = dict(p_drop=p, seed=seed, site=site, mask=mask, ldmask=ldm)
+        if epi == "gelu_drop":
+            rt.gemm(L.EPI_GELU_DROP_T2, A, B, M, N, K, o0, ld, out1=o1, ld1=ld, bias=bias, **kw)
+        else:
+            rt.gemm(L.EPI_DGELU_T, A, B, M, N, K, o0, ld, aux=aux, ldaux=ld, **kw)
+        torch.cuda.synchronize()
+        outs.append((o0.clone(), o1.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[0][0][:, :N] == 0).float().mean().item() > p * 0.8       # dropout really happened
+
+
 @pytest.mark.parametrize("accumulate", [True, False])
 @pytest.mark.parametrize("M,shapes", [
     (523, [(200, 72), (64, 136), (130, 128)]),                       # ragged tiles, few tiles: the contraction is split

@@ -157,11 +157,13 @@ class Runtime:
 
     # ---- thin op wrappers ------------------------------------------------------------------------
     def gemm(self, epi, A, B, M, N, K, out0, ld0, out1=None, ld1=0, bias=None, res=None, ldres=0, aux=None,
-             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0):
+             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0, ln=None):
+        """ln = (stats[M,2], gamma[N], beta[N]): EPI_DROP_RES_F32 takes LayerNorm(res) as its residual (TimEpi.ln_*)"""
         if M == 0 or N == 0:
             return
+        st_, g_, b_ = ln if ln is not None else (None, None, None)
         e = L.TimEpi(ptr(out0), ptr(out1), ptr(bias), ptr(res), ptr(aux), ld0, ld1, ldres, ldaux,
-                     float(p_drop), site, seed, ptr(mask), ldmask, 0)
+                     float(p_drop), site, seed, ptr(mask), ldmask, 0, ptr(st_), ptr(g_), ptr(b_))
         call("timhip_gemm_nt", self.prec, epi, ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K,
              C.byref(e), splitk, _stream())
 
