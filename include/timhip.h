@@ -67,7 +67,11 @@ enum {
   TIMHIP_EPI_DRELU_T = 7,   /* out0(T)   = acc * (aux(T) > 0) */
   TIMHIP_EPI_ATOMIC_F32 = 8,/* out0(f32) += acc (split-K weight gradients) */
   TIMHIP_EPI_SIGMOID_F32 = 9,/* out0(f32) = sigmoid(acc + bias) */
-  TIMHIP_EPI_DRELU_F32IN_T = 10 /* out0(T) = acc * (aux(f32) > 0) */
+  TIMHIP_EPI_DRELU_F32IN_T = 10,/* out0(T) = acc * (aux(f32) > 0) */
+  TIMHIP_EPI_GELU_DROP_G2 = 11, /* u = acc+bias ; out0(T) = dropmask * gelu(u) ; out1(T) = dropmask * gelu'(u): the factor the
+                                   backward multiplies with, so that its epilogue (TIMHIP_EPI_MULAUX_T) needs no erf / exp and
+                                   no second look at the dropout mask */
+  TIMHIP_EPI_MULAUX_T = 12      /* out0(T) = acc * aux(T) */
 };
 
 /* Shape of one call.  M = B*S rows flow through the encoder. */

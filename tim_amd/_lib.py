@@ -13,7 +13,7 @@ PREC_BF16, PREC_BF16X3, PREC_FP32 = 0, 1, 2
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32}
 
 (EPI_STORE_T, EPI_RELU_T, EPI_STORE_F32, EPI_GELU_DROP_T2, EPI_DROP_RES_F32, EPI_ADD_F32,
- EPI_DGELU_T, EPI_DRELU_T, EPI_ATOMIC_F32, EPI_SIGMOID_F32, EPI_DRELU_F32IN_T) = range(11)
+ EPI_DGELU_T, EPI_DRELU_T, EPI_ATOMIC_F32, EPI_SIGMOID_F32, EPI_DRELU_F32IN_T, EPI_GELU_DROP_G2, EPI_MULAUX_T) = range(13)
 
 # dropout site ids (csrc/common.h)
 SITE_FEAT_V, SITE_FEAT_A, SITE_SEQ = 1, 2, 3

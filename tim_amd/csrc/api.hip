@@ -24,7 +24,7 @@ SavedLayout saved_layout(const TimDesc& d) {
   L.h = take(M * d.FF * ts);
   L.y2 = take(M * d.E * 4);
   L.st2 = take(M * 2 * 4);
-  L.ffn_mask = take(M * d.FF / 8);   // keep-bits of the FFN dropout (FF % 64 == 0): written by norm1, read by both FFN epilogues
+  L.ffn_mask = take(M * d.FF / 8);   // keep-bits of the FFN dropout (FF % 64 == 0): written by norm1, read by the linear1 epilogue
   L.total = off;
   return L;
 }
@@ -239,7 +239,9 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
   e.out0 = h; e.ld0 = FF; e.out1 = u; e.ld1 = FF; e.bias = w->l1_b;
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
   e.mask = fmask; e.ldmask = FF / 8;
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_T2, x1t, E, w->l1_w, E, M, FF, E, e, 1, s))) return rc;
+  // (out1 = `u` holds dropmask * gelu'(linear1 output): the factor the backward multiplies with - it never needs the
+  //  pre-activations themselves, so its epilogue is a plain multiply)
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_G2, x1t, E, w->l1_w, E, M, FF, E, e, 1, s))) return rc;
   // 6. linear2 + dropout2 + residual
   e = epi0();
   e.out0 = y2; e.ld0 = E; e.bias = w->l2_b; e.ldres = E;
@@ -316,12 +318,10 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
   // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
   if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, df, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b, (float*)(ws + W.lnp), s))) return rc;
-  // du = (df W2) * dropout-mask * gelu'(u)
+  // du = (df W2) * [dropout-mask * gelu'(pre-activation)]
   TimEpi e = epi0();
-  e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;
-  e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_FFN);
-  e.mask = d.p_drop > 0.f ? (const uint8_t*)saved + saved_layout(d).ffn_mask : nullptr; e.ldmask = FF / 8;
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DGELU_T, df, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
+  e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;   // u = dropmask * gelu'(pre-activation), written by the forward
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_MULAUX_T, df, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
   // dx1 = du W1 + dy2   (residual branch)
   e = epi0();
   e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E;

@@ -177,6 +177,15 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * kInvSqrt2Pi, e, 0.5f * (1.0f + er));
 }
 
+// gelu(x) and gelu'(x) from one erf / exp evaluation
+__device__ __forceinline__ void gelu_both_f(float x, float& gl, float& dg) {
+  const float kInvSqrt2Pi = 0.3989422804014327f;
+  float e;
+  const float ph = 0.5f * (1.0f + erf_half_f(x, e));   // Phi(x)
+  gl = x * ph;
+  dg = fmaf(x * kInvSqrt2Pi, e, ph);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

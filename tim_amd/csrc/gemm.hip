@@ -44,7 +44,7 @@ template <int EPI, typename T>
 __device__ __forceinline__ void epi_one(const EpiDev& e, int m, int n, int N, float v, float mask) {
   size_t i0 = (size_t)m * e.ld0 + n;
   if (e.bias && EPI != TIMHIP_EPI_ADD_F32 && EPI != TIMHIP_EPI_DGELU_T && EPI != TIMHIP_EPI_DRELU_T &&
-      EPI != TIMHIP_EPI_ATOMIC_F32 && EPI != TIMHIP_EPI_DRELU_F32IN_T)
+      EPI != TIMHIP_EPI_ATOMIC_F32 && EPI != TIMHIP_EPI_DRELU_F32IN_T && EPI != TIMHIP_EPI_MULAUX_T)
     v += e.bias[n];
   if (EPI == TIMHIP_EPI_STORE_T) {
     ((T*)e.out0)[i0] = OpT<T>::from_f(v);
@@ -55,6 +55,13 @@ __device__ __forceinline__ void epi_one(const EpiDev& e, int m, int n, int N, fl
   } else if (EPI == TIMHIP_EPI_GELU_DROP_T2) {
     ((T*)e.out1)[(size_t)m * e.ld1 + n] = OpT<T>::from_f(v);
     ((T*)e.out0)[i0] = OpT<T>::from_f(gelu_f(v) * mask);
+  } else if (EPI == TIMHIP_EPI_GELU_DROP_G2) {
+    float gl, dg;
+    gelu_both_f(v, gl, dg);
+    ((T*)e.out1)[(size_t)m * e.ld1 + n] = OpT<T>::from_f(dg * mask);
+    ((T*)e.out0)[i0] = OpT<T>::from_f(gl * mask);
+  } else if (EPI == TIMHIP_EPI_MULAUX_T) {
+    ((T*)e.out0)[i0] = OpT<T>::from_f(v * OpT<T>::to_f(((const T*)e.aux)[(size_t)m * e.ldaux + n]));
   } else if (EPI == TIMHIP_EPI_DROP_RES_F32) {
     float r = e.res[(size_t)m * e.ldres + n];
     if (e.ln_stats) r = (r - e.ln_stats[2 * m]) * e.ln_stats[2 * m + 1] * e.ln_w[n] + e.ln_b[n];
@@ -78,7 +85,8 @@ __device__ __forceinline__ void epi_one(const EpiDev& e, int m, int n, int N, fl
 }
 
 constexpr bool epi_uses_dropout(int EPI) {
-  return EPI == TIMHIP_EPI_GELU_DROP_T2 || EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_DGELU_T;
+  return EPI == TIMHIP_EPI_GELU_DROP_T2 || EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_DGELU_T ||
+         EPI == TIMHIP_EPI_GELU_DROP_G2;
 }
 
 // 4 consecutive columns n..n+3 of row m
@@ -101,7 +109,7 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
   if (e.vec && n + 3 < N) {
     size_t i0 = (size_t)m * e.ld0 + n;
     if (EPI != TIMHIP_EPI_ADD_F32 && EPI != TIMHIP_EPI_DGELU_T && EPI != TIMHIP_EPI_DRELU_T &&
-        EPI != TIMHIP_EPI_ATOMIC_F32 && EPI != TIMHIP_EPI_DRELU_F32IN_T && e.bias) {
+        EPI != TIMHIP_EPI_ATOMIC_F32 && EPI != TIMHIP_EPI_DRELU_F32IN_T && EPI != TIMHIP_EPI_MULAUX_T && e.bias) {
       float4 b = pb;   // this lane's bias columns are the same for every row: fetched once by the caller, or here
       if (!has_b) b = *reinterpret_cast<const float4*>(e.bias + n);
       v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
@@ -115,6 +123,15 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
     } else if (EPI == TIMHIP_EPI_GELU_DROP_T2) {
       store4<T>((T*)e.out1 + (size_t)m * e.ld1 + n, v0, v1, v2, v3);
       store4<T>((T*)e.out0 + i0, gelu_f(v0) * k0, gelu_f(v1) * k1, gelu_f(v2) * k2, gelu_f(v3) * k3);
+    } else if (EPI == TIMHIP_EPI_GELU_DROP_G2) {
+      float g0, g1, g2, g3, d0, d1, d2, d3;
+      gelu_both_f(v0, g0, d0); gelu_both_f(v1, g1, d1); gelu_both_f(v2, g2, d2); gelu_both_f(v3, g3, d3);
+      store4<T>((T*)e.out1 + (size_t)m * e.ld1 + n, d0 * k0, d1 * k1, d2 * k2, d3 * k3);
+      store4<T>((T*)e.out0 + i0, g0 * k0, g1 * k1, g2 * k2, g3 * k3);
+    } else if (EPI == TIMHIP_EPI_MULAUX_T) {
+      float u0, u1, u2, u3;
+      load4<T>((const T*)e.aux + (size_t)m * e.ldaux + n, u0, u1, u2, u3);
+      store4<T>((T*)e.out0 + i0, v0 * u0, v1 * u1, v2 * u2, v3 * u3);
     } else if (EPI == TIMHIP_EPI_DROP_RES_F32) {
       float4 r = pre;   // fetched by the caller ahead of the stores, or here
       if (!has_pre) r = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
@@ -177,7 +194,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr bool epi_has_oct(int EPI) {
   return EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_RELU_T || EPI == TIMHIP_EPI_GELU_DROP_T2 ||
-         EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T;
+         EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_GELU_DROP_G2 ||
+         EPI == TIMHIP_EPI_MULAUX_T;
 }
 __device__ __forceinline__ void store8(bf16_t* p, float4 lo, float4 hi) {
   bf16x8_t o;
@@ -196,6 +214,7 @@ __device__ __forceinline__ float4 epi_math4(float4 v, float4 a, float4 k) {
                        v.w * k.w * gelu_grad_f(a.w));
   if (EPI == TIMHIP_EPI_DRELU_T)
     return make_float4(a.x > 0.f ? v.x : 0.f, a.y > 0.f ? v.y : 0.f, a.z > 0.f ? v.z : 0.f, a.w > 0.f ? v.w : 0.f);
+  if (EPI == TIMHIP_EPI_MULAUX_T) return make_float4(v.x * a.x, v.y * a.y, v.z * a.z, v.w * a.w);
   return v;
 }
 // 8 consecutive columns n..n+7 of row m for the epilogues that write bf16: ONE 16-byte store (and 16-byte aux load)
@@ -217,17 +236,28 @@ __device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, fl
     }
   }
   const size_t i0 = (size_t)m * e.ld0 + n;
-  if ((EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_RELU_T || EPI == TIMHIP_EPI_GELU_DROP_T2) && e.bias) {
+  if ((EPI == TIMHIP_EPI_STORE_T || EPI == TIMHIP_EPI_RELU_T || EPI == TIMHIP_EPI_GELU_DROP_T2 ||
+       EPI == TIMHIP_EPI_GELU_DROP_G2) && e.bias) {
     float4 b0 = pb0, b1 = pb1;
     if (!has_b) { b0 = *reinterpret_cast<const float4*>(e.bias + n); b1 = *reinterpret_cast<const float4*>(e.bias + n + 4); }
     lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w; hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
   }
   float4 alo = make_float4(0.f, 0.f, 0.f, 0.f), ahi = alo;
-  if (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T) {
+  if (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_MULAUX_T) {
     bf16x8_t a = pre;
     if (!has_pre) a = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)e.aux + (size_t)m * e.ldaux + n);
     alo = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
     ahi = make_float4((float)a[4], (float)a[5], (float)a[6], (float)a[7]);
+  }
+  if (EPI == TIMHIP_EPI_GELU_DROP_G2) {
+    float4 glo, ghi, dlo, dhi;
+    gelu_both_f(lo.x, glo.x, dlo.x); gelu_both_f(lo.y, glo.y, dlo.y); gelu_both_f(lo.z, glo.z, dlo.z); gelu_both_f(lo.w, glo.w, dlo.w);
+    gelu_both_f(hi.x, ghi.x, dhi.x); gelu_both_f(hi.y, ghi.y, dhi.y); gelu_both_f(hi.z, ghi.z, dhi.z); gelu_both_f(hi.w, ghi.w, dhi.w);
+    store8((bf16_t*)e.out1 + (size_t)m * e.ld1 + n, make_float4(dlo.x * klo.x, dlo.y * klo.y, dlo.z * klo.z, dlo.w * klo.w),
+           make_float4(dhi.x * khi.x, dhi.y * khi.y, dhi.z * khi.z, dhi.w * khi.w));
+    store8((bf16_t*)e.out0 + i0, make_float4(glo.x * klo.x, glo.y * klo.y, glo.z * klo.z, glo.w * klo.w),
+           make_float4(ghi.x * khi.x, ghi.y * khi.y, ghi.z * khi.z, ghi.w * khi.w));
+    return;
   }
   if (EPI == TIMHIP_EPI_GELU_DROP_T2) store8((bf16_t*)e.out1 + (size_t)m * e.ld1 + n, lo, hi);
   store8((bf16_t*)e.out0 + i0, epi_math4<EPI>(lo, alo, klo), epi_math4<EPI>(hi, ahi, khi));
@@ -445,7 +475,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   // row block ahead, into registers, BEFORE the stores of the current row block: a load placed after a store cannot be
   // moved ahead of it by the compiler (possible aliasing), so without this every chunk paid a full memory latency.
   constexpr bool PRE_RES = (EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_ADD_F32) && !(epi_has_oct(EPI));
-  constexpr bool PRE_AUX = (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T);
+  constexpr bool PRE_AUX = (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_MULAUX_T);
   constexpr int NITQ = 32 * CPR / 64, NITO = 32 * (EP_COLS / 8) / 64;
   constexpr int PD = TM <= 5 ? TM : 2;   // row blocks in flight: all of the tile's (<= 5: 80 VGPRs of fp32 residual), else 2
   float4 rbuf[PD][PRE_RES ? NITQ : 1];
@@ -947,6 +977,8 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
     CASE(TIMHIP_EPI_ATOMIC_F32)
     CASE(TIMHIP_EPI_SIGMOID_F32)
     CASE(TIMHIP_EPI_DRELU_F32IN_T)
+    CASE(TIMHIP_EPI_GELU_DROP_G2)
+    CASE(TIMHIP_EPI_MULAUX_T)
 #undef CASE
     default: return TIMHIP_EINVAL;
   }
