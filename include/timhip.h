@@ -165,6 +165,15 @@ typedef struct TimEpi {
   const float* ln_b;
 } TimEpi;
 
+/* n <= 6 independent small problems with the same epilogue as ONE launch (bf16; TIMHIP_EPI_STORE_F32, _ADD_F32, _STORE_T,
+ * _RELU_T): what the classification heads use - four under-filled GEMMs each way (head.py:17-38).  items is a HOST array. */
+typedef struct TimGemmItem {
+  const void* A; const void* B;
+  int32_t lda, ldb, M, N, K, reserved;
+  TimEpi e;
+} TimGemmItem;
+int timhip_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, void* stream);
+
 /* C[M,N] = A[M,K] * B[N,K]^T through epilogue `epi` (TIMHIP_EPI_*).  A, B operand dtype,
  * lda/ldb multiples of 64 and >= K.  splitk > 1 only with TIMHIP_EPI_ATOMIC_F32. */
 int timhip_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M,

@@ -203,6 +203,33 @@ def test_gemm_residual_is_layernorm(prec, M, N, K, p):
     assert (out - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("epi", ["store_f32", "add_f32"])
+def test_gemm_group(epi):
+    """several independent small problems as one grouped launch == one launch each (the classification heads' shapes: ragged
+    N, different M, ragged K)"""
+    rt = Runtime("bf16")
+    shapes = [(960, 97, 1024), (960, 300, 1024), (960, 3806, 1024), (640, 44, 1024), (70, 136, 192), (1, 5, 24)]
+    items, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A, _ = to_op(rt, rnd(M, K, seed=10 + i))
+        B, _ = to_op(rt, rnd(N, K, seed=30 + i, scale=K ** -0.5))
+        bias = (0.1 * rnd(N, seed=50 + i)).to(DEV)
+        res = rnd(M, N, seed=70 + i).to(DEV)
+        out = torch.full((M, N), 7.0, device=DEV)
+        ref = torch.full((M, N), 7.0, device=DEV)
+        if epi == "store_f32":
+            items.append(dict(A=A, B=B, M=M, N=N, K=K, out0=out, ld0=N, bias=bias))
+            rt.gemm(L.EPI_STORE_F32, A, B, M, N, K, ref, N, bias=bias)
+        else:
+            items.append(dict(A=A, B=B, M=M, N=N, K=K, out0=out, ld0=N, res=res, ldres=N))
+            rt.gemm(L.EPI_ADD_F32, A, B, M, N, K, ref, N, res=res, ldres=N)
+        refs.append(ref)
+    rt.gemm_many(L.EPI_STORE_F32 if epi == "store_f32" else L.EPI_ADD_F32, items)
+    torch.cuda.synchronize()
+    for it, ref in zip(items, refs):
+        assert torch.equal(it["out0"], ref)
+
+
 @pytest.mark.parametrize("epi", ["gelu_drop", "dgelu"])
 @pytest.mark.parametrize("M,N", [(9925, 2048), (130, 72), (64, 256)])
 def test_gemm_dropout_keep_bits(epi, M, N):

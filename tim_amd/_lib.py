@@ -57,6 +57,11 @@ class TimEpi(C.Structure):
                 ("ln_stats", vp), ("ln_w", vp), ("ln_b", vp)]
 
 
+class TimGemmItem(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("lda", i32), ("ldb", i32), ("M", i32), ("N", i32), ("K", i32), ("reserved", i32),
+                ("e", TimEpi)]
+
+
 _SIGS = {
     "timhip_version": (C.c_int, []),
     "timhip_strerror": (C.c_char_p, [C.c_int]),
@@ -66,6 +71,7 @@ _SIGS = {
     "timhip_cast_weight_both": (C.c_int, [i32, vp, i32, i32, vp, i32, vp, i32, vp]),
     "timhip_cast_weights": (C.c_int, [i32, vp, i32, vp]),
     "timhip_gemm_nt": (C.c_int, [i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(TimEpi), i32, vp]),
+    "timhip_gemm_nt_group": (C.c_int, [i32, i32, vp, i32, vp]),
     "timhip_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
     "timhip_wgrad_group_workspace_bytes": (sz, [i32, vp, i32, i32]),

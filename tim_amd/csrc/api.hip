@@ -182,6 +182,10 @@ size_t timhip_wgrad_workspace_bytes(int precision, int Nout, int Kout, int M) {
   return wgrad_ws(precision, Nout, Kout, M).total;
 }
 
+int timhip_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, void* stream) {
+  return tim_gemm_nt_group(precision, epi, items, n, (hipStream_t)stream);
+}
+
 size_t timhip_wgrad_group_workspace_bytes(int precision, const TimWgradItem* items, int n, int M) {
   return (precision == TIMHIP_PREC_BF16 && items && n > 0) ? tim_wgrad_group_ws(items, n, M) : 0;
 }

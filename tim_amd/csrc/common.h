@@ -283,6 +283,7 @@ struct TimGemmScope {
 
 int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
                 int K, const TimEpi& e, int splitk, hipStream_t s);
+int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, hipStream_t s);
 int tim_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,
                   float* colsum, hipStream_t s);
 int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStream_t s);

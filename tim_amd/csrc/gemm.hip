@@ -286,10 +286,11 @@ template <int BKT> __device__ __forceinline__ int kswz(int row);
 template <> __device__ __forceinline__ int kswz<64>(int row) { return (row >> 1) & 7; }
 template <> __device__ __forceinline__ int kswz<32>(int row) { return (row >> 2) & 3; }
 
+// the body of one block: tile `t` (already mapped to a logical tile index) of split `zsplit`
 template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
+__device__ __forceinline__ void gemm_nt_bf16_body(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N,
-    int K, int ksteps_per_split, EpiDev e) {
+    int K, int ksteps_per_split, EpiDev e, int t, int zsplit) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int ROWB = BKT * 2;                 // bytes per tile row
@@ -305,7 +306,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
   const int wm = wave / WN, wn = wave % WN;
 
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   int pm, pn;
   if (GM > 1) {
     const int per_group = GM * tiles_n;
@@ -322,9 +322,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
 
   const int nk_total = K / BKT;
   const int spl = ksteps_per_split * (BK / BKT);
-  const int kt0 = blockIdx.z * spl;
+  const int kt0 = zsplit * spl;
   const int kt1 = min(nk_total, kt0 + spl);
-  if (EPI == TIMHIP_EPI_STORE_F32) e.out0 = (float*)e.out0 + (long long)blockIdx.z * e.slab_stride;
+  if (EPI == TIMHIP_EPI_STORE_F32) e.out0 = (float*)e.out0 + (long long)zsplit * e.slab_stride;
 
   // ---- staging: each wave-instruction moves RPI rows x ROWB bytes ----
   const int lrow = lane / NCH, lchunk = lane % NCH;
@@ -606,6 +606,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
       atomicAdd(c + 6, (unsigned long long)(wall_clock64() - w_begin));
     }
   }
+}
+
+template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
+    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N,
+    int K, int ksteps_per_split, EpiDev e) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  gemm_nt_bf16_body<EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>(A, lda, B, ldb, M, N, K, ksteps_per_split, e,
+                                                           xcd_remap(blockIdx.x, tiles), (int)blockIdx.z);
+}
+
+// Grouped launch: several independent small GEMMs (the classification heads: four under-filled launches each way) as ONE
+// grid - their tile lists concatenated, every block looks its problem up.  Side streams were the alternative and measured
+// slower (every cross-stream edge costs more than such a launch lasts).
+constexpr int GG_MAX = 6;
+struct GemmGroupDev {
+  const bf16_t* A[GG_MAX]; const bf16_t* B[GG_MAX];
+  int lda[GG_MAX], ldb[GG_MAX], M[GG_MAX], N[GG_MAX], K[GG_MAX], tile0[GG_MAX + 1];
+  EpiDev e[GG_MAX];
+  int n;
+};
+template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_group_kernel(const GemmGroupDev g) {
+  const int t = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GG_MAX; ++k)
+    if (k < g.n && t >= g.tile0[k]) i = k;
+  gemm_nt_bf16_body<EPI, BM, BN, WM, WN, BKT, NST, 1, 0>(g.A[i], g.lda[i], g.B[i], g.ldb[i], g.M[i], g.N[i], g.K[i],
+                                                        g.K[i] / BK, g.e[i], t - g.tile0[i], 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -922,8 +952,9 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
 
 }  // namespace
 
-int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
-                int K, const TimEpi& te, int splitk, hipStream_t s) {
+// argument checks + device-side epilogue descriptor shared by the single and the grouped launch
+static int prepare_gemm(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                        const TimEpi& te, int splitk, EpiDev& e) {
   if (!A || !B || !te.out0) return TIMHIP_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return TIMHIP_EINVAL;
   if (precision != TIMHIP_PREC_BF16 && precision != TIMHIP_PREC_FP32 && precision != TIMHIP_PREC_BF16X3)
@@ -932,10 +963,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   if (lda % 64 || ldb % 64 || lda < Kp || ldb < Kp) return TIMHIP_EALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return TIMHIP_EALIGN;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return TIMHIP_EUNSUPPORTED;  // 32-bit lane offsets
-  if (splitk < 1) splitk = 1;
   if (splitk > 1 && epi != TIMHIP_EPI_ATOMIC_F32 && epi != TIMHIP_EPI_STORE_F32) return TIMHIP_EINVAL;
-  TimGemmScope timing(2.0 * M * N * K, s);
-  EpiDev e;
   e.out0 = te.out0; e.out1 = te.out1; e.bias = te.bias; e.res = te.res; e.aux = te.aux;
   e.ld0 = te.ld0; e.ld1 = te.ld1; e.ldres = te.ldres; e.ldaux = te.ldaux;
   e.thr = te.p_drop > 0.f ? drop_threshold(te.p_drop) : 0u;
@@ -959,6 +987,56 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   if (e.aux) vec8 = vec8 && (e.ldaux % 8 == 0);
   e.vec8 = vec8 ? 1 : 0;
   if (e.thr != 0u && (N % 4) != 0) return TIMHIP_EUNSUPPORTED;
+  return TIMHIP_OK;
+}
+
+// n <= 6 independent bf16 problems with the same epilogue as one grid of 64 x 128 tiles (small problems: the heads)
+int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, hipStream_t s) {
+  if (precision != TIMHIP_PREC_BF16) return TIMHIP_EUNSUPPORTED;
+  if (!items || n < 1 || n > GG_MAX) return TIMHIP_EINVAL;
+  if (epi != TIMHIP_EPI_STORE_F32 && epi != TIMHIP_EPI_ADD_F32 && epi != TIMHIP_EPI_STORE_T && epi != TIMHIP_EPI_RELU_T)
+    return TIMHIP_EUNSUPPORTED;
+  GemmGroupDev g;
+  g.n = n;
+  g.tile0[0] = 0;
+  double flops = 0.0;
+  for (int i = 0; i < GG_MAX; ++i) {
+    if (i >= n) {
+      g.A[i] = g.B[i] = nullptr; g.lda[i] = g.ldb[i] = g.M[i] = g.N[i] = g.K[i] = 0; g.tile0[i + 1] = g.tile0[i];
+      g.e[i] = g.e[0];
+      continue;
+    }
+    const TimGemmItem& t = items[i];
+    const int rc = prepare_gemm(precision, epi, t.A, t.lda, t.B, t.ldb, t.M, t.N, t.K, t.e, 1, g.e[i]);
+    if (rc) return rc;
+    g.A[i] = (const bf16_t*)t.A; g.B[i] = (const bf16_t*)t.B; g.lda[i] = t.lda; g.ldb[i] = t.ldb;
+    g.M[i] = t.M; g.N[i] = t.N; g.K[i] = round_up(t.K, 64);
+    g.tile0[i + 1] = g.tile0[i] + ((t.M + 63) / 64) * ((t.N + 127) / 128);
+    flops += 2.0 * t.M * t.N * t.K;
+  }
+  TimGemmScope timing(flops, s);
+  const dim3 grid((unsigned)g.tile0[n]);
+  const size_t shmem = (size_t)2 * (64 + 128) * 64 * 2;
+#define GROUP(X) case X: hipLaunchKernelGGL((gemm_nt_group_kernel<X, 64, 128, 1, 4, 64, 2>), grid, dim3(256), shmem, s, g); break;
+  switch (epi) {
+    GROUP(TIMHIP_EPI_STORE_F32)
+    GROUP(TIMHIP_EPI_ADD_F32)
+    GROUP(TIMHIP_EPI_STORE_T)
+    GROUP(TIMHIP_EPI_RELU_T)
+    default: return TIMHIP_EUNSUPPORTED;
+  }
+#undef GROUP
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
+
+int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
+                int K, const TimEpi& te, int splitk, hipStream_t s) {
+  if (splitk < 1) splitk = 1;
+  EpiDev e;
+  const int rc0 = prepare_gemm(precision, epi, A, lda, B, ldb, M, N, K, te, splitk, e);
+  if (rc0) return rc0;
+  const int Kp = round_up(K, 64);
+  TimGemmScope timing(2.0 * M * N * K, s);
   int variant = 0;
 #ifdef TIMHIP_TUNING  // tools/gemm_tune.py, tools/gemm_abl.py: make -C tim_amd/csrc TUNING=1
   if (const char* v = getenv("TIMHIP_GEMM_VARIANT")) variant = atoi(v);

@@ -176,6 +176,26 @@ class Runtime:
         call("timhip_wgrad", self.prec, ptr(dY), dY.stride(0), Nout, ptr(X), X.stride(0), Kout, M, ptr(dW),
              ptr(db), ptr(ws), nbytes, _stream())
 
+    def gemm_many(self, epi, items):
+        """items: [dict(A, B, M, N, K, out0, ld0, bias=None, res=None, ldres=0)] - independent small problems with the same
+        epilogue; in bf16 up to six go out as one grouped launch (timhip_gemm_nt_group), otherwise one launch each"""
+        items = [it for it in items if it["M"] > 0 and it["N"] > 0]
+        if self.prec != L.PREC_BF16 or len(items) < 2 or os.environ.get("TIM_AMD_NO_GEMM_GROUP", "0") == "1":  # (A/B switch)
+            for it in items:
+                self.gemm(epi, it["A"], it["B"], it["M"], it["N"], it["K"], it["out0"], it["ld0"], bias=it.get("bias"),
+                          res=it.get("res"), ldres=it.get("ldres", 0))
+            return
+        for i0 in range(0, len(items), 6):
+            grp = items[i0:i0 + 6]
+            arr = (L.TimGemmItem * len(grp))()
+            for a, it in zip(arr, grp):
+                a.A, a.B = ptr(it["A"]), ptr(it["B"])
+                a.lda, a.ldb = it["A"].stride(0), it["B"].stride(0)
+                a.M, a.N, a.K = it["M"], it["N"], it["K"]
+                a.e = L.TimEpi(ptr(it["out0"]), None, ptr(it.get("bias")), ptr(it.get("res")), None, it["ld0"], 0,
+                               it.get("ldres", 0), 0, 0.0, 0, 0, None, 0, 0, None, None, None)
+            call("timhip_gemm_nt_group", self.prec, epi, C.cast(arr, C.c_void_p), len(grp), _stream())
+
     def wgrad_many(self, items):
         """items: [(dY, Nout, X, Kout, M, dW, db), ...] - accumulate every weight gradient; in bf16 the items that share M go
         out as one grouped launch (front end, heads: many small GEMMs that each would need their own split-K + reduce)"""
@@ -479,6 +499,7 @@ class EncoderFn(torch.autograd.Function):
         xL_t = xs_t[Lyr]
         outs = {}
         head_saved = []
+        head_gemms = []
         for slot, pname, s0, n in plan.heads:
             w = P["cls_head." + pname + ".weight"]
             Cn = w.shape[0]
@@ -486,10 +507,12 @@ class EncoderFn(torch.autograd.Function):
             logits = torch.empty((B * n, Cn), dtype=torch.float32, device=dev)
             if n > 0:
                 call("timhip_gather_rows", rt.prec, ptr(xL_t), B, S, E, s0, n, ptr(rows), st)
-                rt.gemm(L.EPI_STORE_F32, rows, rt.weight(w), B * n, Cn, E, logits, Cn,
-                        bias=_f32c(P["cls_head." + pname + ".bias"]))
+                head_gemms.append(dict(A=rows, B=rt.weight(w), M=B * n, N=Cn, K=E, out0=logits, ld0=Cn,
+                                       bias=_f32c(P["cls_head." + pname + ".bias"])))
             outs[slot] = logits
             head_saved.append((slot, pname, s0, n, rows))
+        rt.gemm_many(L.EPI_STORE_F32, head_gemms)   # the heads' GEMMs are independent and under-filled: one grouped launch
+        del head_gemms
         reg_saved = []
         for slot, pname, s0, n in plan.reg:
             pre = "reg_head." + pname + "."
@@ -554,6 +577,7 @@ class EncoderFn(torch.autograd.Function):
 
         # ---- heads (their weight gradients are collected and launched grouped by row count)
         wg_items = []
+        head_dgrads, head_scatter = [], []
         for slot, pname, s0, n, rows in ctx.head_saved:
             go = g[slot]
             if go is None or n == 0:
@@ -565,8 +589,12 @@ class EncoderFn(torch.autograd.Function):
             call("timhip_cast_rows", rt.prec, ptr(go), B * n, Cn, Cn, ptr(gT), gT.shape[1], 0.0, 0, 0, st)
             wg_items.append((gT, Cn, rows, E, B * n, G["cls_head." + pname + ".weight"], G["cls_head." + pname + ".bias"]))
             d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
-            rt.gemm(L.EPI_ADD_F32, gT, rt.weight(w, True), B * n, E, Cn, d_rows, E)
+            head_dgrads.append(dict(A=gT, B=rt.weight(w, True), M=B * n, N=E, K=Cn, out0=d_rows, ld0=E))
+            head_scatter.append((d_rows, s0, n))
+        rt.gemm_many(L.EPI_ADD_F32, head_dgrads)   # input gradients of all heads: one grouped launch
+        for d_rows, s0, n in head_scatter:
             call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
+        del head_dgrads, head_scatter
         for slot, pname, s0, n, rows, h1, h2, y in ctx.reg_saved:
             go = g[slot]
             if go is None or n == 0:
