@@ -328,6 +328,16 @@ int timhip_gather_rows(int precision, const void* x_T, int B, int S, int E, int 
 /* dx[b, s0+i, :] += d_rows[b*n+i, :]  (fp32) */
 int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, int n, float* dx,
                             void* stream);
+/* The same moves for up to 6 token ranges in one launch (the four classification heads; the ranges of a scatter must be
+ * DISJOINT - heads that share token rows, as in the detection model, go through timhip_scatter_rows_add one by one), and the
+ * fp32 -> operand-dtype
+ * cast of several cotangent matrices (dst[i] is [rows[i], ld[i]], zero padded beyond cols[i]) in one launch. */
+int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, int count, const int* s0, const int* n,
+                         void* const* rows_T, void* stream);
+int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, const int* n,
+                              const float* const* d_rows, float* dx, void* stream);
+int timhip_cast_rows_many(int precision, int count, const float* const* src, const int* rows, const int* cols,
+                          void* const* dst, const int* ld, void* stream);
 
 /* ---------------------------------------------------------------- loss tail of the training step */
 /* Label-smoothed cross entropy under mixup, as recognition/scripts/train.py:46-49,218-316 applies it through

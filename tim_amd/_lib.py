@@ -120,6 +120,9 @@ _SIGS = {
     "timhip_drloc_gather": (C.c_int, [i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
     "timhip_drloc_scatter_add": (C.c_int, [vp, i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp]),
     "timhip_scatter_rows_add": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp]),
 }
 
 _lib = None

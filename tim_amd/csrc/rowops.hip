@@ -620,6 +620,63 @@ __global__ void scatter_rows_add_kernel(const float* __restrict__ d_rows, int B,
   }
 }
 
+// ---- the same row moves for several token ranges in one launch (the classification heads: 4 ranges per direction) ----
+constexpr int RR_MAX = 6;
+struct RowRanges {
+  const void* src[RR_MAX]; void* dst[RR_MAX];   // per range: gathered / per-head buffer on one side, the [B,S,E] stream on the other
+  int s0[RR_MAX], n[RR_MAX], joff[RR_MAX + 1];  // token range, prefix of n
+  int count;
+};
+template <typename T>
+__global__ void gather_ranges_kernel(const T* __restrict__ xt, int B, int S, int E, RowRanges rr) {
+  const int per = rr.joff[rr.count];
+  const int b = blockIdx.x / per, jg = blockIdx.x % per;
+  int r = 0;
+#pragma unroll
+  for (int k = 1; k < RR_MAX; ++k)
+    if (k < rr.count && jg >= rr.joff[k]) r = k;
+  const int j = jg - rr.joff[r];
+  const T* src = xt + ((size_t)b * S + rr.s0[r] + j) * E;
+  T* dst = (T*)rr.dst[r] + ((size_t)b * rr.n[r] + j) * E;
+  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+    float a0, a1, a2, a3;
+    load4<T>(src + c, a0, a1, a2, a3);
+    store4<T>(dst + c, a0, a1, a2, a3);
+  }
+}
+__global__ void scatter_ranges_add_kernel(int B, int S, int E, float* __restrict__ dx, RowRanges rr) {
+  const int per = rr.joff[rr.count];
+  const int b = blockIdx.x / per, jg = blockIdx.x % per;
+  int r = 0;
+#pragma unroll
+  for (int k = 1; k < RR_MAX; ++k)
+    if (k < rr.count && jg >= rr.joff[k]) r = k;
+  const int j = jg - rr.joff[r];
+  const float* src = (const float*)rr.src[r] + ((size_t)b * rr.n[r] + j) * E;
+  float* dst = dx + ((size_t)b * S + rr.s0[r] + j) * E;
+  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(src + c);
+    float4 o = *reinterpret_cast<float4*>(dst + c);
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    *reinterpret_cast<float4*>(dst + c) = o;
+  }
+}
+// fp32 [rows, cols] -> T [rows, ld] (zero padded) for several matrices in one launch (blockIdx.z = matrix)
+struct CastMany {
+  const float* src[RR_MAX]; void* dst[RR_MAX];
+  int rows[RR_MAX], cols[RR_MAX], ld[RR_MAX];
+};
+template <typename T>
+__global__ void cast_many_kernel(CastMany cm) {
+  const int i = blockIdx.z;
+  const int r = blockIdx.y;
+  if (r >= cm.rows[i]) return;
+  const float* src = cm.src[i] + (size_t)r * cm.cols[i];
+  T* dst = (T*)cm.dst[i] + (size_t)r * cm.ld[i];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cm.ld[i]; c += gridDim.x * blockDim.x)
+    dst[c] = OpT<T>::from_f(c < cm.cols[i] ? src[c] : 0.f);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -873,6 +930,64 @@ int timhip_gather_rows(int precision, const void* x_T, int B, int S, int E, int 
   if (!x_T || !rows_T || n <= 0 || E % 4) return TIMHIP_EINVAL;
   DISPATCH_T(precision, hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(B * n), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)x_T, B, S, E, s0, n, (T*)rows_T));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+static int fill_ranges(RowRanges& rr, int count, const int* s0, const int* n) {
+  if (count < 1 || count > RR_MAX || !s0 || !n) return TIMHIP_EINVAL;
+  rr.count = count;
+  rr.joff[0] = 0;
+  for (int i = 0; i < RR_MAX; ++i) {
+    rr.s0[i] = i < count ? s0[i] : 0;
+    rr.n[i] = i < count ? n[i] : 0;
+    if (i < count && n[i] <= 0) return TIMHIP_EINVAL;
+    rr.joff[i + 1] = rr.joff[i] + rr.n[i];
+    rr.src[i] = nullptr; rr.dst[i] = nullptr;
+  }
+  return TIMHIP_OK;
+}
+
+int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, int count, const int* s0, const int* n,
+                         void* const* rows_T, void* stream) {
+  if (!x_T || !rows_T || B <= 0 || E % 4) return TIMHIP_EINVAL;
+  RowRanges rr;
+  int rc = fill_ranges(rr, count, s0, n);
+  if (rc) return rc;
+  for (int i = 0; i < count; ++i) { if (!rows_T[i]) return TIMHIP_EINVAL; rr.dst[i] = rows_T[i]; }
+  DISPATCH_T(precision, hipLaunchKernelGGL(gather_ranges_kernel<T>, dim3(B * rr.joff[count]), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)x_T, B, S, E, rr));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, const int* n, const float* const* d_rows,
+                              float* dx, void* stream) {
+  if (!d_rows || !dx || B <= 0 || E % 4) return TIMHIP_EINVAL;
+  RowRanges rr;
+  int rc = fill_ranges(rr, count, s0, n);
+  if (rc) return rc;
+  for (int i = 0; i < count; ++i) { if (!d_rows[i]) return TIMHIP_EINVAL; rr.src[i] = d_rows[i]; }
+  hipLaunchKernelGGL(scatter_ranges_add_kernel, dim3(B * rr.joff[count]), dim3(256), 0, (hipStream_t)stream, B, S, E, dx, rr);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_cast_rows_many(int precision, int count, const float* const* src, const int* rows, const int* cols,
+                          void* const* dst, const int* ld, void* stream) {
+  if (count < 1 || count > RR_MAX || !src || !rows || !cols || !dst || !ld) return TIMHIP_EINVAL;
+  CastMany cm;
+  int maxr = 0, maxld = 0;
+  for (int i = 0; i < RR_MAX; ++i) {
+    const bool on = i < count;
+    if (on && (!src[i] || !dst[i] || rows[i] <= 0 || cols[i] <= 0 || ld[i] < cols[i])) return TIMHIP_EINVAL;
+    cm.src[i] = on ? src[i] : nullptr; cm.dst[i] = on ? dst[i] : nullptr;
+    cm.rows[i] = on ? rows[i] : 0; cm.cols[i] = on ? cols[i] : 0; cm.ld[i] = on ? ld[i] : 0;
+    if (on && rows[i] > maxr) maxr = rows[i];
+    if (on && ld[i] > maxld) maxld = ld[i];
+  }
+  dim3 grid((maxld + 255) / 256 > 8 ? 8 : (maxld + 255) / 256, maxr, count);
+  DISPATCH_T(precision, hipLaunchKernelGGL(cast_many_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, cm));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

@@ -236,6 +236,14 @@ class Runtime:
              0 if dyt is None else dyt.stride(0), 0.0, 0, 0, ptr(dgamma), ptr(dbeta), _stream())
 
 
+def _iarr(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _parr(tensors):
+    return (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
 def _f32c(t):
     t = t.detach()
     if t.dtype != torch.float32:
@@ -499,20 +507,27 @@ class EncoderFn(torch.autograd.Function):
         xL_t = xs_t[Lyr]
         outs = {}
         head_saved = []
-        head_gemms = []
+        head_gemms, head_ranges = [], []
         for slot, pname, s0, n in plan.heads:
             w = P["cls_head." + pname + ".weight"]
             Cn = w.shape[0]
             rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
             logits = torch.empty((B * n, Cn), dtype=torch.float32, device=dev)
             if n > 0:
-                call("timhip_gather_rows", rt.prec, ptr(xL_t), B, S, E, s0, n, ptr(rows), st)
+                head_ranges.append((s0, n, rows))
                 head_gemms.append(dict(A=rows, B=rt.weight(w), M=B * n, N=Cn, K=E, out0=logits, ld0=Cn,
                                        bias=_f32c(P["cls_head." + pname + ".bias"])))
             outs[slot] = logits
             head_saved.append((slot, pname, s0, n, rows))
-        rt.gemm_many(L.EPI_STORE_F32, head_gemms)   # the heads' GEMMs are independent and under-filled: one grouped launch
-        del head_gemms
+        # the heads' row gathers and GEMMs are independent and tiny: one launch of each kind for all of them
+        if 2 <= len(head_ranges) <= 6:
+            call("timhip_gather_ranges", rt.prec, ptr(xL_t), B, S, E, len(head_ranges), _iarr([r[0] for r in head_ranges]),
+                 _iarr([r[1] for r in head_ranges]), _parr([r[2] for r in head_ranges]), st)
+        else:
+            for s0, n, rows in head_ranges:
+                call("timhip_gather_rows", rt.prec, ptr(xL_t), B, S, E, s0, n, ptr(rows), st)
+        rt.gemm_many(L.EPI_STORE_F32, head_gemms)
+        del head_gemms, head_ranges
         reg_saved = []
         for slot, pname, s0, n in plan.reg:
             pre = "reg_head." + pname + "."
@@ -577,7 +592,7 @@ class EncoderFn(torch.autograd.Function):
 
         # ---- heads (their weight gradients are collected and launched grouped by row count)
         wg_items = []
-        head_dgrads, head_scatter = [], []
+        head_dgrads, head_scatter, head_casts = [], [], []
         for slot, pname, s0, n, rows in ctx.head_saved:
             go = g[slot]
             if go is None or n == 0:
@@ -586,15 +601,29 @@ class EncoderFn(torch.autograd.Function):
             Cn = w.shape[0]
             go = _f32c(go)
             gT = torch.empty((B * n, _ru(Cn)), dtype=rt.op_dtype, device=dev)
-            call("timhip_cast_rows", rt.prec, ptr(go), B * n, Cn, Cn, ptr(gT), gT.shape[1], 0.0, 0, 0, st)
+            head_casts.append((go, B * n, Cn, gT))
             wg_items.append((gT, Cn, rows, E, B * n, G["cls_head." + pname + ".weight"], G["cls_head." + pname + ".bias"]))
             d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
             head_dgrads.append(dict(A=gT, B=rt.weight(w, True), M=B * n, N=E, K=Cn, out0=d_rows, ld0=E))
             head_scatter.append((d_rows, s0, n))
-        rt.gemm_many(L.EPI_ADD_F32, head_dgrads)   # input gradients of all heads: one grouped launch
-        for d_rows, s0, n in head_scatter:
-            call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
-        del head_dgrads, head_scatter
+        # cotangent casts, input-gradient GEMMs and row scatters of all heads: one launch of each kind
+        if 2 <= len(head_casts) <= 6:
+            call("timhip_cast_rows_many", rt.prec, len(head_casts), _parr([c[0] for c in head_casts]),
+                 _iarr([c[1] for c in head_casts]), _iarr([c[2] for c in head_casts]), _parr([c[3] for c in head_casts]),
+                 _iarr([c[3].shape[1] for c in head_casts]), st)
+        else:
+            for go, r_, c_, gT in head_casts:
+                call("timhip_cast_rows", rt.prec, ptr(go), r_, c_, c_, ptr(gT), gT.shape[1], 0.0, 0, 0, st)
+        rt.gemm_many(L.EPI_ADD_F32, head_dgrads)
+        spans = sorted((h[1], h[1] + h[2]) for h in head_scatter)
+        disjoint = all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))   # detection: several heads read one row
+        if 2 <= len(head_scatter) <= 6 and disjoint:
+            call("timhip_scatter_ranges_add", B, S, E, len(head_scatter), _iarr([h[1] for h in head_scatter]),
+                 _iarr([h[2] for h in head_scatter]), _parr([h[0] for h in head_scatter]), ptr(dx), st)
+        else:
+            for d_rows, s0, n in head_scatter:
+                call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
+        del head_dgrads, head_scatter, head_casts
         for slot, pname, s0, n, rows, h1, h2, y in ctx.reg_saved:
             go = g[slot]
             if go is None or n == 0:
