@@ -112,7 +112,16 @@ typedef struct TimLayerParams {
 typedef struct TimLayerGrads {
   float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b;
   float *n1_w, *n1_b, *n2_w, *n2_b;
+  /* optional (NULL = reduce inside the layer call): timhip_layer_ln_partial_bytes() bytes that receive the per-block partial
+   * sums of the two LayerNorm parameter gradients (norm2 first, then norm1) INSTEAD of adding them into n*_w / n*_b; the
+   * caller reduces the partials of all its layers with one timhip_ln_partials_reduce launch (12 small launches -> 1) */
+  float* ln_partials;
 } TimLayerGrads;
+size_t timhip_layer_ln_partial_bytes(const TimDesc* d);
+/* dgamma[i] += column sums of set i's gamma partials, dbeta[i] likewise: nsets sets laid out back to back, each as written by one
+ * LayerNorm backward over `rows` rows of `cols` columns; dgamma / dbeta: HOST arrays of nsets device pointers (<= 16) */
+int timhip_ln_partials_reduce(const float* partials, int nsets, int rows, int cols, float* const* dgamma,
+                              float* const* dbeta, void* stream);
 
 int timhip_version(void);
 const char* timhip_strerror(int code);

@@ -28,7 +28,7 @@ class TimDesc(C.Structure):
 
 _LP = ["in_w", "in_wt", "out_w", "out_wt", "l1_w", "l1_wt", "l2_w", "l2_wt",
        "in_b", "out_b", "l1_b", "l2_b", "n1_w", "n1_b", "n2_w", "n2_b"]
-_LG = ["in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w", "n2_b"]
+_LG = ["in_w", "in_b", "out_w", "out_b", "l1_w", "l1_b", "l2_w", "l2_b", "n1_w", "n1_b", "n2_w", "n2_b", "ln_partials"]
 
 
 class TimLayerParams(C.Structure):
@@ -120,6 +120,8 @@ _SIGS = {
     "timhip_drloc_gather": (C.c_int, [i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
     "timhip_drloc_scatter_add": (C.c_int, [vp, i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp]),
     "timhip_scatter_rows_add": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "timhip_layer_ln_partial_bytes": (sz, [C.POINTER(TimDesc)]),
+    "timhip_ln_partials_reduce": (C.c_int, [vp, i32, i32, i32, vp, vp, vp]),
     "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -291,6 +291,7 @@ static DyLayout dy_layout(const TimDesc& d) {
   return L;
 }
 
+size_t timhip_layer_ln_partial_bytes(const TimDesc* d) { return d ? 2 * tim_layernorm_bwd_ws(d->B * d->S, d->E) : 0; }
 size_t timhip_layer_dy_bytes(const TimDesc* d) { return d ? dy_layout(*d).total : 0; }
 size_t timhip_layer_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).total + dy_layout(*d).total : 0; }
 size_t timhip_layer_data_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).total : 0; }
@@ -321,7 +322,8 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
 
   // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
   if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, df, E, d.p_drop, d.seed,
-                              layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b, (float*)(ws + W.lnp), s))) return rc;
+                              layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b,
+                              g->ln_partials ? g->ln_partials : (float*)(ws + W.lnp), s, g->ln_partials != nullptr))) return rc;
   // du = (df W2) * [dropout-mask * gelu'(pre-activation)]
   TimEpi e = epi0();
   e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;   // u = dropmask * gelu'(pre-activation), written by the forward
@@ -332,7 +334,9 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
   // norm1 backward -> dy1 (fp32) and da = dropout1-mask * dy1 (T)
   if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, da, E, d.p_drop, d.seed,
-                              layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b, (float*)(ws + W.lnp), s))) return rc;
+                              layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b,
+                              g->ln_partials ? g->ln_partials + tim_layernorm_bwd_ws(M, E) / sizeof(float) : (float*)(ws + W.lnp), s,
+                              g->ln_partials != nullptr))) return rc;
   // do = da Wo
   e = epi0();
   e.out0 = Tc; e.ld0 = E;

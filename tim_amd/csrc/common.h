@@ -303,8 +303,9 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
                       const float* stats, int rows, int cols, int act, const float* w, float* dy_f32,
                       int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,
-                      float* dgamma, float* dbeta, float* partial_ws, hipStream_t s);
+                      float* dgamma, float* dbeta, float* partial_ws, hipStream_t s, bool defer_colsum = false);
 size_t tim_layernorm_bwd_ws(int rows, int cols);
+int tim_layernorm_bwd_blocks(int rows);   // partial rows one backward launch over `rows` rows writes
 int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
 int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse,
                       const void* d_o, void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);

@@ -149,6 +149,29 @@ __global__ void partial_colsum_kernel(const float* __restrict__ part, int nblk, 
   if (o) atomicAdd(o + (c < cols ? c : c - cols), (s0 + s1) + (s2 + s3));
 }
 
+// the same for several LayerNorm backward launches at once (blockIdx.z = set): one launch per training step instead of one per
+// LayerNorm
+constexpr int LNS_MAX = 16;
+struct LnSets { float* dg[LNS_MAX]; float* db[LNS_MAX]; };
+__global__ void partial_colsum_sets_kernel(const float* __restrict__ part, long long set_stride, int nblk, int cols, LnSets ls) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * cols) return;
+  const float* p = part + (long long)blockIdx.z * set_stride;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += p[(size_t)b * 2 * cols + c];
+    s1 += p[(size_t)(b + 1) * 2 * cols + c];
+    s2 += p[(size_t)(b + 2) * 2 * cols + c];
+    s3 += p[(size_t)(b + 3) * 2 * cols + c];
+  }
+  for (; b < b1; ++b) s0 += p[(size_t)b * 2 * cols + c];
+  float* o = c < cols ? ls.dg[blockIdx.z] : ls.db[blockIdx.z];
+  if (o) atomicAdd(o + (c < cols ? c : c - cols), (s0 + s1) + (s2 + s3));
+}
+
 // dW[i] += sum_z slab[z][i]   (split-K weight-gradient partials)
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, long long n, int nslab, float* __restrict__ dW) {
   for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
@@ -739,18 +762,23 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
   return TIMHIP_OK;
 }
 
+// 16 rows per block, more when that would exceed the 512 co-resident blocks (2 per CU): one balanced round
+static int ln_bwd_rows_per_block(int rows) {
+  int rpb = 16;
+  if (rows > 16 * 512) rpb = (((rows + 511) / 512) + 3) / 4 * 4;
+  return rpb;
+}
+
 size_t tim_layernorm_bwd_ws(int rows, int cols) { return (size_t)((rows + 15) / 16) * 2 * cols * sizeof(float); }
 
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
                       float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, float* partial_ws,
-                      hipStream_t s) {
+                      hipStream_t s, bool defer_colsum) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
     return TIMHIP_EUNSUPPORTED;
-  // 16 rows per block, more when that would exceed the 512 co-resident blocks (2 per CU): one balanced round
-  int rpb = 16;
-  if (rows > 16 * 512) rpb = (((rows + 511) / 512) + 3) / 4 * 4;
+  const int rpb = ln_bwd_rows_per_block(rows);
   dim3 grid((rows + rpb - 1) / rpb);
   const size_t shmem = (size_t)4 * 2 * cols * sizeof(float);
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
@@ -761,12 +789,17 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   DISPATCH_T(precision, if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4); else LN_BWD(8));
 #undef LN_BWD
   TIM_CHECK_LAUNCH();
-  if (partial_ws && (dgamma || dbeta)) {
+  if (partial_ws && (dgamma || dbeta) && !defer_colsum) {
     hipLaunchKernelGGL(partial_colsum_kernel, dim3((2 * cols + 255) / 256, 32), dim3(256), 0, s, partial_ws,
                        (int)grid.x, cols, dgamma, dbeta);
     TIM_CHECK_LAUNCH();
   }
   return TIMHIP_OK;
+}
+
+int tim_layernorm_bwd_blocks(int rows) {
+  const int rpb = ln_bwd_rows_per_block(rows);
+  return (rows + rpb - 1) / rpb;
 }
 
 extern "C" {
@@ -988,6 +1021,19 @@ int timhip_cast_rows_many(int precision, int count, const float* const* src, con
   }
   dim3 grid((maxld + 255) / 256 > 8 ? 8 : (maxld + 255) / 256, maxr, count);
   DISPATCH_T(precision, hipLaunchKernelGGL(cast_many_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, cm));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_ln_partials_reduce(const float* partials, int nsets, int rows, int cols, float* const* dgamma,
+                              float* const* dbeta, void* stream) {
+  if (!partials || nsets < 1 || nsets > LNS_MAX || rows <= 0 || cols <= 0 || !dgamma || !dbeta) return TIMHIP_EINVAL;
+  LnSets ls;
+  for (int i = 0; i < LNS_MAX; ++i) { ls.dg[i] = i < nsets ? dgamma[i] : nullptr; ls.db[i] = i < nsets ? dbeta[i] : nullptr; }
+  const int nblk = tim_layernorm_bwd_blocks(rows);
+  const long long stride = (long long)(tim_layernorm_bwd_ws(rows, cols) / sizeof(float));
+  hipLaunchKernelGGL(partial_colsum_sets_kernel, dim3((2 * cols + 255) / 256, 32, nsets), dim3(256), 0, (hipStream_t)stream,
+                     partials, stride, nblk, cols, ls);
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

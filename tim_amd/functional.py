@@ -674,9 +674,16 @@ class EncoderFn(torch.autograd.Function):
         else:
             ws_bytes = lib.timhip_layer_workspace_bytes(C.byref(desc))
             ws = model._workspace(ws_bytes, dev)
+        # LayerNorm dgamma / dbeta: every layer leaves per-block partials, one launch reduces them all at the end - unless a
+        # data-parallel hook takes each layer's bucket as soon as the layer is done (then the layer call reduces its own)
+        defer_ln = rt.bucket_hook is None and os.environ.get("TIM_AMD_NO_DEFER_LN", "0") != "1"   # (env: A/B switch)
+        ln_part_bytes = lib.timhip_layer_ln_partial_bytes(C.byref(desc)) if defer_ln else 0
+        ln_part = torch.empty(Lyr * ln_part_bytes, dtype=torch.uint8, device=dev) if defer_ln else None
         for l in reversed(range(Lyr)):
             pre = "%s.layers.%d." % (stack, l)
             lg = L.TimLayerGrads(*[ptr(G[pre + n]) for n in model._LAYER_GRAD_NAMES])
+            if defer_ln:
+                lg.ln_partials = ptr(ln_part) + l * ln_part_bytes
             desc.layer = l
             if overlap:
                 dyb = dys[l & 1]
@@ -700,6 +707,17 @@ class EncoderFn(torch.autograd.Function):
                 grads.done("layer%d" % l)
             dx, dx2 = dx2, dx
             ctx.layer_saved[l] = None
+
+        # LayerNorm parameter gradients of all layers: one reduction of the saved per-block partials (sets: norm2, norm1 per layer)
+        dgs, dbs = [], []
+        for l in range(Lyr if defer_ln else 0):
+            pre = "%s.layers.%d." % (stack, l)
+            dgs += [G[pre + "norm2.weight"], G[pre + "norm1.weight"]]
+            dbs += [G[pre + "norm2.bias"], G[pre + "norm1.bias"]]
+        for i0 in range(0, len(dgs), 16):
+            call("timhip_ln_partials_reduce", ptr(ln_part) + (i0 // 2) * ln_part_bytes, len(dgs[i0:i0 + 16]), M, E,
+                 _parr(dgs[i0:i0 + 16]), _parr(dbs[i0:i0 + 16]), st)
+        del ln_part
 
         # ---- sequence assembly backward
         ncls, nmod = len(plan.cls_names), len(plan.mod_names)
