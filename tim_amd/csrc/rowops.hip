@@ -597,23 +597,41 @@ __global__ __launch_bounds__(128) void assemble_bwd_te_kernel(const TimSeqRow* _
                                                               const float* __restrict__ dx, int Trows, uint32_t thr,
                                                               float scale, TimSeed seed, uint32_t site,
                                                               float* __restrict__ d_te) {
-  const int bt = blockIdx.x;
-  const int b = bt / Trows, t = bt % Trows;
+  // block (t, y): time row t for the y-th share of the windows.  The token rows that read time row t (1 for features and audio
+  // queries, 3 for visual queries) are found ONCE per block - the table scan is 155 dependent scalar loads, which a block per
+  // (window, time row) repeated 8000 times.
+  const int t = blockIdx.x;
   const int E = 2 * d;
-  for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
-      if (rows[s].te_row != t) continue;
-      const size_t bs = (size_t)b * S + s;
-      float4 g = *reinterpret_cast<const float4*>(dx + bs * E + d + c);
-      if (thr != 0u) {
-        float k0, k1, k2, k3;
-        drop_mask4(seed, site, (bs * E + d + c) >> 2, thr, scale, k0, k1, k2, k3);
-        g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+  __shared__ int readers[8];
+  __shared__ int nread;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int s = 0; s < S; ++s)
+      if (rows[s].te_row == t) { if (n < 8) readers[n] = s; ++n; }
+    nread = n;
+  }
+  __syncthreads();
+  const int nr = nread;   // > 8 (no TIM layout does this): the list is not used, every row is tested again
+  const int bper = (B + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
+  for (int b = b0; b < b1; ++b) {
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int cnt = nr <= 8 ? nr : S;
+      for (int i = 0; i < cnt; ++i) {
+        const int sr = nr <= 8 ? readers[i] : i;
+        if (nr > 8 && rows[sr].te_row != t) continue;
+        const size_t bs = (size_t)b * S + sr;
+        float4 g = *reinterpret_cast<const float4*>(dx + bs * E + d + c);
+        if (thr != 0u) {
+          float k0, k1, k2, k3;
+          drop_mask4(seed, site, (bs * E + d + c) >> 2, thr, scale, k0, k1, k2, k3);
+          g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+        }
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
       }
-      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      store4<float>(d_te + ((size_t)b * Trows + t) * d + c, acc.x, acc.y, acc.z, acc.w);
     }
-    store4<float>(d_te + ((size_t)b * Trows + t) * d + c, acc.x, acc.y, acc.z, acc.w);
   }
 }
 
@@ -952,7 +970,7 @@ int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float*
                      scale, seed, site, d_e0, d_e1, d_cls, d_mod);
   TIM_CHECK_LAUNCH();
   if (d_te) {
-    hipLaunchKernelGGL(assemble_bwd_te_kernel, dim3(B * T_), dim3(128), 0, (hipStream_t)stream, rows, B, S, d, dx, T_,
+    hipLaunchKernelGGL(assemble_bwd_te_kernel, dim3(T_, B >= 32 ? 16 : (B >= 8 ? 4 : 1)), dim3(128), 0, (hipStream_t)stream, rows, B, S, d, dx, T_,
                        thr, scale, seed, site, d_te);
     TIM_CHECK_LAUNCH();
   }
