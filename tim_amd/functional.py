@@ -447,6 +447,7 @@ class EncoderFn(torch.autograd.Function):
 
         # ---- modality embedders: e = LN(GELU(drop(x) W^T + b))  (encodings.py:21-26,140-153)
         emb_saved = []
+        emb_gemms = []
         e_bufs = [None, None]
         for name, slot in plan.embedders:
             x = visual if name == "visual" else audio
@@ -460,13 +461,19 @@ class EncoderFn(torch.autograd.Function):
             call("timhip_cast_rows", rt.prec, ptr(x2), R, Cin, Cin, ptr(xT), xT.shape[1], p_feat, seed, site, st)
             w = P[fe + name + "_embedder.1.weight"]
             u = torch.empty((R, d), dtype=torch.float32, device=dev)
-            rt.gemm(L.EPI_STORE_F32, xT, rt.weight(w), R, d, Cin, u, d, bias=_f32c(P[fe + name + "_embedder.1.bias"]))
+            emb_gemms.append(dict(A=xT, B=rt.weight(w), M=R, N=d, K=Cin, out0=u, ld0=d,
+                                  bias=_f32c(P[fe + name + "_embedder.1.bias"])))
+            emb_saved.append((name, slot, xT, u, None, Cin, site))
+        rt.gemm_many(L.EPI_STORE_F32, emb_gemms)   # the two modality embedders (under-filled, independent): one grouped launch
+        del emb_gemms
+        for i, (name, slot, xT, u, _, Cin, site) in enumerate(emb_saved):
+            R = B * nf
             e = torch.empty((R, d), dtype=torch.float32, device=dev)
             stats = torch.empty((R, 2), dtype=torch.float32, device=dev)
             rt.ln_fwd(u, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), _f32c(P[fe + name + "_embedder.3.bias"]),
                       xf=e, ldx=d, stats=stats)
             e_bufs[slot] = e
-            emb_saved.append((name, slot, xT, u, stats, Cin, site))
+            emb_saved[i] = (name, slot, xT, u, stats, Cin, site)
 
         # ---- sequence assembly (encodings.py:190-250)
         cls = torch.cat([_f32c(P[fe + n]).reshape(1, d) for n in plan.cls_names], 0) if plan.cls_names else None
