@@ -1015,6 +1015,15 @@ int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, h
     flops += 2.0 * t.M * t.N * t.K;
   }
   TimGemmScope timing(flops, s);
+  if (g.tile0[n] <= 512 && epi == TIMHIP_EPI_ADD_F32) {
+    // still under-filled with 64 x 128 tiles (the heads' input gradients: one long-K item dominates): 64 x 64 tiles double
+    // the blocks again
+    for (int i = 0; i < n; ++i) g.tile0[i + 1] = g.tile0[i] + ((items[i].M + 63) / 64) * ((items[i].N + 63) / 64);
+    for (int i = n; i < GG_MAX; ++i) g.tile0[i + 1] = g.tile0[n];
+    hipLaunchKernelGGL((gemm_nt_group_kernel<TIMHIP_EPI_ADD_F32, 64, 64, 2, 2, 64, 2>), dim3((unsigned)g.tile0[n]), dim3(256),
+                       (size_t)2 * (64 + 64) * 64 * 2, s, g);
+    return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+  }
   const dim3 grid((unsigned)g.tile0[n]);
   const size_t shmem = (size_t)2 * (64 + 128) * 64 * 2;
 #define GROUP(X) case X: hipLaunchKernelGGL((gemm_nt_group_kernel<X, 64, 128, 1, 4, 64, 2>), grid, dim3(256), shmem, s, g); break;
