@@ -29,7 +29,7 @@
  *     No exception crosses the ABI.
  *   - Layout: batch-first.  A window is S = F + Q token rows (F feature tokens first, then Q query
  *     tokens); activations are row-major [B*S, E].  "Operand dtype" T is bf16 for
- *     TIMHIP_PREC_BF16 / _BF16X3 and fp32 for TIMHIP_PREC_FP32.  Operand matrices are K-contiguous
+ *     TIMHIP_PREC_BF16, fp16 for TIMHIP_PREC_F16 and fp32 for TIMHIP_PREC_FP32 / _BF16X3 (which splits on the fly).  Operand matrices are K-contiguous
  *     with a leading dimension that is a multiple of 64 elements, zero padded.
  */
 #ifndef TIMHIP_H
@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 1
+#define TIMHIP_VERSION 2
 
 enum {
   TIMHIP_OK = 0,
@@ -53,7 +53,10 @@ enum {
   TIMHIP_EALIGN = -5        /* pointer or leading dimension not aligned */
 };
 
-enum { TIMHIP_PREC_BF16 = 0, TIMHIP_PREC_BF16X3 = 1, TIMHIP_PREC_FP32 = 2 };
+/* TIMHIP_PREC_F16: fp16 MFMA operands (v_mfma_f32_32x32x16_f16: the bf16 rate, 3 more mantissa bits), fp32 accumulation -
+ * the arithmetic of the reference's own GPU recipe (torch.cuda.amp fp16 autocast, recognition/scripts/train.py:82,197).
+ * Gradient operands are stored multiplied by a power of two (TimDesc.grad_scale; the weight-gradient outputs undo it). */
+enum { TIMHIP_PREC_BF16 = 0, TIMHIP_PREC_BF16X3 = 1, TIMHIP_PREC_FP32 = 2, TIMHIP_PREC_F16 = 3 };
 
 /* epilogue selector of the generic GEMM entry point (unit tests, heads) */
 enum {
@@ -88,6 +91,10 @@ typedef struct TimDesc {
   uint64_t seed;     /* Philox key for this step */
   int32_t layer;     /* layer index (part of the Philox stream id) */
   int32_t reserved;  /* flags: TIMHIP_DESC_* (0 by default) */
+  const float* grad_scale; /* backward of TIMHIP_PREC_F16: device {S, 1/S} as timhip_grad_scale writes them (NULL: S = 1).
+                              fp16 gradient operands (the T copies LayerNorm-backward writes, and everything the data chain
+                              derives from them) are stored multiplied by S; the fp32 gradient stream, the weight, bias
+                              and LayerNorm-parameter gradients are true-scale.  Ignored by the other precisions' forward */
 } TimDesc;
 /* TimDesc.reserved flags */
 #define TIMHIP_DESC_ATTN_FP32 1        /* run the attention in fp32 arithmetic (reference kernels) */
@@ -172,6 +179,10 @@ typedef struct TimEpi {
   const float* ln_stats;
   const float* ln_w;
   const float* ln_b;
+  /* optional device scalar: the accumulators are multiplied by *acc_scale before the epilogue (NULL = 1).  TIMHIP_PREC_F16
+   * keeps its gradient OPERANDS multiplied by a power of two S (timhip_grad_scale); an input-gradient GEMM whose result joins
+   * the fp32 gradient stream (TIMHIP_EPI_ADD_F32) passes 1/S here. */
+  const float* acc_scale;
 } TimEpi;
 
 /* n <= 6 independent small problems with the same epilogue as ONE launch (bf16; TIMHIP_EPI_STORE_F32, _ADD_F32, _STORE_T,
@@ -196,9 +207,16 @@ int timhip_transpose(int precision, const void* src, int rows, int cols, int lds
 int timhip_colsum(int precision, const void* src, int rows, int cols, int ld, float* out,
                   void* stream);
 
-/* fp32 -> T with optional dropout (p_drop > 0) and zero padding to ld */
+/* Gradient scale of the fp16 mode.  fp16 has 5 exponent bits: gradient operands would underflow (the reference's GPU recipe
+ * wraps its step in a GradScaler for that reason, recognition/scripts/train.py:82,355-363).  Here the scale is chosen per
+ * backward pass ON THE DEVICE from the cotangents entering it: S = 2^floor(log2(target / max|cot|)), out[0] = S,
+ * out[1] = 1/S (S = 1 when every cotangent is 0).  cot / counts: HOST arrays of n <= 8 device pointers / element counts;
+ * out: 4 floats in device memory, out[2..3] zero before the first call (scratch, left zero).  One launch, no host sync. */
+int timhip_grad_scale(const float* const* cot, const long long* counts, int n, float target, float* out, void* stream);
+
+/* fp32 -> T with optional dropout (p_drop > 0) and zero padding to ld; scale: optional device scalar multiplied in */
 int timhip_cast_rows(int precision, const float* src, int rows, int cols, int lds, void* dst, int ld,
-                     float p_drop, uint64_t seed, uint32_t site, void* stream);
+                     float p_drop, uint64_t seed, uint32_t site, const float* scale, void* stream);
 
 /* LayerNorm over the last dim of act(y): x = LN(act(y)) * w + b.
  * act: 0 none, 1 relu, 2 gelu(erf).  Writes x_f32 (may be null, row stride ldx, column
@@ -212,7 +230,7 @@ int timhip_layernorm_fwd(int precision, const float* y, int rows, int cols, int 
 int timhip_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
                          const float* stats, int rows, int cols, int act, const float* w,
                          float* dy_f32, int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed,
-                         uint32_t site, float* dgamma, float* dbeta, void* stream);
+                         uint32_t site, float* dgamma, float* dbeta, const float* t_scale, void* stream);
 
 /* structured attention over qkv[B*S, 3E] (T): token i attends to the F feature tokens and to
  * itself.  o[B*S,E] (T), lse[B,H,S] fp32. */
@@ -227,7 +245,7 @@ size_t timhip_attention_bwd_workspace_bytes(const TimDesc* d);
  * operand copies and the split-K fp32 partial slabs. */
 size_t timhip_wgrad_workspace_bytes(int precision, int Nout, int Kout, int M);
 int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout,
-                 int M, float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
+                 int M, float* dW, float* db, void* workspace, size_t workspace_bytes, const float* out_scale, void* stream);
 
 /* The same for n <= 8 Linear layers that share M (the four of one encoder layer), as ONE launch: their tile lists are
  * concatenated and the number of splits of the contraction is chosen for the total - at E = 1024, FF = 2048 the layer has
@@ -244,7 +262,7 @@ typedef struct TimWgradItem {
 } TimWgradItem;
 size_t timhip_wgrad_group_workspace_bytes(int precision, const TimWgradItem* items, int n, int M);
 int timhip_wgrad_group(int precision, const TimWgradItem* items, int n, int M, int accumulate, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       size_t workspace_bytes, const float* out_scale, void* stream);
 
 /* dx[r,c] = g[r,c] * keep-mask/(1-p): backward of the feature dropout applied by timhip_cast_rows */
 int timhip_dropout_rows_bwd(const float* g, int rows, int cols, int ldg, float* dx, int ldx,
@@ -255,7 +273,7 @@ int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const
                        const float* b, void* h, int ld, void* stream);
 /* dh: gradient w.r.t. the pre-activation of layer 1 (T).  dw[d,2] +=, db[d] +=, dt[rows,2] = (may be NULL) */
 int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const float* w,
-                       const void* dh, int ld, float* dw, float* db, float* dt, void* stream);
+                       const void* dh, int ld, float* dw, float* db, float* dt, const float* out_scale, void* stream);
 
 /* keep-mask (1/0 bytes) of a dropout site, as the kernels generate it: test hook */
 int timhip_dropout_mask(uint64_t seed, uint32_t site, float p, int rows, int cols, uint8_t* out,
@@ -346,7 +364,7 @@ int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, in
 int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, const int* n,
                               const float* const* d_rows, float* dx, void* stream);
 int timhip_cast_rows_many(int precision, int count, const float* const* src, const int* rows, const int* cols,
-                          void* const* dst, const int* ld, void* stream);
+                          void* const* dst, const int* ld, const float* scale, void* stream);
 
 /* ---------------------------------------------------------------- loss tail of the training step */
 /* Label-smoothed cross entropy under mixup, as recognition/scripts/train.py:46-49,218-316 applies it through

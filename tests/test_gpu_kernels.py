@@ -20,7 +20,9 @@ from tim_amd import _lib as L  # noqa: E402
 from tim_amd.functional import Runtime, _ru  # noqa: E402
 
 DEV = "cuda:0"
-PRECS = ["fp32", "bf16x3", "bf16"]
+PRECS = ["fp32", "bf16x3", "bf16", "fp16"]
+H16 = ["bf16", "fp16"]
+HALF_ULP = {"bf16": 2 ** -8, "fp16": 2 ** -11}   # relative rounding step of a stored 16-bit result
 
 
 def st():
@@ -42,7 +44,7 @@ def to_op(rt, x, ld=None):
 
 def tol(prec, ref):
     s = max(1.0, float(ref.detach().abs().max()))
-    return {"fp32": 1e-5, "bf16x3": 5e-5, "bf16": 1e-3}[prec] * s
+    return {"fp32": 1e-5, "bf16x3": 5e-5, "bf16": 1e-3, "fp16": 1.5e-4}[prec] * s
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -66,7 +68,7 @@ def test_gemm_store(prec, M, N, K):
     torch.cuda.synchronize()
     got = outT.float().cpu()
     assert (got[:, N:] == 0).all()
-    lim = tol(prec, ref) + (0.0 if prec != "bf16" else 2 ** -8 * float(ref.abs().max()))
+    lim = tol(prec, ref) + HALF_ULP.get(prec, 0.0) * float(ref.abs().max())
     assert (got[:, :N].double() - ref.clamp(min=0)).abs().max().item() <= lim
 
 
@@ -117,7 +119,7 @@ def test_gemm_fused_epilogues(prec, M, N, K):
     h = torch.zeros((M, N), dtype=rt.op_dtype, device=DEV)
     rt.gemm(L.EPI_GELU_DROP_T2, A, B, M, N, K, h, N, out1=u, ld1=N, bias=bias, p_drop=p, seed=seed, site=site)
     torch.cuda.synchronize()
-    rnd_tol = 0.0 if prec != "bf16" else 2 ** -8 * float(lin.abs().max()) * 2
+    rnd_tol = HALF_ULP.get(prec, 0.0) * float(lin.abs().max()) * 2
     assert (u.float().cpu().double() - lin).abs().max().item() <= tol(prec, lin) + rnd_tol
     href = O._gelu(lin) * mk / (1 - p)
     assert (h.float().cpu().double() - href).abs().max().item() <= tol(prec, href) + rnd_tol
@@ -203,11 +205,12 @@ def test_gemm_residual_is_layernorm(prec, M, N, K, p):
     assert (out - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("epi", ["store_f32", "add_f32"])
-def test_gemm_group(epi):
+def test_gemm_group(epi, prec):
     """several independent small problems as one grouped launch == one launch each (the classification heads' shapes: ragged
     N, different M, ragged K)"""
-    rt = Runtime("bf16")
+    rt = Runtime(prec)
     shapes = [(960, 97, 1024), (960, 300, 1024), (960, 3806, 1024), (640, 44, 1024), (70, 136, 192), (1, 5, 24)]
     items, refs = [], []
     for i, (M, N, K) in enumerate(shapes):
@@ -230,12 +233,13 @@ def test_gemm_group(epi):
         assert torch.equal(it["out0"], ref)
 
 
+@pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("epi", ["gelu_drop", "dgelu"])
 @pytest.mark.parametrize("M,N", [(9925, 2048), (130, 72), (64, 256)])
-def test_gemm_dropout_keep_bits(epi, M, N):
+def test_gemm_dropout_keep_bits(epi, M, N, prec):
     """the FFN epilogues with the keep-bits drawn ahead of time (TimEpi.mask: what LayerNorm-1 writes inside the layer) ==
     the same epilogues drawing Philox themselves; the bits here come from the timhip_dropout_mask test hook"""
-    rt = Runtime("bf16")
+    rt = Runtime(prec)
     K, p, seed, site = 128, 0.3, 1234, 16 + 8 + 3
     A, _ = to_op(rt, rnd(M, K, seed=1))
     B, _ = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))
@@ -249,9 +253,9 @@ def test_gemm_dropout_keep_bits(epi, M, N):
     bits = (padded.view(M, ldm, 8).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
     outs = []
     for mask in (None, bits):
-        o0 = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV)
-        o1 = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV)
-        aux = (rnd(M, ld, seed=9)).to(DEV).bfloat16()
+        o0 = torch.zeros((M, ld), dtype=rt.op_dtype, device=DEV)
+        o1 = torch.zeros((M, ld), dtype=rt.op_dtype, device=DEV)
+        aux = (rnd(M, ld, seed=9)).to(DEV).to(rt.op_dtype)
         kw = dict(p_drop=p, seed=seed, site=site, mask=mask, ldmask=ldm)
         if epi == "gelu_drop":
             rt.gemm(L.EPI_GELU_DROP_T2, A, B, M, N, K, o0, ld, out1=o1, ld1=ld, bias=bias, **kw)
@@ -263,6 +267,7 @@ def test_gemm_dropout_keep_bits(epi, M, N):
     assert (outs[0][0][:, :N] == 0).float().mean().item() > p * 0.8       # dropout really happened
 
 
+@pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("accumulate", [True, False])
 @pytest.mark.parametrize("M,shapes", [
     (523, [(200, 72), (64, 136), (130, 128)]),                       # ragged tiles, few tiles: the contraction is split
@@ -270,9 +275,9 @@ def test_gemm_dropout_keep_bits(epi, M, N):
     (9920, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # C2a: 512 tiles, no split, direct writes
     (4100, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # same, ragged last step of 64 rows
 ])
-def test_wgrad_group(M, shapes, accumulate):
+def test_wgrad_group(M, shapes, accumulate, prec):
     """several Linear weight gradients sharing M in one launch == the per-layer reference; biases optional"""
-    rt = Runtime("bf16")
+    rt = Runtime(prec)
     items, refs = [], []
     for i, (N, K) in enumerate(shapes):
         dY, dYr = to_op(rt, rnd(M, N, seed=20 + i) * 0.25)
@@ -311,7 +316,7 @@ def test_layernorm_fwd_bwd(prec, cols, act):
     a = {0: lambda t: t, 1: torch.relu, 2: O._gelu}[act](y64)
     ref = O._ln(a, w64, b64)
     assert (xf.cpu().double() - ref.detach()).abs().max().item() <= 2e-5
-    assert (xt[:, :cols].float().cpu().double() - ref.detach()).abs().max().item() <= (2e-5 if prec != "bf16" else 0.05)
+    assert (xt[:, :cols].float().cpu().double() - ref.detach()).abs().max().item() <= {"bf16": 0.05, "fp16": 0.01}.get(prec, 2e-5)
     (ref * dxo.double()).sum().backward()
     dyf = torch.empty((rows, cols), device=DEV)
     dg = torch.zeros(cols, device=DEV)
@@ -343,7 +348,7 @@ def _attn_case(prec, B, S, F, H, Dh, p=0.0, seed=11):
     x = qkvr.double().view(B, S, 3, H, Dh).requires_grad_(True)
     q, k, v = [x[:, :, i].transpose(1, 2) for i in range(3)]
     ref = O.attention_structured(q, k, v, F, mask, p).transpose(1, 2).reshape(B * S, E)
-    rnd_tol = 0.0 if prec != "bf16" else 2 ** -8 * float(ref.abs().max())
+    rnd_tol = HALF_ULP.get(prec, 0.0) * float(ref.abs().max())
     err = (o.float().cpu().double() - ref.detach()).abs().max().item()
     assert err <= tol(prec, ref) + rnd_tol, ("fwd", err)
     # backward
@@ -355,7 +360,7 @@ def _attn_case(prec, B, S, F, H, Dh, p=0.0, seed=11):
     L.call("timhip_attention_bwd", C.byref(desc), L.ptr(qkv), L.ptr(o), L.ptr(lse), L.ptr(do), L.ptr(dqkv),
            L.ptr(ws), wsb, st())
     torch.cuda.synchronize()
-    rnd_tol = 0.0 if prec != "bf16" else 2 ** -7 * float(gref.abs().max())
+    rnd_tol = 2 * HALF_ULP.get(prec, 0.0) * float(gref.abs().max())
     err = (dqkv.float().cpu().double() - gref).abs().max().item()
     assert err <= 5 * tol(prec, gref) + rnd_tol, ("bwd", err)
 
@@ -388,3 +393,50 @@ def test_dropout_mask_statistics_and_determinism():
         # no row/column structure
         assert (m1.float().mean(0) - (1 - p)).abs().max().item() < 0.2
         assert abs(np.corrcoef(m1.cpu().numpy().ravel()[:-1], m1.cpu().numpy().ravel()[1:])[0, 1]) < 0.01
+
+
+def test_grad_scale_kernel():
+    """timhip_grad_scale: S = 2^floor(log2(target / max|cot|)) over several tensors, computed on the device; scratch left zero"""
+    rt = Runtime("fp16")
+    a = (rnd(1000, 37, seed=1) * 3e-4).to(DEV)
+    b = (rnd(5, seed=2) * 1e-6).to(DEV)
+    c = torch.zeros(0, device=DEV)
+    for tensors in ([a, b, c], [b], [a[:7, :5].contiguous()]):
+        gs = rt.grad_scale(tensors, DEV)
+        torch.cuda.synchronize()
+        amax = max(float(t.abs().max()) for t in tensors if t.numel())
+        S = 2.0 ** math.floor(math.log2(rt.grad_scale_target / amax))
+        assert gs.tolist() == [S, 1.0 / S, 0.0, 0.0], (gs.tolist(), S)
+    gs = rt.grad_scale([torch.zeros(64, device=DEV)], DEV)
+    torch.cuda.synchronize()
+    assert gs.tolist()[:2] == [1.0, 1.0]
+    assert Runtime("bf16").grad_scale([a], DEV) is None
+
+
+def test_fp16_scaled_gradient_operands():
+    """fp16 gradient operands stored times S: cast (x S) -> input-gradient GEMM (acc x 1/S) and weight-gradient GEMM (out x 1/S)
+    reproduce the unscaled products of values that fp16 alone would flush to zero"""
+    rt = Runtime("fp16")
+    M, N, K = 300, 256, 128
+    g = (rnd(M, N, seed=3) * 1e-7).to(DEV)          # below the fp16 subnormal range (6e-8) for most elements
+    W = rnd(K, N, seed=4, scale=N ** -0.5)          # [K, N]: the transposed copy an input-gradient product reads
+    X = rnd(M, K, seed=5)
+    Wt, Wr = to_op(rt, W)
+    Xt, Xr = to_op(rt, X)
+    gs = rt.grad_scale([g], DEV)
+    gT = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    L.call("timhip_cast_rows", rt.prec, L.ptr(g), M, N, N, L.ptr(gT), N, 0.0, 0, 0, L.ptr(gs), st())
+    dx = torch.empty((M, K), device=DEV)
+    rt.gemm(L.EPI_ADD_F32, gT, Wt, M, K, N, dx, K, acc_scale=L.ptr(gs) + 4)
+    dW = torch.zeros((N, K), device=DEV)
+    db = torch.zeros((N,), device=DEV)
+    rt.wgrad(gT, N, Xt, K, M, dW, db, out_scale=L.ptr(gs) + 4)
+    torch.cuda.synchronize()
+    S = gs[0].item()
+    gq = (g.cpu().double() * S).to(torch.float16).double() / S     # what the scaled fp16 operand holds
+    ref_dx = gq @ Wr.double().t()
+    ref_dW = gq.t() @ Xr.double()
+    assert (dx.cpu().double() - ref_dx).abs().max().item() <= 1e-5 * ref_dx.abs().max().item()
+    assert (dW.cpu().double() - ref_dW).abs().max().item() <= 1e-5 * ref_dW.abs().max().item()
+    assert (db.cpu().double() - gq.sum(0)).abs().max().item() <= 1e-5 * gq.sum(0).abs().max().item()
+    assert ref_dx.abs().max().item() > 0 and float(g.cpu().to(torch.float16).abs().max()) < 2e-6

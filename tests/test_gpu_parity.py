@@ -148,6 +148,32 @@ def test_tiny_bf16_vs_oracle(fname, im, dm, vn, nv, na):
             assert v.abs().max().item() == 0.0, k
 
 
+@pytest.mark.parametrize("fname,im,dm,vn,nv,na", H.rec_golden_cases())
+def test_tiny_fp16_vs_oracle(fname, im, dm, vn, nv, na):
+    """fp16 mode on every modality combination (2 layers): outputs within 1e-3 of the fp32 oracle, every gradient finite
+    and within the fp16 noise class of the fp32 oracle's (the gradient operands are scaled per pass on the device)"""
+    cfg = H.tiny_cfg("recognition", im, dm, vn)
+    sd, inp = H.synth_torch(cfg, 3, nv, na, seed=1, dtype=torch.float32)
+    m = build(cfg, "fp16", sd)
+    with torch.no_grad():
+        outs0 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+    for scale in (1.0, 1e-6):   # cotangents of the size a mean-reduced loss hands back: the scale choice must absorb it
+        R = {k: v * scale for k, v in H.cotangents(cfg, 3, nv, na, outs0, seed=1, dtype=torch.float32).items()}
+        m.zero_grad()
+        res = run_model(m, inp, nv, na, True, R)
+        o_32, te_32, g_32, gi_32 = oracle_run(cfg, sd, inp, nv, na, R, torch.float32)
+        for k, v in res["outs"].items():
+            assert maxerr(v, o_32[k]) <= TOL_BF16 * max(1.0, amax(o_32[k])), (k, maxerr(v, o_32[k]))
+        for k, v in res["grads"].items():
+            assert torch.isfinite(v).all(), k
+            if k in g_32:
+                assert relerr(v, g_32[k]) <= 1e-2, (k, scale, relerr(v, g_32[k]))
+            else:
+                assert v.abs().max().item() == 0.0, k
+        for k, v in res["gin"].items():
+            assert relerr(v, gi_32[k]) <= 1e-2, (k, scale, relerr(v, gi_32[k]))
+
+
 # ------------------------------------------------------------------------------------------------
 # real model sizes (BASELINE configs[0] and configs[1] shapes at small batch)
 # ------------------------------------------------------------------------------------------------
@@ -202,6 +228,43 @@ def test_named_config_bf16(cname, B, nv, na):
         rms = (v.double() - o32[k].double()).pow(2).mean().sqrt().item()
         rms_pred = (obf[k].double() - o32[k].double()).pow(2).mean().sqrt().item()
         assert rms <= 1.5 * rms_pred + 1e-4, (k, rms, rms_pred)
+
+
+@pytest.mark.parametrize("cname,B,nv,na", [("C1", 2, 10, 0), ("C2a", 2, 15, 10), ("C3", 2, 15, 10)])
+def test_named_config_fp16_meets_1e3(cname, B, nv, na):
+    """precision="fp16" - the mode bench.py times: fp16 MFMA operands in the encoder layers and embedders (the reference's own
+    AMP arithmetic, scripts/train.py:82,197), split-operand kernels for the time MLP and the classification heads.  north_star's
+    bound for the 16-bit path: every per-query logit within 1e-3 of the fp32 reference arithmetic, on the 6-layer models;
+    gradients (fp16 operands scaled per pass on the device) against the fp32 oracle's."""
+    g = np.load(os.path.join(H.GOLDEN, "%s_rec_summary.npz" % cname))
+    cfg = named_config(cname)
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
+    m = build(cfg, "fp16", sd)
+    with torch.no_grad():
+        o32 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+    R = H.cotangents(cfg, B, nv, na, o32, seed=2, dtype=torch.float32)
+    res = run_model(m, inp, nv, na, True, R)
+    worst = 0.0
+    for k, v in res["outs"].items():
+        if k == "feats":
+            assert maxerr(v, o32[k]) <= 5e-3, (k, maxerr(v, o32[k]))
+            continue
+        worst = max(worst, maxerr(v, o32[k]))
+        assert maxerr(v, o32[k]) <= TOL_BF16, (k, maxerr(v, o32[k]))
+        assert maxerr(v[:, :8], torch.from_numpy(g["out/%s/slice" % k])) <= TOL_BF16, k   # the imported reference's own logits
+    print("fp16 worst |dlogit| %s: %.3g" % (cname, worst))
+    _, _, g32, gin32 = oracle_run(cfg, sd, inp, nv, na, R, torch.float32)
+    wc, wr = 1.0, 0.0
+    for k, v in res["grads"].items():
+        a, b = v.double().flatten(), g32[k].double().flatten()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        wc, wr = min(wc, cos), max(wr, relerr(v, g32[k]))
+        assert torch.isfinite(v).all(), k
+        assert cos >= 0.9995, (k, cos)
+        assert relerr(v, g32[k]) <= 0.06, (k, relerr(v, g32[k]))
+    for k, v in res["gin"].items():
+        assert relerr(v, gin32[k]) <= 0.06, (k, relerr(v, gin32[k]))
+    print("fp16 grads %s: min cos %.6f, max rel err %.3g" % (cname, wc, wr))
 
 
 @pytest.mark.parametrize("cname,B,nv,na", [("C1", 2, 10, 0), ("C2a", 2, 15, 10)])

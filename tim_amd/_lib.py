@@ -9,8 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtimhip.so")
 
-PREC_BF16, PREC_BF16X3, PREC_FP32 = 0, 1, 2
-PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32}
+PREC_BF16, PREC_BF16X3, PREC_FP32, PREC_F16 = 0, 1, 2, 3
+PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32, "fp16": PREC_F16}
+H16 = (PREC_BF16, PREC_F16)   # 16-bit operand storage (the MFMA GEMM / attention / transposing weight-gradient kernels)
 
 (EPI_STORE_T, EPI_RELU_T, EPI_STORE_F32, EPI_GELU_DROP_T2, EPI_DROP_RES_F32, EPI_ADD_F32,
  EPI_DGELU_T, EPI_DRELU_T, EPI_ATOMIC_F32, EPI_SIGMOID_F32, EPI_DRELU_F32IN_T, EPI_GELU_DROP_G2, EPI_MULAUX_T) = range(13)
@@ -23,7 +24,8 @@ vp, i32, u32, u64, f32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_
 
 class TimDesc(C.Structure):
     _fields_ = [("B", i32), ("S", i32), ("F", i32), ("d", i32), ("E", i32), ("H", i32), ("FF", i32),
-                ("precision", i32), ("p_drop", f32), ("seed", u64), ("layer", i32), ("reserved", i32)]
+                ("precision", i32), ("p_drop", f32), ("seed", u64), ("layer", i32), ("reserved", i32),
+                ("grad_scale", vp)]
 
 
 _LP = ["in_w", "in_wt", "out_w", "out_wt", "l1_w", "l1_wt", "l2_w", "l2_wt",
@@ -54,7 +56,7 @@ class TimEpi(C.Structure):
     _fields_ = [("out0", vp), ("out1", vp), ("bias", vp), ("res", vp), ("aux", vp),
                 ("ld0", i32), ("ld1", i32), ("ldres", i32), ("ldaux", i32),
                 ("p_drop", f32), ("site", u32), ("seed", u64), ("mask", vp), ("ldmask", i32), ("reserved", i32),
-                ("ln_stats", vp), ("ln_w", vp), ("ln_b", vp)]
+                ("ln_stats", vp), ("ln_w", vp), ("ln_b", vp), ("acc_scale", vp)]
 
 
 class TimGemmItem(C.Structure):
@@ -73,21 +75,21 @@ _SIGS = {
     "timhip_gemm_nt": (C.c_int, [i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(TimEpi), i32, vp]),
     "timhip_gemm_nt_group": (C.c_int, [i32, i32, vp, i32, vp]),
     "timhip_wgrad_workspace_bytes": (sz, [i32, i32, i32, i32]),
-    "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
+    "timhip_wgrad": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, sz, vp, vp]),
     "timhip_wgrad_group_workspace_bytes": (sz, [i32, vp, i32, i32]),
-    "timhip_wgrad_group": (C.c_int, [i32, vp, i32, i32, i32, vp, sz, vp]),
+    "timhip_wgrad_group": (C.c_int, [i32, vp, i32, i32, i32, vp, sz, vp, vp]),
     "timhip_transpose": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, vp]),
     "timhip_colsum": (C.c_int, [i32, vp, i32, i32, i32, vp, vp]),
-    "timhip_cast_rows": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, f32, u64, u32, vp]),
+    "timhip_cast_rows": (C.c_int, [i32, vp, i32, i32, i32, vp, i32, f32, u64, u32, vp, vp]),
     "timhip_dropout_rows_bwd": (C.c_int, [vp, i32, i32, i32, vp, i32, f32, u64, u32, vp]),
     "timhip_layernorm_fwd": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, vp, vp]),
     "timhip_layernorm_bwd": (C.c_int, [i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, i32,
-                                       f32, u64, u32, vp, vp, vp]),
+                                       f32, u64, u32, vp, vp, vp, vp]),
     "timhip_attention_fwd": (C.c_int, [C.POINTER(TimDesc), vp, vp, vp, vp]),
     "timhip_attention_bwd": (C.c_int, [C.POINTER(TimDesc), vp, vp, vp, vp, vp, vp, sz, vp]),
     "timhip_attention_bwd_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_time_l1_fwd": (C.c_int, [i32, vp, i32, i32, vp, vp, vp, i32, vp]),
-    "timhip_time_l1_bwd": (C.c_int, [i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
+    "timhip_time_l1_bwd": (C.c_int, [i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "timhip_dropout_mask": (C.c_int, [u64, u32, f32, i32, i32, vp, vp]),
     "timhip_dropout_salt": (C.c_int, [vp]),
     "timhip_layer_fwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp, vp, vp, sz, vp]),
@@ -124,7 +126,8 @@ _SIGS = {
     "timhip_ln_partials_reduce": (C.c_int, [vp, i32, i32, i32, vp, vp, vp]),
     "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
-    "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp]),
+    "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),
 }
 
 _lib = None

@@ -43,7 +43,7 @@ struct WgradWs { size_t tA, tB, slab, total; };
 WgradWs wgrad_ws(int prec, int Nout, int Kout, int M) {
   const size_t Mp = round_up(M, 64), ts = opsize(prec);
   WgradWs w;
-  if (prec == TIMHIP_PREC_BF16) {  // transposing-read kernel: no operand copies
+  if (h16_storage(prec)) {  // transposing-read kernel: no operand copies
     w.tA = w.tB = w.slab = 0;
     w.total = tim_wgrad_tn_ws(Nout, Kout, M);
     return w;
@@ -81,7 +81,7 @@ WsLayout ws_layout(const TimDesc& d) {
     size_t w3 = wgrad_ws(d.precision, d.FF, d.E, (int)M).total;
     if (w2 > wg) wg = w2;
     if (w3 > wg) wg = w3;
-    if (d.precision == TIMHIP_PREC_BF16) {   // the grouped launch of timhip_layer_bwd_weights (slabs only when it splits)
+    if (h16_storage(d.precision)) {   // the grouped launch of timhip_layer_bwd_weights (slabs only when it splits)
       const TimWgradItem it[4] = {{nullptr, nullptr, nullptr, nullptr, d.E, d.FF, d.E, d.FF},
                                   {nullptr, nullptr, nullptr, nullptr, d.FF, d.E, d.FF, d.E},
                                   {nullptr, nullptr, nullptr, nullptr, d.E, d.E, d.E, d.E},
@@ -103,8 +103,7 @@ WsLayout ws_layout(const TimDesc& d) {
 int check_layer_desc(const TimDesc& d) {
   if (d.B <= 0 || d.S <= 0 || d.F <= 0 || d.F > d.S || d.E <= 0 || d.H <= 0 || d.FF <= 0) return TIMHIP_EINVAL;
   if (d.E % 64 || d.FF % 64 || d.E % d.H) return TIMHIP_EUNSUPPORTED;
-  if (d.precision != TIMHIP_PREC_BF16 && d.precision != TIMHIP_PREC_FP32 && d.precision != TIMHIP_PREC_BF16X3)
-    return TIMHIP_EUNSUPPORTED;
+  if (!valid_precision(d.precision)) return TIMHIP_EUNSUPPORTED;
   if (d.p_drop < 0.f || d.p_drop >= 1.f) return TIMHIP_EINVAL;
   return TIMHIP_OK;
 }
@@ -115,6 +114,7 @@ TimEpi epi0() {
   e.ld0 = e.ld1 = e.ldres = e.ldaux = 0; e.p_drop = 0.f; e.site = 0; e.seed = 0;
   e.mask = nullptr; e.ldmask = 0; e.reserved = 0;
   e.ln_stats = e.ln_w = e.ln_b = nullptr;
+  e.acc_scale = nullptr;
   return e;
 }
 
@@ -122,12 +122,12 @@ TimEpi epi0() {
 // Both operands are transposed into K(=M)-contiguous copies, the product runs split-K into fp32
 // slabs (plain coalesced stores, no atomics) and one reduce kernel adds the slabs into dW.
 int wgrad(int prec, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
-          void* ws, size_t ws_bytes, hipStream_t s, int accumulate = 1) {
+          void* ws, size_t ws_bytes, hipStream_t s, int accumulate = 1, const float* out_scale = nullptr) {
   const int Mp = round_up(M, 64);
   const WgradWs W = wgrad_ws(prec, Nout, Kout, M);
   if (ws_bytes < W.total) return TIMHIP_EWORKSPACE;
-  if (prec == TIMHIP_PREC_BF16) return tim_wgrad_tn_bf16(dY, ldy, Nout, X, ldx, Kout, M, dW, db, ws, ws_bytes, s, accumulate);
-  if (!accumulate) return TIMHIP_EUNSUPPORTED;   // the fp32 / bf16x3 route accumulates into dW
+  if (h16_storage(prec)) return tim_wgrad_tn_h16(prec, dY, ldy, Nout, X, ldx, Kout, M, dW, db, ws, ws_bytes, s, accumulate, out_scale);
+  if (!accumulate || out_scale) return TIMHIP_EUNSUPPORTED;   // the fp32 / bf16x3 route accumulates into dW, unscaled
   char* w = (char*)ws;
   void* tA = w + W.tA; void* tB = w + W.tB; float* slab = (float*)(w + W.slab);
   int rc;
@@ -187,19 +187,18 @@ int timhip_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n
 }
 
 size_t timhip_wgrad_group_workspace_bytes(int precision, const TimWgradItem* items, int n, int M) {
-  return (precision == TIMHIP_PREC_BF16 && items && n > 0) ? tim_wgrad_group_ws(items, n, M) : 0;
+  return (h16_storage(precision) && items && n > 0) ? tim_wgrad_group_ws(items, n, M) : 0;
 }
 
 int timhip_wgrad_group(int precision, const TimWgradItem* items, int n, int M, int accumulate, void* workspace,
-                       size_t workspace_bytes, void* stream) {
-  if (precision != TIMHIP_PREC_BF16) return TIMHIP_EUNSUPPORTED;
-  return tim_wgrad_group_bf16(items, n, M, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+                       size_t workspace_bytes, const float* out_scale, void* stream) {
+  return tim_wgrad_group_h16(precision, items, n, M, accumulate, workspace, workspace_bytes, out_scale, (hipStream_t)stream);
 }
 
 int timhip_wgrad(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M,
-                 float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+                 float* dW, float* db, void* workspace, size_t workspace_bytes, const float* out_scale, void* stream) {
   if (!dY || !X || !dW || !workspace) return TIMHIP_EINVAL;
-  return wgrad(precision, dY, ldy, Nout, X, ldx, Kout, M, dW, db, workspace, workspace_bytes, (hipStream_t)stream);
+  return wgrad(precision, dY, ldy, Nout, X, ldx, Kout, M, dW, db, workspace, workspace_bytes, (hipStream_t)stream, 1, out_scale);
 }
 
 // The fp32 residual stream is only ever READ by the "+ residual" epilogues, and each of them can normalise on the fly
@@ -319,24 +318,28 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
   void* Tc = ws + W.Tc;
   char* yb = (char*)dy;
   void* df = yb + Y.df; void* du = yb + Y.du; void* da = yb + Y.da; void* dqkv = yb + Y.dqkv;
+  // fp16: the gradient OPERANDS (df, du, da, Tc, dqkv and the attention scratch) carry the factor S = grad_scale[0]; it enters
+  // with the T copies LayerNorm-backward writes and leaves where an input-gradient product joins the fp32 stream
+  const float* gs_in = (prec == TIMHIP_PREC_F16 && d.grad_scale) ? d.grad_scale : nullptr;
+  const float* gs_out = gs_in ? gs_in + 1 : nullptr;
 
   // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
   if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, df, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b,
-                              g->ln_partials ? g->ln_partials : (float*)(ws + W.lnp), s, g->ln_partials != nullptr))) return rc;
+                              g->ln_partials ? g->ln_partials : (float*)(ws + W.lnp), s, g->ln_partials != nullptr, gs_in))) return rc;
   // du = (df W2) * [dropout-mask * gelu'(pre-activation)]
   TimEpi e = epi0();
   e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;   // u = dropmask * gelu'(pre-activation), written by the forward
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_MULAUX_T, df, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
   // dx1 = du W1 + dy2   (residual branch)
   e = epi0();
-  e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E;
+  e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E; e.acc_scale = gs_out;
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
   // norm1 backward -> dy1 (fp32) and da = dropout1-mask * dy1 (T)
   if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, da, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b,
                               g->ln_partials ? g->ln_partials + tim_layernorm_bwd_ws(M, E) / sizeof(float) : (float*)(ws + W.lnp), s,
-                              g->ln_partials != nullptr))) return rc;
+                              g->ln_partials != nullptr, gs_in))) return rc;
   // do = da Wo
   e = epi0();
   e.out0 = Tc; e.ld0 = E;
@@ -345,7 +348,7 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
   if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, dqkv, ws + W.attn, W.lnp - W.attn, s))) return rc;
   // dx_in = dqkv Win + dy1
   e = epi0();
-  e.out0 = dx_in; e.ld0 = E; e.res = f32a; e.ldres = E;
+  e.out0 = dx_in; e.ld0 = E; e.res = f32a; e.ldres = E; e.acc_scale = gs_out;
   return tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, dqkv, 3 * E, w->in_wt, 3 * E, M, E, 3 * E, e, 1, s);
 }
 
@@ -364,19 +367,20 @@ int timhip_layer_bwd_weights(const TimDesc* dp, const void* x_in_T, const void* 
   // linear2: dW2 += df^T h ; linear1: dW1 += du^T x1 ; out-proj: dWo += da^T o ; in-proj: dWin += dqkv^T x_in
   // (TIMHIP_DESC_WGRAD_OVERWRITE: "=" instead of "+=": the gradient buffers are neither zero-filled nor read)
   const int acc = (d.reserved & TIMHIP_DESC_WGRAD_OVERWRITE) ? 0 : 1;
-  if (prec == TIMHIP_PREC_BF16 && !(d.reserved & TIMHIP_DESC_WGRAD_SEPARATE) && ((size_t)E * E) % 4 == 0 && ((size_t)E * FF) % 4 == 0) {
+  const float* gs_out = (prec == TIMHIP_PREC_F16 && d.grad_scale) ? d.grad_scale + 1 : nullptr;
+  if (h16_storage(prec) && !(d.reserved & TIMHIP_DESC_WGRAD_SEPARATE) && ((size_t)E * E) % 4 == 0 && ((size_t)E * FF) % 4 == 0) {
     // one grouped launch (wgrad.hip): 12 E^2 / 128^2 tiles with FF = 2E, i.e. 512 at E = 1024 - the contraction is not split
     const TimWgradItem it[4] = {
         {yb + Y.df, sv + L.h, g->l2_w, g->l2_b, E, FF, E, FF},
         {yb + Y.du, sv + L.x1t, g->l1_w, g->l1_b, FF, E, FF, E},
         {yb + Y.da, sv + L.o, g->out_w, g->out_b, E, E, E, E},
         {yb + Y.dqkv, x_in_T, g->in_w, g->in_b, 3 * E, E, 3 * E, E}};
-    return tim_wgrad_group_bf16(it, 4, M, acc, workspace, workspace_bytes, s);
+    return tim_wgrad_group_h16(prec, it, 4, M, acc, workspace, workspace_bytes, gs_out, s);
   }
-  if ((rc = wgrad(prec, yb + Y.df, E, E, sv + L.h, FF, FF, M, g->l2_w, g->l2_b, workspace, workspace_bytes, s, acc))) return rc;
-  if ((rc = wgrad(prec, yb + Y.du, FF, FF, sv + L.x1t, E, E, M, g->l1_w, g->l1_b, workspace, workspace_bytes, s, acc))) return rc;
-  if ((rc = wgrad(prec, yb + Y.da, E, E, sv + L.o, E, E, M, g->out_w, g->out_b, workspace, workspace_bytes, s, acc))) return rc;
-  return wgrad(prec, yb + Y.dqkv, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, workspace, workspace_bytes, s, acc);
+  if ((rc = wgrad(prec, yb + Y.df, E, E, sv + L.h, FF, FF, M, g->l2_w, g->l2_b, workspace, workspace_bytes, s, acc, gs_out))) return rc;
+  if ((rc = wgrad(prec, yb + Y.du, FF, FF, sv + L.x1t, E, E, M, g->l1_w, g->l1_b, workspace, workspace_bytes, s, acc, gs_out))) return rc;
+  if ((rc = wgrad(prec, yb + Y.da, E, E, sv + L.o, E, E, M, g->out_w, g->out_b, workspace, workspace_bytes, s, acc, gs_out))) return rc;
+  return wgrad(prec, yb + Y.dqkv, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, workspace, workspace_bytes, s, acc, gs_out);
 }
 
 // single-stream form: data chain followed by the weight gradients

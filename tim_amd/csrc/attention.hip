@@ -254,7 +254,7 @@ int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hi
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse) return TIMHIP_EINVAL;
-  if (d.precision == TIMHIP_PREC_BF16 && !(d.reserved & 1)) {  // reserved bit 0: force the fp32-arithmetic kernels
+  if (h16_storage(d.precision) && !(d.reserved & 1)) {  // reserved bit 0: force the fp32-arithmetic kernels
     rc = tim_attention_fwd_mfma(d, qkv, o, lse, s);
     if (rc != TIMHIP_EUNSUPPORTED) return rc;
   }
@@ -265,13 +265,9 @@ int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hi
   const size_t lds = simple_lds(d, 1);
   if (lds > 160 * 1024) return TIMHIP_EUNSUPPORTED;
   AttnArgs a = make_args(d);
-  if (f32_storage(d.precision)) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_simple<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_fwd_simple<float>, dim3(d.B * d.H), dim3(256), lds, s, (const float*)qkv, (float*)o, lse, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_simple<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_fwd_simple<bf16_t>, dim3(d.B * d.H), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse, a);
-  }
+  DISPATCH_T(d.precision,
+    (void)hipFuncSetAttribute((const void*)attn_fwd_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd_simple<T>, dim3(d.B * d.H), dim3(256), lds, s, (const T*)qkv, (T*)o, lse, a));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
@@ -289,7 +285,7 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse || !d_o || !dqkv || !ws) return TIMHIP_EINVAL;
-  if (d.precision == TIMHIP_PREC_BF16 && !(d.reserved & 1)) {
+  if (h16_storage(d.precision) && !(d.reserved & 1)) {
     if (!(d.reserved & 2)) {  // reserved bit 1: force the single-kernel MFMA backward
       rc = tim_attention_bwd2_mfma(d, qkv, o, lse, d_o, dqkv, ws, ws_bytes, s);
       if (rc != TIMHIP_EUNSUPPORTED) return rc;
@@ -305,15 +301,10 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
   const size_t lds = simple_lds(d, 2);
   if (lds > 160 * 1024) return TIMHIP_EUNSUPPORTED;
   AttnArgs a = make_args(d);
-  if (f32_storage(d.precision)) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_simple<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_simple<float>, dim3(d.B * d.H), dim3(256), lds, s, (const float*)qkv, (const float*)o,
-                       lse, (const float*)d_o, (float*)dqkv, (float*)ws, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_simple<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_simple<bf16_t>, dim3(d.B * d.H), dim3(256), lds, s, (const bf16_t*)qkv,
-                       (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dqkv, (float*)ws, a);
-  }
+  DISPATCH_T(d.precision,
+    (void)hipFuncSetAttribute((const void*)attn_bwd_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_simple<T>, dim3(d.B * d.H), dim3(256), lds, s, (const T*)qkv, (const T*)o, lse, (const T*)d_o,
+                       (T*)dqkv, (float*)ws, a));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

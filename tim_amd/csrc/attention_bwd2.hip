@@ -36,11 +36,11 @@ __device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int
   return c == 0 ? k[0] : (c == 1 ? k[1] : (c == 2 ? k[2] : k[3]));
 }
 
-template <int DH, int NJB>
-__global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
-                                                     const float* __restrict__ lse, const bf16_t* __restrict__ d_o,
-                                                     bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dS_scr,
-                                                     bf16_t* __restrict__ Pt_scr, AttnArgsM a) {
+template <typename HT, int DH, int NJB>
+__global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv, const HT* __restrict__ o,
+                                                     const float* __restrict__ lse, const HT* __restrict__ d_o,
+                                                     HT* __restrict__ dqkv, HT* __restrict__ dS_scr,
+                                                     HT* __restrict__ Pt_scr, AttnArgsM a) {
   constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
@@ -50,13 +50,13 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t ld = (size_t)3 * E;
-  const bf16_t* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
-  bf16_t* dbase = dqkv + (size_t)b * S * ld + (size_t)h * DH;
-  const bf16_t* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
-  const bf16_t* obase = o + (size_t)b * S * E + (size_t)h * DH;
+  const HT* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
+  HT* dbase = dqkv + (size_t)b * S * ld + (size_t)h * DH;
+  const HT* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
+  const HT* obase = o + (size_t)b * S * E + (size_t)h * DH;
   const float* lsebase = lse + ((size_t)b * a.H + h) * S;
-  bf16_t* dSs = dS_scr + (size_t)blockIdx.x * S * FP;
-  bf16_t* Pts = Pt_scr + (size_t)blockIdx.x * S * FP;
+  HT* dSs = dS_scr + (size_t)blockIdx.x * S * FP;
+  HT* Pts = Pt_scr + (size_t)blockIdx.x * S * FP;
   stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
   stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
@@ -72,16 +72,16 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
     const int rowc = valid ? row : S - 1;
     const bool isq = rowc >= F;
     const int rowl = ATT_ABL(a, 4) ? (rowc & 1) : rowc;
-    const bf16_t* qp = base + (size_t)rowl * ld;
-    const bf16_t* dop = dobase + (size_t)rowl * E;
-    const bf16_t* op = obase + (size_t)rowl * E;
-    bf16x8_t qf[NKK], df[NKK];
+    const HT* qp = base + (size_t)rowl * ld;
+    const HT* dop = dobase + (size_t)rowl * E;
+    const HT* op = obase + (size_t)rowl * E;
+    vec8<HT> qf[NKK], df[NKK];
     float delta = 0.f;
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
-      qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 16 + g * 8);
-      df[kk] = *reinterpret_cast<const bf16x8_t*>(dop + kk * 16 + g * 8);
-      delta += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(op + kk * 16 + g * 8));
+      qf[kk] = *reinterpret_cast<const vec8<HT>*>(qp + kk * 16 + g * 8);
+      df[kk] = *reinterpret_cast<const vec8<HT>*>(dop + kk * 16 + g * 8);
+      delta += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(op + kk * 16 + g * 8));
     }
     delta += __shfl_xor(delta, 32, 64);
     const float l = lsebase[rowc];
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
       float t = 0.f, u = 0.f;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        t += dot8(qf[kk], *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8));
-        u += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(qp + 2 * E + kk * 16 + g * 8));
+        t += dot8(qf[kk], *reinterpret_cast<const vec8<HT>*>(qp + E + kk * 16 + g * 8));
+        u += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + kk * 16 + g * 8));
       }
       ds_self = t; pt_self = u;
     }
@@ -121,10 +121,10 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
       for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
-        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + tile_off<DH>(jb * 32 + li, kk * 2 + g));
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[kk], dp, 0, 0, 0);
+        const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        const vec8<HT> vf = *reinterpret_cast<const vec8<HT>*>(sV + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        sc = mfma16<HT>(kf, qf[kk], sc);
+        dp = mfma16<HT>(vf, df[kk], dp);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -149,23 +149,23 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
                       dp[8 * p2 + 6], dp[8 * p2 + 7], g);
         if (valid && !ATT_ABL(a, 1)) {
           const size_t so = (size_t)row * FP + jb * 32 + 16 * p2 + 8 * g;
-          store8_bf16(dSs + so, vs);
-          store8_bf16(Pts + so, vp);
+          store8_h<HT>(dSs + so, vs);
+          store8_h<HT>(Pts + so, vp);
         }
       }
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
-        const bf16x8_t sf = pack8(sc, aa);
+        const vec8<HT> sf = pack8<HT>(sc, aa);
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-          const bf16x8_t kf = tr_frag<DH>(sK, jb * 32 + 16 * aa, db, lane);
-          qa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, qa[db], 0, 0, 0);
+          const vec8<HT> kf = tr_frag<DH, HT>(sK, jb * 32 + 16 * aa, db, lane);
+          qa[db] = mfma16<HT>(kf, sf, qa[db]);
         }
       }
     }
     {
       // lanes l and l ^ 32 trade quads (mfma_tiles.h: pair_exchange) so that every store is 16 bytes per lane
-      bf16_t* dq = dbase + (size_t)row * ld;
+      HT* dq = dbase + (size_t)row * ld;
       const bool st = valid && !ATT_ABL(a, 2);
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
           const int dh = 32 * db + 16 * p2 + 8 * g;
           if (st) {
             if (isq) {
-              const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(qp + E + dh);
-              const bf16x8_t qf8 = *reinterpret_cast<const bf16x8_t*>(qp + dh);
-              const bf16x8_t d8 = *reinterpret_cast<const bf16x8_t*>(dop + dh);
+              const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(qp + E + dh);
+              const vec8<HT> qf8 = *reinterpret_cast<const vec8<HT>*>(qp + dh);
+              const vec8<HT> d8 = *reinterpret_cast<const vec8<HT>*>(dop + dh);
               float kself[8], vself[8];
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
@@ -187,10 +187,10 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
                 kself[u] = ds_self * (float)qf8[u];      // a query token's own key / value receive the self term only
                 vself[u] = pt_self * (float)d8[u];
               }
-              store8_bf16(dq + E + dh, kself);
-              store8_bf16(dq + 2 * E + dh, vself);
+              store8_h<HT>(dq + E + dh, kself);
+              store8_h<HT>(dq + 2 * E + dh, vself);
             }
-            store8_bf16(dq + dh, v);
+            store8_h<HT>(dq + dh, v);
           }
         }
     }
@@ -200,9 +200,10 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const bf16_t* __restrict__ 
 
 // dK / dV of the feature keys: out[key][dh] = sum_row Y[row][key] X[row][dh]
 //   blockIdx.y = 0: Y = dS, X = Q  -> dK ;  blockIdx.y = 1: Y = P~, X = dO -> dV ;  blockIdx.z = (window, head)
-__global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ dS_scr, const bf16_t* __restrict__ Pt_scr,
-                                                     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                     bf16_t* __restrict__ dqkv, int S, int F, int FP, int E, int H,
+template <typename HT>
+__global__ __launch_bounds__(256) void attn_bwd_keys(const HT* __restrict__ dS_scr, const HT* __restrict__ Pt_scr,
+                                                     const HT* __restrict__ qkv, const HT* __restrict__ d_o,
+                                                     HT* __restrict__ dqkv, int S, int F, int FP, int E, int H,
                                                      int DH) {
   constexpr int WT = 128, WM = 64, TILE_BYTES = WM * WT * 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -210,12 +211,12 @@ __global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave >> 1, wn = wave & 1;
   const int bh = blockIdx.z, b = bh / H, h = bh % H, prod = blockIdx.y;
-  const bf16_t* Y = (prod ? Pt_scr : dS_scr) + (size_t)bh * S * FP;
+  const HT* Y = (prod ? Pt_scr : dS_scr) + (size_t)bh * S * FP;
   const int ldy = FP;
-  const bf16_t* X = prod ? d_o + (size_t)b * S * E + (size_t)h * DH : qkv + (size_t)b * S * 3 * E + (size_t)h * DH;
+  const HT* X = prod ? d_o + (size_t)b * S * E + (size_t)h * DH : qkv + (size_t)b * S * 3 * E + (size_t)h * DH;
   const int ldx = prod ? E : 3 * E;
   const int xcols = prod ? E - h * DH : 3 * E - h * DH;   // columns of the row that lie at or after X's first column
-  bf16_t* out = dqkv + (size_t)b * S * 3 * E + (prod ? 2 * E : E) + (size_t)h * DH;
+  HT* out = dqkv + (size_t)b * S * 3 * E + (prod ? 2 * E : E) + (size_t)h * DH;
   const int ldo = 3 * E;
   const int n0 = blockIdx.x * WT, k0 = 0, M = S, N = F, K = DH;
   const int nsteps = (M + WM - 1) / WM;
@@ -281,27 +282,27 @@ __global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ 
     char* sX = sY + TILE_BYTES;
     if (st * WM + WM > M) {
       const int first = M - st * WM;
-      bf16x8_t z;
+      vec8<HT> z;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) z[u] = (bf16_t)0.f;
+      for (int u = 0; u < 8; ++u) z[u] = (HT)0.f;
       for (int idx = tid; idx < (WM - first) * 16; idx += 256) {
         const int off = (first + idx / 16) * 256 + (idx % 16) * 16;
-        *reinterpret_cast<bf16x8_t*>(sY + off) = z;
-        *reinterpret_cast<bf16x8_t*>(sX + off) = z;
+        *reinterpret_cast<vec8<HT>*>(sY + off) = z;
+        *reinterpret_cast<vec8<HT>*>(sX + off) = z;
       }
       __syncthreads();
     }
 #pragma unroll
     for (int ms = 0; ms < WM / 16; ++ms) {
-      bf16x8_t xf[2], yf[2];
+      vec8<HT> xf[2], yf[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) xf[i] = cat8(tr_read(sX + xtr[i][0] + ms * 4096), tr_read(sX + xtr[i][1] + ms * 4096));
+      for (int i = 0; i < 2; ++i) xf[i] = cat8<HT>(tr_read<HT>(sX + xtr[i][0] + ms * 4096), tr_read<HT>(sX + xtr[i][1] + ms * 4096));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) yf[j] = cat8(tr_read(sY + ytr[j][0] + ms * 4096), tr_read(sY + ytr[j][1] + ms * 4096));
+      for (int j = 0; j < 2; ++j) yf[j] = cat8<HT>(tr_read<HT>(sY + ytr[j][0] + ms * 4096), tr_read<HT>(sY + ytr[j][1] + ms * 4096));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<HT>(xf[i], yf[j], acc[i][j]);
     }
   }
   // D[i = dh][j = key]: lane owns one key row of dK / dV, 4 consecutive dh per quad
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys(const bf16_t* __restrict__ 
         pair_exchange(v, acc[i][j][8 * p2], acc[i][j][8 * p2 + 1], acc[i][j][8 * p2 + 2], acc[i][j][8 * p2 + 3],
                       acc[i][j][8 * p2 + 4], acc[i][j][8 * p2 + 5], acc[i][j][8 * p2 + 6], acc[i][j][8 * p2 + 7], g);
         const int k = wk * 64 + i * 32 + 16 * p2 + 8 * g;
-        if (n < N && k + 7 < K) store8_bf16(out + (size_t)n * ldo + k, v);
+        if (n < N && k + 7 < K) store8_h<HT>(out + (size_t)n * ldo + k, v);
       }
   }
 }
@@ -335,35 +336,35 @@ AttnArgsM make_args2(const TimDesc& d) {
 
 static inline int rows_waves(int S) { const int n = (S + 31) / 32; return n < 1 ? 1 : (n > 8 ? 8 : n); }
 
-template <int DH, int NJB>
+template <typename HT, int DH, int NJB>
 int launch_bwd2(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
                 void* ws, hipStream_t s) {
   const int FP = NJB * 32;
-  bf16_t* dS = (bf16_t*)ws;
-  bf16_t* Pt = dS + (size_t)d.B * d.H * d.S * FP;
+  HT* dS = (HT*)ws;
+  HT* Pt = dS + (size_t)d.B * d.H * d.S * FP;
   const size_t lds1 = (size_t)2 * FP * DH * 2;
-  (void)hipFuncSetAttribute((const void*)attn_bwd_rows<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-  hipLaunchKernelGGL((attn_bwd_rows<DH, NJB>), dim3(d.B * d.H), dim3(64 * rows_waves(d.S)), lds1, s, (const bf16_t*)qkv,
-                     (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dqkv, dS, Pt, make_args2(d));
+  (void)hipFuncSetAttribute((const void*)attn_bwd_rows<HT, DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  hipLaunchKernelGGL((attn_bwd_rows<HT, DH, NJB>), dim3(d.B * d.H), dim3(64 * rows_waves(d.S)), lds1, s, (const HT*)qkv,
+                     (const HT*)o, lse, (const HT*)d_o, (HT*)dqkv, dS, Pt, make_args2(d));
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   const size_t lds2 = 2 * 2 * 64 * 128 * 2;
-  hipLaunchKernelGGL(attn_bwd_keys, dim3((d.F + 127) / 128, 2, d.B * d.H), dim3(256), lds2, s, dS, Pt, (const bf16_t*)qkv,
-                     (const bf16_t*)d_o, (bf16_t*)dqkv, d.S, d.F, FP, d.E, d.H, DH);
+  hipLaunchKernelGGL(attn_bwd_keys<HT>, dim3((d.F + 127) / 128, 2, d.B * d.H), dim3(256), lds2, s, dS, Pt, (const HT*)qkv,
+                     (const HT*)d_o, (HT*)dqkv, d.S, d.F, FP, d.E, d.H, DH);
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
 }  // namespace
 
 size_t tim_attention_bwd2_ws(const TimDesc& d) {
-  return (size_t)2 * d.B * d.H * d.S * round_up(d.F, 32) * sizeof(bf16_t);
+  return (size_t)2 * d.B * d.H * d.S * round_up(d.F, 32) * 2;
 }
 
 int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                             void* dqkv, void* ws, size_t ws_bytes, hipStream_t s) {
-  if (d.precision != TIMHIP_PREC_BF16 || (d.E % 8) != 0 || d.B * d.H > 65535) return TIMHIP_EUNSUPPORTED;
+  if (!h16_storage(d.precision) || (d.E % 8) != 0 || d.B * d.H > 65535) return TIMHIP_EUNSUPPORTED;
   if (!ws || ws_bytes < tim_attention_bwd2_ws(d)) return TIMHIP_EUNSUPPORTED;
   const int DHv = d.E / d.H, NJBv = (d.F + 31) / 32;
-#define B2(DHc, NJBc) return launch_bwd2<DHc, NJBc>(d, qkv, o, lse, d_o, dqkv, ws, s)
+#define B2(DHc, NJBc) DISPATCH_H16(d.precision, return (launch_bwd2<HT, DHc, NJBc>(d, qkv, o, lse, d_o, dqkv, ws, s)))
   if (DHv == 128) {
     switch (NJBv) { case 1: B2(128, 1); case 2: B2(128, 2); case 3: B2(128, 3); case 4: B2(128, 4); case 5: B2(128, 5); default: break; }
   } else if (DHv == 64) {

@@ -1,4 +1,4 @@
-// MFMA (bf16) structured attention for the TIM encoder, forward and backward.
+// MFMA (bf16 / fp16 operands: template parameter HT) structured attention for the TIM encoder, forward and backward.
 //
 // Math: see attention.hip (token i attends to the F feature tokens + itself; reference
 // tim.py:161-166 mask over nn.MultiheadAttention, transformers.py:102).
@@ -50,8 +50,8 @@ __device__ __forceinline__ float quad_pick(float k0, float k1, float k2, float k
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <int DH, int NJB>
-__global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+template <typename HT, int DH, int NJB>
+__global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv, HT* __restrict__ o,
                                                      float* __restrict__ lse, AttnArgsM a) {
   constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t ld = (size_t)3 * E;
-  const bf16_t* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
+  const HT* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
   stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
   stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
@@ -75,12 +75,12 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
     const bool isq = rowc >= F;
-    const bf16_t* qp = base + (size_t)rowc * ld;
-    bf16x8_t qf[NKK], kself[NKK];
+    const HT* qp = base + (size_t)rowc * ld;
+    vec8<HT> qf[NKK], kself[NKK];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 16 + g * 8);
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const vec8<HT>*>(qp + kk * 16 + g * 8);
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) kself[kk] = *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8);
+    for (int kk = 0; kk < NKK; ++kk) kself[kk] = *reinterpret_cast<const vec8<HT>*>(qp + E + kk * 16 + g * 8);
 
     // S^T = K Q^T : lane owns query row `row`, registers hold keys 32jb + (r&3) + 8(r>>2) + 4g
     f32x16_t sc[NJB];
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
       for (int r = 0; r < 16; ++r) sc[jb][r] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
-        sc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sc[jb], 0, 0, 0);
+        const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        sc[jb] = mfma16<HT>(kf, qf[kk], sc[jb]);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the K-fragment reads of later key blocks from being hoisted
     }
@@ -157,14 +157,14 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
 
     // O^T = V^T P^T.  P is packed to bf16 first (frees the fp32 score registers); the head dim is
     // processed in halves so only NDB/2 accumulator tiles are live at a time.
-    bf16x8_t pf[NJB][2];
+    vec8<HT> pf[NJB][2];
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb) {
-      pf[jb][0] = pack8(sc[jb], 0);
-      pf[jb][1] = pack8(sc[jb], 1);
+      pf[jb][0] = pack8<HT>(sc[jb], 0);
+      pf[jb][1] = pack8<HT>(sc[jb], 1);
     }
     constexpr int NH = NDB >= 2 ? 2 : 1, DBH = NDB / NH;
-    bf16_t* op = o + ((size_t)b * S + rowc) * E + (size_t)h * DH;
+    HT* op = o + ((size_t)b * S + rowc) * E + (size_t)h * DH;
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
       f32x16_t oa[DBH];
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
         for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
           for (int d2 = 0; d2 < DBH; ++d2) {
-            const bf16x8_t vf = tr_frag<DH>(sV, jb * 32 + 16 * aa, hh * DBH + d2, lane);
-            oa[d2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jb][aa], oa[d2], 0, 0, 0);
+            const vec8<HT> vf = tr_frag<DH, HT>(sV, jb * 32 + 16 * aa, hh * DBH + d2, lane);
+            oa[d2] = mfma16<HT>(vf, pf[jb][aa], oa[d2]);
             if (d2 == DBH - 1 && aa == 1) __builtin_amdgcn_sched_barrier(0);
           }
       // lanes l and l ^ 32 trade quads so that each stores 8 contiguous head-dim columns (16 bytes) per pair of quads;
@@ -194,11 +194,11 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
           const int dh = 32 * (hh * DBH + d2) + 16 * p2 + 8 * g;
           if (valid) {
             if (isq) {
-              const bf16x8_t sv = *reinterpret_cast<const bf16x8_t*>(qp + 2 * E + dh);
+              const vec8<HT> sv = *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + dh);
 #pragma unroll
               for (int u = 0; u < 8; ++u) v[u] = fmaf(pself, (float)sv[u], v[u]);
             }
-            store8_bf16(op + dh, v);
+            store8_h<HT>(op + dh, v);
           }
         }
     }
@@ -212,10 +212,10 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const bf16_t* __restrict__ 
 //                               that dS / P~ land in registers as B operands of
 //                               dK^T = Q^T dS and dV^T = dO^T P~ (contraction over the 32 rows of a block).
 // ---------------------------------------------------------------------------
-template <int DH, int NJB>
-__global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
-                                                     const float* __restrict__ lse, const bf16_t* __restrict__ d_o,
-                                                     bf16_t* __restrict__ dqkv, AttnArgsM a) {
+template <typename HT, int DH, int NJB>
+__global__ __launch_bounds__(256) void attn_bwd_mfma(const HT* __restrict__ qkv, const HT* __restrict__ o,
+                                                     const float* __restrict__ lse, const HT* __restrict__ d_o,
+                                                     HT* __restrict__ dqkv, AttnArgsM a) {
   constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t ld = (size_t)3 * E;
-  const bf16_t* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
-  bf16_t* dbase = dqkv + (size_t)b * S * ld + (size_t)h * DH;
-  const bf16_t* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
-  const bf16_t* obase = o + (size_t)b * S * E + (size_t)h * DH;
+  const HT* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
+  HT* dbase = dqkv + (size_t)b * S * ld + (size_t)h * DH;
+  const HT* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
+  const HT* obase = o + (size_t)b * S * E + (size_t)h * DH;
   const float* lsebase = lse + ((size_t)b * a.H + h) * S;
   stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
   stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
@@ -248,16 +248,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
     const bool isq = rowc >= F;
-    const bf16_t* qp = base + (size_t)rowc * ld;
-    const bf16_t* dop = dobase + (size_t)rowc * E;
-    const bf16_t* op = obase + (size_t)rowc * E;
-    bf16x8_t qf[NKK], df[NKK];
+    const HT* qp = base + (size_t)rowc * ld;
+    const HT* dop = dobase + (size_t)rowc * E;
+    const HT* op = obase + (size_t)rowc * E;
+    vec8<HT> qf[NKK], df[NKK];
     float delta = 0.f;
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
-      qf[kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 16 + g * 8);
-      df[kk] = *reinterpret_cast<const bf16x8_t*>(dop + kk * 16 + g * 8);
-      delta += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(op + kk * 16 + g * 8));
+      qf[kk] = *reinterpret_cast<const vec8<HT>*>(qp + kk * 16 + g * 8);
+      df[kk] = *reinterpret_cast<const vec8<HT>*>(dop + kk * 16 + g * 8);
+      delta += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(op + kk * 16 + g * 8));
     }
     delta += __shfl_xor(delta, 32, 64);
     const float l = lsebase[rowc];
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
       float t = 0.f, u = 0.f;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        t += dot8(qf[kk], *reinterpret_cast<const bf16x8_t*>(qp + E + kk * 16 + g * 8));
-        u += dot8(df[kk], *reinterpret_cast<const bf16x8_t*>(qp + 2 * E + kk * 16 + g * 8));
+        t += dot8(qf[kk], *reinterpret_cast<const vec8<HT>*>(qp + E + kk * 16 + g * 8));
+        u += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + kk * 16 + g * 8));
       }
       ds_self = t; pt_self = u;
     }
@@ -298,10 +298,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
       for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
-        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + tile_off<DH>(jb * 32 + li, kk * 2 + g));
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, df[kk], dp, 0, 0, 0);
+        const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        const vec8<HT> vf = *reinterpret_cast<const vec8<HT>*>(sV + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+        sc = mfma16<HT>(kf, qf[kk], sc);
+        dp = mfma16<HT>(vf, df[kk], dp);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -317,16 +317,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
       }
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
-        const bf16x8_t sf = pack8(sc, aa);
+        const vec8<HT> sf = pack8<HT>(sc, aa);
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-          const bf16x8_t kf = tr_frag<DH>(sK, jb * 32 + 16 * aa, db, lane);
-          qa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, sf, qa[db], 0, 0, 0);
+          const vec8<HT> kf = tr_frag<DH, HT>(sK, jb * 32 + 16 * aa, db, lane);
+          qa[db] = mfma16<HT>(kf, sf, qa[db]);
         }
       }
     }
     if (valid) {
-      bf16_t* dq = dbase + (size_t)row * ld;
+      HT* dq = dbase + (size_t)row * ld;
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -335,15 +335,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
           float v0 = qa[db][4 * q], v1 = qa[db][4 * q + 1], v2 = qa[db][4 * q + 2], v3 = qa[db][4 * q + 3];
           if (isq) {
             float k0, k1, k2, k3, q0, q1, q2, q3, d0, d1, d2, d3;
-            load4<bf16_t>(qp + E + dh, k0, k1, k2, k3);
-            load4<bf16_t>(qp + dh, q0, q1, q2, q3);
-            load4<bf16_t>(dop + dh, d0, d1, d2, d3);
+            load4<HT>(qp + E + dh, k0, k1, k2, k3);
+            load4<HT>(qp + dh, q0, q1, q2, q3);
+            load4<HT>(dop + dh, d0, d1, d2, d3);
             v0 = fmaf(ds_self, k0, v0); v1 = fmaf(ds_self, k1, v1); v2 = fmaf(ds_self, k2, v2); v3 = fmaf(ds_self, k3, v3);
             // a query token's own key / value receive the self term only
-            store4<bf16_t>(dq + E + dh, ds_self * q0, ds_self * q1, ds_self * q2, ds_self * q3);
-            store4<bf16_t>(dq + 2 * E + dh, pt_self * d0, pt_self * d1, pt_self * d2, pt_self * d3);
+            store4<HT>(dq + E + dh, ds_self * q0, ds_self * q1, ds_self * q2, ds_self * q3);
+            store4<HT>(dq + 2 * E + dh, pt_self * d0, pt_self * d1, pt_self * d2, pt_self * d3);
           }
-          store4<bf16_t>(dq + dh, v0, v1, v2, v3);
+          store4<HT>(dq + dh, v0, v1, v2, v3);
         }
     }
   }
@@ -374,12 +374,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
       for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(sQ + tile_off<DH>(li, kk * 2 + g));
-        const bf16x8_t df = *reinterpret_cast<const bf16x8_t*>(sD + tile_off<DH>(li, kk * 2 + g));
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + tile_off<DH>(jbc * 32 + li, kk * 2 + g));
-        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + tile_off<DH>(jbc * 32 + li, kk * 2 + g));
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf, sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf, dp, 0, 0, 0);
+        const vec8<HT> qf = *reinterpret_cast<const vec8<HT>*>(sQ + tile_off<DH>(li, kk * 2 + g));
+        const vec8<HT> df = *reinterpret_cast<const vec8<HT>*>(sD + tile_off<DH>(li, kk * 2 + g));
+        const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(sK + tile_off<DH>(jbc * 32 + li, kk * 2 + g));
+        const vec8<HT> vf = *reinterpret_cast<const vec8<HT>*>(sV + tile_off<DH>(jbc * 32 + li, kk * 2 + g));
+        sc = mfma16<HT>(qf, kf, sc);
+        dp = mfma16<HT>(df, vf, dp);
       }
       // dropout keep factors: the 4 lanes of a quad hold 4 consecutive keys, so one Philox call
       // (4 outputs) serves a whole quad; lane t of the quad draws for register-row t and the
@@ -416,26 +416,26 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
       // dK^T += Q^T dS ; dV^T += dO^T P~   (contraction over the 32 rows: two K=16 MFMAs)
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
-        const bf16x8_t sf = pack8(dsr, aa), pf = pack8(ptr_, aa);
+        const vec8<HT> sf = pack8<HT>(dsr, aa), pf = pack8<HT>(ptr_, aa);
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-          const bf16x8_t qt = tr_frag<DH>(sQ, 16 * aa, db, lane);
-          const bf16x8_t dt = tr_frag<DH>(sD, 16 * aa, db, lane);
-          ka[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, sf, ka[db], 0, 0, 0);
-          va[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt, pf, va[db], 0, 0, 0);
+          const vec8<HT> qt = tr_frag<DH, HT>(sQ, 16 * aa, db, lane);
+          const vec8<HT> dt = tr_frag<DH, HT>(sD, 16 * aa, db, lane);
+          ka[db] = mfma16<HT>(qt, sf, ka[db]);
+          va[db] = mfma16<HT>(dt, pf, va[db]);
         }
       }
     }
     if (active && key < F) {
-      bf16_t* dk = dbase + (size_t)key * ld + E;
-      bf16_t* dv = dbase + (size_t)key * ld + 2 * E;
+      HT* dk = dbase + (size_t)key * ld + E;
+      HT* dv = dbase + (size_t)key * ld + 2 * E;
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int dh = 32 * db + 8 * q + 4 * g;
-          store4<bf16_t>(dk + dh, ka[db][4 * q], ka[db][4 * q + 1], ka[db][4 * q + 2], ka[db][4 * q + 3]);
-          store4<bf16_t>(dv + dh, va[db][4 * q], va[db][4 * q + 1], va[db][4 * q + 2], va[db][4 * q + 3]);
+          store4<HT>(dk + dh, ka[db][4 * q], ka[db][4 * q + 1], ka[db][4 * q + 2], ka[db][4 * q + 3]);
+          store4<HT>(dv + dh, va[db][4 * q], va[db][4 * q + 1], va[db][4 * q + 2], va[db][4 * q + 3]);
         }
     }
   }
@@ -454,21 +454,21 @@ AttnArgsM make_args(const TimDesc& d) {
 // one wave per 32-row block of queries, at most 8 waves (2 per SIMD keeps the 256-VGPR budget)
 static inline int attn_waves(int S) { const int n = (S + 31) / 32; return n < 1 ? 1 : (n > 8 ? 8 : n); }
 
-template <int DH, int NJB>
+template <typename HT, int DH, int NJB>
 int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
   const size_t lds = (size_t)2 * NJB * 32 * DH * 2;
-  (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_mfma<DH, NJB>), dim3(d.B * d.H), dim3(64 * attn_waves(d.S)), lds, s, (const bf16_t*)qkv, (bf16_t*)o, lse,
+  (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HT, DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_fwd_mfma<HT, DH, NJB>), dim3(d.B * d.H), dim3(64 * attn_waves(d.S)), lds, s, (const HT*)qkv, (HT*)o, lse,
                      make_args(d));
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
-template <int DH, int NJB>
+template <typename HT, int DH, int NJB>
 int launch_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
                hipStream_t s) {
   const size_t lds = (size_t)2 * NJB * 32 * DH * 2 + (size_t)2 * 32 * DH * 2 + (size_t)2 * d.S * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)attn_bwd_mfma<DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_mfma<DH, NJB>), dim3(d.B * d.H), dim3(256), lds, s, (const bf16_t*)qkv,
-                     (const bf16_t*)o, lse, (const bf16_t*)d_o, (bf16_t*)dqkv, make_args(d));
+  (void)hipFuncSetAttribute((const void*)attn_bwd_mfma<HT, DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_mfma<HT, DH, NJB>), dim3(d.B * d.H), dim3(256), lds, s, (const HT*)qkv,
+                     (const HT*)o, lse, (const HT*)d_o, (HT*)dqkv, make_args(d));
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
@@ -481,24 +481,24 @@ int launch_bwd(const TimDesc& d, const void* qkv, const void* o, const float* ls
     const int DHv = d.E / d.H, NJBv = (d.F + 31) / 32;                           \
     if (DHv == 128) {                                                            \
       switch (NJBv) {                                                            \
-        case 1: return FN<128, 1>(__VA_ARGS__);                                  \
-        case 2: return FN<128, 2>(__VA_ARGS__);                                  \
-        case 3: return FN<128, 3>(__VA_ARGS__);                                  \
-        case 4: return FN<128, 4>(__VA_ARGS__);                                  \
-        case 5: return FN<128, 5>(__VA_ARGS__);                                  \
+        case 1: return FN<HT, 128, 1>(__VA_ARGS__);                                  \
+        case 2: return FN<HT, 128, 2>(__VA_ARGS__);                                  \
+        case 3: return FN<HT, 128, 3>(__VA_ARGS__);                                  \
+        case 4: return FN<HT, 128, 4>(__VA_ARGS__);                                  \
+        case 5: return FN<HT, 128, 5>(__VA_ARGS__);                                  \
         default: return TIMHIP_EUNSUPPORTED;                                     \
       }                                                                          \
     } else if (DHv == 64) {                                                      \
       switch (NJBv) {                                                            \
-        case 1: return FN<64, 1>(__VA_ARGS__);                                   \
-        case 2: return FN<64, 2>(__VA_ARGS__);                                   \
-        case 4: return FN<64, 4>(__VA_ARGS__);                                   \
+        case 1: return FN<HT, 64, 1>(__VA_ARGS__);                                   \
+        case 2: return FN<HT, 64, 2>(__VA_ARGS__);                                   \
+        case 4: return FN<HT, 64, 4>(__VA_ARGS__);                                   \
         default: return TIMHIP_EUNSUPPORTED;                                     \
       }                                                                          \
     } else if (DHv == 32) {                                                      \
       switch (NJBv) {                                                            \
-        case 1: return FN<32, 1>(__VA_ARGS__);                                   \
-        case 2: return FN<32, 2>(__VA_ARGS__);                                   \
+        case 1: return FN<HT, 32, 1>(__VA_ARGS__);                                   \
+        case 2: return FN<HT, 32, 2>(__VA_ARGS__);                                   \
         default: return TIMHIP_EUNSUPPORTED;                                     \
       }                                                                          \
     }                                                                            \
@@ -506,12 +506,14 @@ int launch_bwd(const TimDesc& d, const void* qkv, const void* o, const float* ls
   } while (0)
 
 int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
-  if (d.precision != TIMHIP_PREC_BF16 || (d.E % 8) != 0) return TIMHIP_EUNSUPPORTED;
-  ATTN_DISPATCH(launch_fwd, d, qkv, o, lse, s);
+  if (!h16_storage(d.precision) || (d.E % 8) != 0) return TIMHIP_EUNSUPPORTED;
+  DISPATCH_H16(d.precision, ATTN_DISPATCH(launch_fwd, d, qkv, o, lse, s));
+  return TIMHIP_EUNSUPPORTED;
 }
 
 int tim_attention_bwd_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                            void* dqkv, hipStream_t s) {
-  if (d.precision != TIMHIP_PREC_BF16 || (d.E % 8) != 0) return TIMHIP_EUNSUPPORTED;
-  ATTN_DISPATCH(launch_bwd, d, qkv, o, lse, d_o, dqkv, s);
+  if (!h16_storage(d.precision) || (d.E % 8) != 0) return TIMHIP_EUNSUPPORTED;
+  DISPATCH_H16(d.precision, ATTN_DISPATCH(launch_bwd, d, qkv, o, lse, d_o, dqkv, s));
+  return TIMHIP_EUNSUPPORTED;
 }

@@ -5,9 +5,14 @@
 
 #include "../../include/timhip.h"
 
+// 16-bit MFMA operand types: HT = bf16_t (TIMHIP_PREC_BF16) or f16_t (TIMHIP_PREC_F16).  Every 16-bit kernel is a template
+// over H; the two differ in the MFMA opcode and the f32 <-> H conversions only (same fragment layouts, same LDS images).
 typedef __bf16 bf16_t;
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+template <typename T> using vec8 = T __attribute__((ext_vector_type(8)));
+template <typename T> using vec4 = T __attribute__((ext_vector_type(4)));
+typedef vec8<bf16_t> bf16x8_t;
+typedef vec4<bf16_t> bf16x4_t;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -33,6 +38,20 @@ template <> struct OpT<bf16_t> {
   static __device__ __forceinline__ bf16_t from_f(float v) { return (bf16_t)v; }
 };
 
+template <> struct OpT<f16_t> {
+  static __device__ __forceinline__ float to_f(f16_t v) { return (float)v; }
+  static __device__ __forceinline__ f16_t from_f(float v) { return (f16_t)v; }
+};
+
+// v_mfma_f32_32x32x16_{bf16,f16}: D[32x32] += A[32x16] B[16x32], 8 operand values per lane, fp32 accumulate
+template <typename HT> __device__ __forceinline__ f32x16_t mfma16(vec8<HT> a, vec8<HT> b, f32x16_t c);
+template <> __device__ __forceinline__ f32x16_t mfma16<bf16_t>(vec8<bf16_t> a, vec8<bf16_t> b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16_t mfma16<f16_t>(vec8<f16_t> a, vec8<f16_t> b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <>
@@ -45,6 +64,12 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, floa
   v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
   *reinterpret_cast<bf16x4_t*>(p) = v;
 }
+template <>
+__device__ __forceinline__ void store4<f16_t>(f16_t* p, float a, float b, float c, float d) {
+  vec4<f16_t> v;
+  v[0] = (f16_t)a; v[1] = (f16_t)b; v[2] = (f16_t)c; v[3] = (f16_t)d;
+  *reinterpret_cast<vec4<f16_t>*>(p) = v;
+}
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, float& a, float& b, float& c, float& d);
 template <>
@@ -55,6 +80,12 @@ __device__ __forceinline__ void load4<float>(const float* p, float& a, float& b,
 template <>
 __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float& a, float& b, float& c, float& d) {
   bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+  a = (float)v[0]; b = (float)v[1]; c = (float)v[2]; d = (float)v[3];
+}
+
+template <>
+__device__ __forceinline__ void load4<f16_t>(const f16_t* p, float& a, float& b, float& c, float& d) {
+  vec4<f16_t> v = *reinterpret_cast<const vec4<f16_t>*>(p);
   a = (float)v[0]; b = (float)v[1]; c = (float)v[2]; d = (float)v[3];
 }
 
@@ -288,11 +319,14 @@ int tim_transpose(int precision, const void* src, int rows, int cols, int lds, v
                   float* colsum, hipStream_t s);
 int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStream_t s);
 size_t tim_wgrad_tn_ws(int Nout, int Kout, int M);
-int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
-                      void* ws, size_t ws_bytes, hipStream_t s, int accumulate = 1);
+// out_scale: NULL, or a device scalar the written gradients are multiplied by (TIMHIP_PREC_F16 stores its gradient operands
+// multiplied by S and passes 1/S here, see timhip_grad_scale)
+int tim_wgrad_tn_h16(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW,
+                     float* db, void* ws, size_t ws_bytes, hipStream_t s, int accumulate = 1, const float* out_scale = nullptr);
 size_t tim_wgrad_group_ws(const TimWgradItem* it, int n, int M);
 int tim_wgrad_group_splits(const TimWgradItem* it, int n, int M);
-int tim_wgrad_group_bf16(const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int tim_wgrad_group_h16(int precision, const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes,
+                        const float* out_scale, hipStream_t s);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
 // mask_out != NULL: additionally writes the dropout keep-bits of a [rows, mask_cols] site (1 bit per element, row stride
 // mask_cols / 8 bytes, element index r * mask_cols + c as in the GEMM epilogues) - see drop_bits32
@@ -303,7 +337,8 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
                       const float* stats, int rows, int cols, int act, const float* w, float* dy_f32,
                       int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,
-                      float* dgamma, float* dbeta, float* partial_ws, hipStream_t s, bool defer_colsum = false);
+                      float* dgamma, float* dbeta, float* partial_ws, hipStream_t s, bool defer_colsum = false,
+                      const float* t_scale = nullptr);   // t_scale: device scalar multiplied into the operand-dtype copy dy_T
 size_t tim_layernorm_bwd_ws(int rows, int cols);
 int tim_layernorm_bwd_blocks(int rows);   // partial rows one backward launch over `rows` rows writes
 int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
@@ -311,6 +346,21 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
                       const void* d_o, void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);
 size_t tim_attention_bwd_ws(const TimDesc& d);
 
-// operand storage: bf16 for TIMHIP_PREC_BF16, fp32 for TIMHIP_PREC_FP32 and TIMHIP_PREC_BF16X3
-static inline bool f32_storage(int precision) { return precision != TIMHIP_PREC_BF16; }
+// operand storage: bf16 for TIMHIP_PREC_BF16, fp16 for TIMHIP_PREC_F16, fp32 for TIMHIP_PREC_FP32 and TIMHIP_PREC_BF16X3
+static inline bool h16_storage(int precision) { return precision == TIMHIP_PREC_BF16 || precision == TIMHIP_PREC_F16; }
+static inline bool f32_storage(int precision) { return !h16_storage(precision); }
+static inline bool valid_precision(int precision) { return precision >= TIMHIP_PREC_BF16 && precision <= TIMHIP_PREC_F16; }
+// run the statement with HT = the 16-bit operand type of `precision` (which must satisfy h16_storage)
+// run the statement with T = the operand STORAGE type of `precision` (float / bf16_t / f16_t)
+#define DISPATCH_T(prec, ...)                                           \
+  do {                                                                  \
+    if (f32_storage(prec)) { using T = float; __VA_ARGS__; }            \
+    else if ((prec) == TIMHIP_PREC_F16) { using T = f16_t; __VA_ARGS__; } \
+    else { using T = bf16_t; __VA_ARGS__; }                             \
+  } while (0)
+#define DISPATCH_H16(precision, ...)                                   \
+  do {                                                                 \
+    if ((precision) == TIMHIP_PREC_F16) { using HT = f16_t; __VA_ARGS__; } \
+    else { using HT = bf16_t; __VA_ARGS__; }                            \
+  } while (0)
 static inline size_t opsize(int precision) { return f32_storage(precision) ? 4 : 2; }

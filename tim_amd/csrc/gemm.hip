@@ -35,6 +35,7 @@ struct EpiDev {
   // DROP_RES_F32 only: the residual is LayerNorm(res) - res holds the PRE-norm rows, ln_stats their (mean, rstd) pairs, ln_w /
   // ln_b the affine parameters - so the normalised fp32 rows never have to exist in memory (NULL: res is used as it is)
   const float* ln_stats; const float* ln_w; const float* ln_b;
+  const float* acc_scale;  // device scalar or NULL: factor on the accumulators (1 / gradient scale where fp16 gradient operands end)
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
   int vec8; // the operand-dtype outputs / aux of this epilogue also allow 8-element (16-byte) accesses
   long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)
@@ -197,11 +198,12 @@ constexpr bool epi_has_oct(int EPI) {
          EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_GELU_DROP_G2 ||
          EPI == TIMHIP_EPI_MULAUX_T;
 }
-__device__ __forceinline__ void store8(bf16_t* p, float4 lo, float4 hi) {
-  bf16x8_t o;
-  o[0] = (bf16_t)lo.x; o[1] = (bf16_t)lo.y; o[2] = (bf16_t)lo.z; o[3] = (bf16_t)lo.w;
-  o[4] = (bf16_t)hi.x; o[5] = (bf16_t)hi.y; o[6] = (bf16_t)hi.z; o[7] = (bf16_t)hi.w;
-  *reinterpret_cast<bf16x8_t*>(p) = o;
+template <typename HT>
+__device__ __forceinline__ void store8(HT* p, float4 lo, float4 hi) {
+  vec8<HT> o;
+  o[0] = (HT)lo.x; o[1] = (HT)lo.y; o[2] = (HT)lo.z; o[3] = (HT)lo.w;
+  o[4] = (HT)hi.x; o[5] = (HT)hi.y; o[6] = (HT)hi.z; o[7] = (HT)hi.w;
+  *reinterpret_cast<vec8<HT>*>(p) = o;
 }
 // the arithmetic of the bf16-output epilogues on one quad (v in/out; a = the quad's aux values; k = dropout factors)
 template <int EPI>
@@ -219,9 +221,9 @@ __device__ __forceinline__ float4 epi_math4(float4 v, float4 a, float4 k) {
 }
 // 8 consecutive columns n..n+7 of row m for the epilogues that write bf16: ONE 16-byte store (and 16-byte aux load)
 // per lane instead of two 8-byte ones.  Caller guarantees e.vec8 and n + 7 < N.
-template <int EPI>
+template <int EPI, typename HT>
 __device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, float4 lo, float4 hi, uint32_t byte,
-                                        bool has_pre = false, bf16x8_t pre = bf16x8_t{}, bool has_b = false,
+                                        bool has_pre = false, vec8<HT> pre = vec8<HT>{}, bool has_b = false,
                                         float4 pb0 = make_float4(0.f, 0.f, 0.f, 0.f),
                                         float4 pb1 = make_float4(0.f, 0.f, 0.f, 0.f)) {
   float4 klo = make_float4(1.f, 1.f, 1.f, 1.f), khi = klo;
@@ -244,8 +246,8 @@ __device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, fl
   }
   float4 alo = make_float4(0.f, 0.f, 0.f, 0.f), ahi = alo;
   if (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_MULAUX_T) {
-    bf16x8_t a = pre;
-    if (!has_pre) a = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)e.aux + (size_t)m * e.ldaux + n);
+    vec8<HT> a = pre;
+    if (!has_pre) a = *reinterpret_cast<const vec8<HT>*>((const HT*)e.aux + (size_t)m * e.ldaux + n);
     alo = make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
     ahi = make_float4((float)a[4], (float)a[5], (float)a[6], (float)a[7]);
   }
@@ -253,14 +255,14 @@ __device__ __forceinline__ void epi_oct(const EpiDev& e, int m, int n, int N, fl
     float4 glo, ghi, dlo, dhi;
     gelu_both_f(lo.x, glo.x, dlo.x); gelu_both_f(lo.y, glo.y, dlo.y); gelu_both_f(lo.z, glo.z, dlo.z); gelu_both_f(lo.w, glo.w, dlo.w);
     gelu_both_f(hi.x, ghi.x, dhi.x); gelu_both_f(hi.y, ghi.y, dhi.y); gelu_both_f(hi.z, ghi.z, dhi.z); gelu_both_f(hi.w, ghi.w, dhi.w);
-    store8((bf16_t*)e.out1 + (size_t)m * e.ld1 + n, make_float4(dlo.x * klo.x, dlo.y * klo.y, dlo.z * klo.z, dlo.w * klo.w),
+    store8((HT*)e.out1 + (size_t)m * e.ld1 + n, make_float4(dlo.x * klo.x, dlo.y * klo.y, dlo.z * klo.z, dlo.w * klo.w),
            make_float4(dhi.x * khi.x, dhi.y * khi.y, dhi.z * khi.z, dhi.w * khi.w));
-    store8((bf16_t*)e.out0 + i0, make_float4(glo.x * klo.x, glo.y * klo.y, glo.z * klo.z, glo.w * klo.w),
+    store8((HT*)e.out0 + i0, make_float4(glo.x * klo.x, glo.y * klo.y, glo.z * klo.z, glo.w * klo.w),
            make_float4(ghi.x * khi.x, ghi.y * khi.y, ghi.z * khi.z, ghi.w * khi.w));
     return;
   }
-  if (EPI == TIMHIP_EPI_GELU_DROP_T2) store8((bf16_t*)e.out1 + (size_t)m * e.ld1 + n, lo, hi);
-  store8((bf16_t*)e.out0 + i0, epi_math4<EPI>(lo, alo, klo), epi_math4<EPI>(hi, ahi, khi));
+  if (EPI == TIMHIP_EPI_GELU_DROP_T2) store8((HT*)e.out1 + (size_t)m * e.ld1 + n, lo, hi);
+  store8((HT*)e.out0 + i0, epi_math4<EPI>(lo, alo, klo), epi_math4<EPI>(hi, ahi, khi));
 }
 
 // XCD-aware tile order: block b runs on XCD b % 8 (observed); give each XCD a
@@ -273,7 +275,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 }
 
 // ---------------------------------------------------------------------------
-// bf16 MFMA kernel
+// 16-bit MFMA kernel (HT = bf16_t or f16_t)
 //   BM x BN output tile, WM x WN waves, BKT (32|64) contraction elements per stage, NST-deep LDS ring.
 //   Stages are filled by LDS-DMA issued from inline asm and retired with COUNTED vmcnt waits, so up to
 //   NST-1 stages stay in flight across the per-step barrier (latency of an L2 miss >> one step).
@@ -287,9 +289,9 @@ template <> __device__ __forceinline__ int kswz<64>(int row) { return (row >> 1)
 template <> __device__ __forceinline__ int kswz<32>(int row) { return (row >> 2) & 3; }
 
 // the body of one block: tile `t` (already mapped to a logical tile index) of split `zsplit`
-template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
-__device__ __forceinline__ void gemm_nt_bf16_body(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N,
+template <typename HT, int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
+__device__ __forceinline__ void gemm_nt_h16_body(
+    const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb, int M, int N,
     int K, int ksteps_per_split, EpiDev e, int t, int zsplit) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -396,7 +398,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
   for (int p = 0; p < NST - 1; ++p)
     if (kt0 + p < kt1) stage(kt0 + p, p);
   int buf = 0;
-  bf16x8_t xa[2][TM], wb[2][TN];
+  vec8<HT> xa[2][TM], wb[2][TN];
   // ABL & 16 (tuning builds): per-phase shader-cycle counters of one wave per block, summed into e.aux[0..7]
   constexpr bool PROF = (ABL & 16) != 0;
   long long t_wait = 0, t_issue = 0, t_mma = 0, t_begin = 0, t0 = 0, t1 = 0;
@@ -421,10 +423,10 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
       const int c = kk * 2 + fhalf;
 #pragma unroll
       for (int j = 0; j < TM; ++j)
-        xa[set][j] = *reinterpret_cast<const bf16x8_t*>(base + a_off[j] + ((c ^ a_swz[j]) << 4));
+        xa[set][j] = *reinterpret_cast<const vec8<HT>*>(base + a_off[j] + ((c ^ a_swz[j]) << 4));
 #pragma unroll
       for (int i = 0; i < TN; ++i)
-        wb[set][i] = *reinterpret_cast<const bf16x8_t*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
+        wb[set][i] = *reinterpret_cast<const vec8<HT>*>(base + b_off[i] + ((c ^ b_swz[i]) << 4));
     };
     if ((ABL & 2) == 0 || kt == kt0) load_frags(0, 0);
 #pragma unroll
@@ -435,7 +437,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk & 1][i], xa[kk & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<HT>(wb[kk & 1][i], xa[kk & 1][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
@@ -445,6 +447,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
   if constexpr (PROF) t_loop_end = __builtin_readcyclecounter();
 
   // ---- epilogue: D[i = n][j = m]; lane owns row m = lane & 31 ----
+  const float asc = e.acc_scale ? *e.acc_scale : 1.f;
   if constexpr ((ABL & 8) != 0) {  // ablation: keep the accumulators alive, store (practically) nothing
     if (e.ld0 != -12345) return;
   }
@@ -463,8 +466,8 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
         for (int q = 0; q < 4; ++q) {
           const int n = n0 + wn * (BN / WN) + i * 32 + 4 * fhalf + 8 * q;
           if (n < N)
-            epi_quad<EPI, bf16_t>(e, m, n, N, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                                  acc[i][j][4 * q + 3]);
+            epi_quad<EPI, HT>(e, m, n, N, acc[i][j][4 * q] * asc, acc[i][j][4 * q + 1] * asc, acc[i][j][4 * q + 2] * asc,
+                                  acc[i][j][4 * q + 3] * asc);
         }
     }
     return;
@@ -481,7 +484,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
   float4 rbuf[PD][PRE_RES ? NITQ : 1];
   float2 sbuf[PD][PRE_RES ? NITQ : 1];   // (mean, rstd) of the rows in rbuf when the residual is LayerNorm(res)
   const bool pre_ln = PRE_RES && EPI == TIMHIP_EPI_DROP_RES_F32 && e.vec && e.res != nullptr && e.ln_stats != nullptr;
-  bf16x8_t abuf[PD][PRE_AUX ? (NITO > 0 ? NITO : 1) : 1];
+  vec8<HT> abuf[PD][PRE_AUX ? (NITO > 0 ? NITO : 1) : 1];
   const bool pre_res = PRE_RES && e.vec && e.res != nullptr;
   const bool pre_aux = PRE_AUX && e.vec8;
   auto fetch = [&](auto jc, auto slotc) {
@@ -509,7 +512,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
           const int m = m0 + wm * (BM / WM) + j * 32 + row;
           const int n = n0 + wn * (BN / WN) + ch * 8;
           if (m < M && n + 7 < N)
-            abuf[slot][it] = *reinterpret_cast<const bf16x8_t*>((const bf16_t*)e.aux + (size_t)m * e.ldaux + n);
+            abuf[slot][it] = *reinterpret_cast<const vec8<HT>*>((const HT*)e.aux + (size_t)m * e.ldaux + n);
         }
       }
     }
@@ -557,7 +560,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(ep + frow * EP_LD + i * 32 + 8 * q + 4 * fhalf) =
-            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            make_float4(acc[i][j][4 * q] * asc, acc[i][j][4 * q + 1] * asc, acc[i][j][4 * q + 2] * asc, acc[i][j][4 * q + 3] * asc);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no block barrier needed
     if (epi_has_oct(EPI) && e.vec8) {
       constexpr int OPR = EP_COLS / 8;  // 16-byte output chunks per row
@@ -570,10 +573,10 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 8;
         if (m < M && n + 7 < N) {
-          epi_oct<EPI>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j % PD][PRE_AUX ? it : 0], pre_b8, bias8[0], bias8[1]);
+          epi_oct<EPI, HT>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j % PD][PRE_AUX ? it : 0], pre_b8, bias8[0], bias8[1]);
         } else if (m < M) {
-          if (n < N) epi_quad<EPI, bf16_t>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
-          if (n + 4 < N) epi_quad<EPI, bf16_t>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
+          if (n < N) epi_quad<EPI, HT>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
+          if (n + 4 < N) epi_quad<EPI, HT>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
         }
       }
     } else {
@@ -585,7 +588,7 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
         const int m = m0 + wm * (BM / WM) + j * 32 + row;
         const int n = n0 + wn * (BN / WN) + ch * 4;
         if (m < M && n < N)
-          epi_quad<EPI, bf16_t>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PD][PRE_RES ? it : 0],
+          epi_quad<EPI, HT>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PD][PRE_RES ? it : 0],
                                 pre_b4 && n + 3 < N, bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j % PD][PRE_RES ? it : 0],
                                 lng, lnb);
       }
@@ -608,12 +611,12 @@ __device__ __forceinline__ void gemm_nt_bf16_body(
   }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N,
+template <typename HT, int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_h16_kernel(
+    const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb, int M, int N,
     int K, int ksteps_per_split, EpiDev e) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  gemm_nt_bf16_body<EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>(A, lda, B, ldb, M, N, K, ksteps_per_split, e,
+  gemm_nt_h16_body<HT, EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>(A, lda, B, ldb, M, N, K, ksteps_per_split, e,
                                                            xcd_remap(blockIdx.x, tiles), (int)blockIdx.z);
 }
 
@@ -622,19 +625,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_bf16_kernel(
 // slower (every cross-stream edge costs more than such a launch lasts).
 constexpr int GG_MAX = 6;
 struct GemmGroupDev {
-  const bf16_t* A[GG_MAX]; const bf16_t* B[GG_MAX];
+  const void* A[GG_MAX]; const void* B[GG_MAX];
   int lda[GG_MAX], ldb[GG_MAX], M[GG_MAX], N[GG_MAX], K[GG_MAX], tile0[GG_MAX + 1];
   EpiDev e[GG_MAX];
   int n;
 };
-template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST>
+template <typename HT, int EPI, int BM, int BN, int WM, int WN, int BKT, int NST>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_group_kernel(const GemmGroupDev g) {
   const int t = blockIdx.x;
   int i = 0;
 #pragma unroll
   for (int k = 1; k < GG_MAX; ++k)
     if (k < g.n && t >= g.tile0[k]) i = k;
-  gemm_nt_bf16_body<EPI, BM, BN, WM, WN, BKT, NST, 1, 0>(g.A[i], g.lda[i], g.B[i], g.ldb[i], g.M[i], g.N[i], g.K[i],
+  gemm_nt_h16_body<HT, EPI, BM, BN, WM, WN, BKT, NST, 1, 0>((const HT*)g.A[i], g.lda[i], (const HT*)g.B[i], g.ldb[i], g.M[i], g.N[i], g.K[i],
                                                         g.K[i] / BK, g.e[i], t - g.tile0[i], 0);
 }
 
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i], xa[j], acc[i][j], 0, 0, 0);
     }
   }
+  const float asc = e.acc_scale ? *e.acc_scale : 1.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = m0 + wm * 64 + j * 32 + frow;
@@ -717,8 +721,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
       for (int q = 0; q < 4; ++q) {
         const int n = nb + 8 * q;
         if (n < N)
-          epi_quad<EPI, float>(e, m, n, N, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                               acc[i][j][4 * q + 3]);
+          epi_quad<EPI, float>(e, m, n, N, acc[i][j][4 * q] * asc, acc[i][j][4 * q + 1] * asc, acc[i][j][4 * q + 2] * asc,
+                               acc[i][j][4 * q + 3] * asc);
       }
     }
   }
@@ -821,6 +825,7 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(const float* __restrict
         }
     }
   }
+  const float asc = e.acc_scale ? *e.acc_scale : 1.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int m = m0 + wm * 64 + j * 32 + frow;
@@ -832,15 +837,15 @@ __global__ __launch_bounds__(256) void gemm_nt_x3_kernel(const float* __restrict
       for (int q = 0; q < 4; ++q) {
         const int n = nb + 8 * q;
         if (n < N)
-          epi_quad<EPI, float>(e, m, n, N, acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                               acc[i][j][4 * q + 3]);
+          epi_quad<EPI, float>(e, m, n, N, acc[i][j][4 * q] * asc, acc[i][j][4 * q + 1] * asc, acc[i][j][4 * q + 2] * asc,
+                               acc[i][j][4 * q + 3] * asc);
       }
     }
   }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
-void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int splitk,
+template <typename HT, int EPI, int BM, int BN, int WM, int WN, int BKT, int NST, int GM, int ABL = 0>
+void launch_h16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int splitk,
                  hipStream_t s) {
   const int nk = K / BK;
   const int per = (nk + splitk - 1) / splitk;
@@ -848,12 +853,12 @@ void launch_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, i
   const size_t shmem = (size_t)NST * (BM + BN) * BKT * 2;
   static bool attr_set = false;  // idempotent; a benign race sets it twice at worst
   if (!attr_set && shmem > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_h16_kernel<HT, EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>), grid, dim3(WM * WN * 64), shmem, s,
-                     (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, per, e);
+  hipLaunchKernelGGL((gemm_nt_h16_kernel<HT, EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>), grid, dim3(WM * WN * 64), shmem, s,
+                     (const HT*)A, lda, (const HT*)B, ldb, M, N, K, per, e);
 }
 
 // Tile height.  Two tiles are built: 128 x 128 (2 x 2 waves of 64 x 64) and 160 x 128 (1 x 4 waves of 160 x 32).
@@ -894,7 +899,7 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
   } else {
 #ifdef TIMHIP_TUNING
     if constexpr (EPI == TIMHIP_EPI_STORE_T) {  // ablation builds (tools/gemm_abl.py): variant = 100*ABL + tile
-#define ABLV(T, ...) case T: launch_bf16<EPI, __VA_ARGS__>(A, lda, B, ldb, M, N, K, e, splitk, s); return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+#define ABLV(T, ...) case T: launch_h16<bf16_t, EPI, __VA_ARGS__>(A, lda, B, ldb, M, N, K, e, splitk, s); return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
       switch (variant) {
         ABLV(100, 128, 128, 2, 2, 64, 2, 1, 1) ABLV(200, 128, 128, 2, 2, 64, 2, 1, 2) ABLV(300, 128, 128, 2, 2, 64, 2, 1, 3)
         ABLV(700, 128, 128, 2, 2, 64, 2, 1, 7) ABLV(800, 128, 128, 2, 2, 64, 2, 1, 8)
@@ -910,25 +915,25 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
     }
     if constexpr (tunable<EPI>()) {
       switch (variant) {
-        case 1: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 2: launch_bf16<EPI, 128, 128, 2, 2, 32, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 3: launch_bf16<EPI, 256, 128, 4, 2, 64, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 4: launch_bf16<EPI, 256, 256, 2, 4, 32, 4, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 5: launch_bf16<EPI, 256, 256, 4, 2, 32, 4, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 6: launch_bf16<EPI, 256, 128, 4, 2, 32, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 7: launch_bf16<EPI, 128, 128, 2, 2, 64, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 8: launch_bf16<EPI, 256, 256, 2, 4, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 9: launch_bf16<EPI, 128, 128, 2, 2, 32, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 11: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 12: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 13: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 39>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 10: launch_bf16<EPI, 128, 128, 2, 2, 32, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 14: launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 19: launch_bf16<EPI, 192, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 22: launch_bf16<EPI, 320, 128, 2, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 24: launch_bf16<EPI, 160, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        case 25: launch_bf16<EPI, 192, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
-        default: launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 1: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 64, 2, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 2: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 32, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 3: launch_h16<bf16_t, EPI, 256, 128, 4, 2, 64, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 4: launch_h16<bf16_t, EPI, 256, 256, 2, 4, 32, 4, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 5: launch_h16<bf16_t, EPI, 256, 256, 4, 2, 32, 4, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 6: launch_h16<bf16_t, EPI, 256, 128, 4, 2, 32, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 7: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 64, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 8: launch_h16<bf16_t, EPI, 256, 256, 2, 4, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 9: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 32, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 11: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 64, 2, 4>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 12: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 64, 2, 16>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 13: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 64, 2, 39>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 10: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 32, 3, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 14: launch_h16<bf16_t, EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 19: launch_h16<bf16_t, EPI, 192, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 22: launch_h16<bf16_t, EPI, 320, 128, 2, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 24: launch_h16<bf16_t, EPI, 160, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        case 25: launch_h16<bf16_t, EPI, 192, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
+        default: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
       }
     } else
 #endif
@@ -938,12 +943,13 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
       // half of the 512 block slots, 64 x 128 tiles (1 x 4 waves of 64 x 32, 48 KB of LDS: three blocks per CU) double
       // the number of blocks - these launches are occupancy-bound, not staging-bound
       const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
-      if (t128 <= 256 && M > 64)
-        launch_bf16<EPI, 64, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
-      else if (tall_tile_wins(M, N, splitk))
-        launch_bf16<EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
-      else
-        launch_bf16<EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+      DISPATCH_H16(precision,
+        if (t128 <= 256 && M > 64)
+          launch_h16<HT, EPI, 64, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+        else if (tall_tile_wins(M, N, splitk))
+          launch_h16<HT, EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+        else
+          launch_h16<HT, EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s));
     }
   }
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
@@ -957,8 +963,7 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
                         const TimEpi& te, int splitk, EpiDev& e) {
   if (!A || !B || !te.out0) return TIMHIP_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return TIMHIP_EINVAL;
-  if (precision != TIMHIP_PREC_BF16 && precision != TIMHIP_PREC_FP32 && precision != TIMHIP_PREC_BF16X3)
-    return TIMHIP_EUNSUPPORTED;
+  if (!valid_precision(precision)) return TIMHIP_EUNSUPPORTED;
   const int Kp = round_up(K, 64);
   if (lda % 64 || ldb % 64 || lda < Kp || ldb < Kp) return TIMHIP_EALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return TIMHIP_EALIGN;
@@ -971,6 +976,7 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
   e.site = te.site; e.seed = te.seed;
   e.mask = (const uint8_t*)te.mask; e.ldmask = te.ldmask;
   e.ln_stats = te.ln_stats; e.ln_w = te.ln_w; e.ln_b = te.ln_b;
+  e.acc_scale = te.acc_scale;
   if (e.ln_stats && (epi != TIMHIP_EPI_DROP_RES_F32 || !e.res || !e.ln_w || !e.ln_b)) return TIMHIP_EINVAL;
   e.slab_stride = splitk > 1 ? (long long)M * te.ld0 : 0;
 
@@ -982,7 +988,7 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
   e.vec = vec ? 1 : 0;
   // 8-element accesses of the bf16 outputs / aux (N % 4 == 0 is implied where it matters: dropout needs it, and a
   // ragged last chunk falls back to quads)
-  bool vec8 = vec && precision == TIMHIP_PREC_BF16 && (e.ld0 % 8 == 0);
+  bool vec8 = vec && h16_storage(precision) && (e.ld0 % 8 == 0);
   if (e.out1) vec8 = vec8 && (e.ld1 % 8 == 0);
   if (e.aux) vec8 = vec8 && (e.ldaux % 8 == 0);
   e.vec8 = vec8 ? 1 : 0;
@@ -992,7 +998,7 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
 
 // n <= 6 independent bf16 problems with the same epilogue as one grid of 64 x 128 tiles (small problems: the heads)
 int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, hipStream_t s) {
-  if (precision != TIMHIP_PREC_BF16) return TIMHIP_EUNSUPPORTED;
+  if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
   if (!items || n < 1 || n > GG_MAX) return TIMHIP_EINVAL;
   if (epi != TIMHIP_EPI_STORE_F32 && epi != TIMHIP_EPI_ADD_F32 && epi != TIMHIP_EPI_STORE_T && epi != TIMHIP_EPI_RELU_T)
     return TIMHIP_EUNSUPPORTED;
@@ -1009,7 +1015,7 @@ int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, h
     const TimGemmItem& t = items[i];
     const int rc = prepare_gemm(precision, epi, t.A, t.lda, t.B, t.ldb, t.M, t.N, t.K, t.e, 1, g.e[i]);
     if (rc) return rc;
-    g.A[i] = (const bf16_t*)t.A; g.B[i] = (const bf16_t*)t.B; g.lda[i] = t.lda; g.ldb[i] = t.ldb;
+    g.A[i] = t.A; g.B[i] = t.B; g.lda[i] = t.lda; g.ldb[i] = t.ldb;
     g.M[i] = t.M; g.N[i] = t.N; g.K[i] = round_up(t.K, 64);
     g.tile0[i + 1] = g.tile0[i] + ((t.M + 63) / 64) * ((t.N + 127) / 128);
     flops += 2.0 * t.M * t.N * t.K;
@@ -1020,13 +1026,13 @@ int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, h
     // the blocks again
     for (int i = 0; i < n; ++i) g.tile0[i + 1] = g.tile0[i] + ((items[i].M + 63) / 64) * ((items[i].N + 63) / 64);
     for (int i = n; i < GG_MAX; ++i) g.tile0[i + 1] = g.tile0[n];
-    hipLaunchKernelGGL((gemm_nt_group_kernel<TIMHIP_EPI_ADD_F32, 64, 64, 2, 2, 64, 2>), dim3((unsigned)g.tile0[n]), dim3(256),
-                       (size_t)2 * (64 + 64) * 64 * 2, s, g);
+    DISPATCH_H16(precision, hipLaunchKernelGGL((gemm_nt_group_kernel<HT, TIMHIP_EPI_ADD_F32, 64, 64, 2, 2, 64, 2>),
+                                               dim3((unsigned)g.tile0[n]), dim3(256), (size_t)2 * (64 + 64) * 64 * 2, s, g));
     return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
   }
   const dim3 grid((unsigned)g.tile0[n]);
   const size_t shmem = (size_t)2 * (64 + 128) * 64 * 2;
-#define GROUP(X) case X: hipLaunchKernelGGL((gemm_nt_group_kernel<X, 64, 128, 1, 4, 64, 2>), grid, dim3(256), shmem, s, g); break;
+#define GROUP(X) case X: DISPATCH_H16(precision, hipLaunchKernelGGL((gemm_nt_group_kernel<HT, X, 64, 128, 1, 4, 64, 2>), grid, dim3(256), shmem, s, g)); break;
   switch (epi) {
     GROUP(TIMHIP_EPI_STORE_F32)
     GROUP(TIMHIP_EPI_ADD_F32)

@@ -309,15 +309,9 @@ int timhip_drloc_gather(int precision, const float* x1, const float* x2, int64_t
       row_stride % 4 || batch_stride % 4)
     return TIMHIP_EINVAL;
   if ((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)out) & 15) != 0) return TIMHIP_EALIGN;
-  if (f32_storage(precision)) {
-    hipLaunchKernelGGL(drloc_gather_kernel<float>, dim3(n * m, 2), dim3(128), 0, (hipStream_t)stream, x1, x2,
-                       (long long)batch_stride, (long long)row_stride, l, D, (const long long*)pos1,
-                       (const long long*)pos2, m, (float*)out, ld);
-  } else {
-    hipLaunchKernelGGL(drloc_gather_kernel<bf16_t>, dim3(n * m, 2), dim3(128), 0, (hipStream_t)stream, x1, x2,
-                       (long long)batch_stride, (long long)row_stride, l, D, (const long long*)pos1,
-                       (const long long*)pos2, m, (bf16_t*)out, ld);
-  }
+  DISPATCH_T(precision, hipLaunchKernelGGL(drloc_gather_kernel<T>, dim3(n * m, 2), dim3(128), 0, (hipStream_t)stream, x1, x2,
+                                           (long long)batch_stride, (long long)row_stride, l, D, (const long long*)pos1,
+                                           (const long long*)pos2, m, (T*)out, ld));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

@@ -1,7 +1,7 @@
 // LDS tile images and transposing fragment reads shared by the MFMA attention and the
 // weight-gradient kernels (gfx950).
 //
-// A [rows][DH] bf16 tile has row stride DH*2 bytes and its 16-byte chunk index is XORed with
+// A [rows][DH] 16-bit (bf16 / fp16) tile has row stride DH*2 bytes and its 16-byte chunk index is XORed with
 // swz<DH>(row), chosen so that BOTH fragment access patterns are bank-conflict free:
 //   ds_read_b128      : 16 different rows, same chunk          -> 16 distinct 16-B slots
 //   ds_read_b64_tr_b16: 4 rows x 64 B (two 16-lane groups)     -> 16 distinct 16-B slots
@@ -18,27 +18,31 @@ template <int DH> __device__ __forceinline__ int tile_off(int row, int c) {
   return row * (DH * 2) + ((c ^ swz<DH>(row)) << 4);
 }
 
-typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
-
-__device__ __forceinline__ bf16x4_t tr_read(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_ptr)(p));
+// ds_read_b64_tr_b16: the transposing read moves 16-bit patterns, whatever they encode
+typedef short s16x4_lds_t __attribute__((ext_vector_type(4)));
+template <typename HT>
+__device__ __forceinline__ vec4<HT> tr_read(const char* p) {
+  return __builtin_bit_cast(vec4<HT>, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_lds_t*)(p)));
 }
 
-__device__ __forceinline__ bf16x8_t cat8(bf16x4_t a, bf16x4_t b) {
-  bf16x8_t r;
+template <typename HT>
+__device__ __forceinline__ vec8<HT> cat8(vec4<HT> a, vec4<HT> b) {
+  vec8<HT> r;
   r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
   r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
   return r;
 }
 
-__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& v, int a) {
-  bf16x8_t r;
+template <typename HT>
+__device__ __forceinline__ vec8<HT> pack8(const f32x16_t& v, int a) {
+  vec8<HT> r;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) r[u] = (bf16_t)v[8 * a + u];
+  for (int u = 0; u < 8; ++u) r[u] = (HT)v[8 * a + u];
   return r;
 }
 
-__device__ __forceinline__ float dot8(bf16x8_t a, bf16x8_t b) {
+template <typename HT>
+__device__ __forceinline__ float dot8(vec8<HT> a, vec8<HT> b) {
   float s = 0.f;
 #pragma unroll
   for (int u = 0; u < 8; ++u) s = fmaf((float)a[u], (float)b[u], s);
@@ -46,43 +50,43 @@ __device__ __forceinline__ float dot8(bf16x8_t a, bf16x8_t b) {
 }
 
 // stage `nrows` rows (row r -> src + r*ld, DH bf16 each; rows >= nvalid are zero) into a tile
-template <int DH>
-__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, size_t ld, int nrows, int nvalid, int tid,
+template <int DH, typename HT>
+__device__ __forceinline__ void stage_tile(char* tile, const HT* src, size_t ld, int nrows, int nvalid, int tid,
                                            int nthreads) {
   constexpr int NC = DH / 8, UN = 8;
   // all of a thread's global loads are issued before the first LDS write (one HBM latency per tile, not one per chunk)
   for (int i0 = tid; i0 < nrows * NC; i0 += nthreads * UN) {
-    bf16x8_t v[UN];
+    vec8<HT> v[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int idx = i0 + u * nthreads;
       const int row = idx / NC, c = idx % NC;
       if (idx < nrows * NC && row < nvalid) {
-        v[u] = *reinterpret_cast<const bf16x8_t*>(src + (size_t)row * ld + c * 8);
+        v[u] = *reinterpret_cast<const vec8<HT>*>(src + (size_t)row * ld + c * 8);
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[u][e] = (bf16_t)0.f;
+        for (int e = 0; e < 8; ++e) v[u][e] = (HT)0.f;
       }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int idx = i0 + u * nthreads;
-      if (idx < nrows * NC) *reinterpret_cast<bf16x8_t*>(tile + tile_off<DH>(idx / NC, idx % NC)) = v[u];
+      if (idx < nrows * NC) *reinterpret_cast<vec8<HT>*>(tile + tile_off<DH>(idx / NC, idx % NC)) = v[u];
     }
   }
 }
 
 // V^T / K^T fragment for the PV-style MFMA: lane (i = lane & 31 -> dh 32*db + i, g = lane >> 5)
 // gets the 8 values tile[key(u)][dh], key(u) = kb + 8*(u>>2) + 4*g + (u&3)   (kb = 32*jb + 16*a)
-template <int DH>
-__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int kb, int db, int lane) {
+template <int DH, typename HT>
+__device__ __forceinline__ vec8<HT> tr_frag(const char* tile, int kb, int db, int lane) {
   const int gid = lane >> 4, p = lane & 15, g = gid >> 1;
   const int row0 = kb + 4 * g + (p >> 2);
   const int c = 4 * db + 2 * (gid & 1) + ((p & 3) >> 1);
   const int sub = (p & 1) * 8;
-  bf16x4_t lo = tr_read(tile + tile_off<DH>(row0, c) + sub);
-  bf16x4_t hi = tr_read(tile + tile_off<DH>(row0 + 8, c) + sub);
-  return cat8(lo, hi);
+  vec4<HT> lo = tr_read<HT>(tile + tile_off<DH>(row0, c) + sub);
+  vec4<HT> hi = tr_read<HT>(tile + tile_off<DH>(row0 + 8, c) + sub);
+  return cat8<HT>(lo, hi);
 }
 
 
@@ -99,10 +103,11 @@ __device__ __forceinline__ void pair_exchange(float (&out)[8], float e0, float e
   if (g == 0) { out[0] = e0; out[1] = e1; out[2] = e2; out[3] = e3; out[4] = r0; out[5] = r1; out[6] = r2; out[7] = r3; }
   else { out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3; out[4] = o0; out[5] = o1; out[6] = o2; out[7] = o3; }
 }
-__device__ __forceinline__ void store8_bf16(bf16_t* p, const float (&v)[8]) {
-  bf16x8_t o;
-  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-  o[4] = (bf16_t)v[4]; o[5] = (bf16_t)v[5]; o[6] = (bf16_t)v[6]; o[7] = (bf16_t)v[7];
-  *reinterpret_cast<bf16x8_t*>(p) = o;
+template <typename HT>
+__device__ __forceinline__ void store8_h(HT* p, const float (&v)[8]) {
+  vec8<HT> o;
+  o[0] = (HT)v[0]; o[1] = (HT)v[1]; o[2] = (HT)v[2]; o[3] = (HT)v[3];
+  o[4] = (HT)v[4]; o[5] = (HT)v[5]; o[6] = (HT)v[6]; o[7] = (HT)v[7];
+  *reinterpret_cast<vec8<HT>*>(p) = o;
 }
 

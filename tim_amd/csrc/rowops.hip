@@ -187,8 +187,10 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, long long n, 
 // fp32 rows -> T rows with optional dropout and zero padding
 template <typename T>
 __global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int cols, int lds_, T* __restrict__ dst,
-                                 int ld, uint32_t thr, float scale, TimSeed seed, uint32_t site) {
+                                 int ld, uint32_t thr, float scale, TimSeed seed, uint32_t site,
+                                 const float* __restrict__ vscale) {
   const int r = blockIdx.y;
+  const float vs = vscale ? *vscale : 1.f;   // factor on the values (gradient scale of the fp16 mode)
   const int colsq = (cols + 3) >> 2;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < ld; q += gridDim.x * blockDim.x) {
     float k[4] = {1.f, 1.f, 1.f, 1.f};
@@ -196,7 +198,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int co
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = q * 4 + j;
-      if (c < ld) dst[(size_t)r * ld + c] = OpT<T>::from_f(c < cols ? src[(size_t)r * lds_ + c] * k[j] : 0.f);
+      if (c < ld) dst[(size_t)r * ld + c] = OpT<T>::from_f(c < cols ? src[(size_t)r * lds_ + c] * k[j] * vs : 0.f);
     }
   }
 }
@@ -320,8 +322,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      T* __restrict__ dyt, int ldt, uint32_t thr, float scale,
                                                      TimSeed seed, uint32_t site, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows_pb,
-                                                     float* __restrict__ partial) {
+                                                     float* __restrict__ partial, const float* __restrict__ t_scale) {
   extern __shared__ float red[];  // [4][2][cols]
+  const float ts = t_scale ? *t_scale : 1.f;   // factor on the operand-dtype copy (gradient scale of the fp16 mode)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (cols + 255) >> 8;
   float4 ag[LN_MAXV], ab[LN_MAXV];
@@ -387,8 +390,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (act != 0) { o0 *= ga[i].x; o1 *= ga[i].y; o2 *= ga[i].z; o3 *= ga[i].w; }
         if (dyf) store4<float>(dyf + (size_t)row * lddy + c, o0, o1, o2, o3);
         if (dyt) {
-          float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
-          if (thr != 0u) drop_mask4(seed, site, ((uint64_t)row * cols + c) >> 2, thr, scale, k0, k1, k2, k3);
+          float k0 = ts, k1 = ts, k2 = ts, k3 = ts;
+          if (thr != 0u) {
+            drop_mask4(seed, site, ((uint64_t)row * cols + c) >> 2, thr, scale, k0, k1, k2, k3);
+            k0 *= ts; k1 *= ts; k2 *= ts; k3 *= ts;
+          }
           store4<T>(dyt + (size_t)row * ldt + c, o0 * k0, o1 * k1, o2 * k2, o3 * k3);
         }
       }
@@ -440,7 +446,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restrict__ times, int rows, int d,
                                                           const float* __restrict__ w, const T* __restrict__ dh,
                                                           int ld, float* __restrict__ dw, float* __restrict__ db,
-                                                          float* __restrict__ dt, int rows_pb) {
+                                                          float* __restrict__ dt, int rows_pb,
+                                                          const float* __restrict__ out_scale) {
+  const float os = out_scale ? *out_scale : 1.f;   // factor on everything written (1 / gradient scale of the fp16 mode)
   // one block: rows [r0, r1).  dw/db: a thread owns 4 consecutive columns (one vector load per row) and every RL-th row;
   // the row lanes are combined through LDS before the block's atomics (3 per column).  per-row dt via wave reduction
   const int r0 = blockIdx.x * rows_pb, r1 = min(rows, r0 + rows_pb);
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int j = 4 * q + u;
-          atomicAdd(dw + 2 * j, v0[u]); atomicAdd(dw + 2 * j + 1, v1[u]); atomicAdd(db + j, v2[u]);
+          atomicAdd(dw + 2 * j, v0[u] * os); atomicAdd(dw + 2 * j + 1, v1[u] * os); atomicAdd(db + j, v2[u] * os);
         }
       }
     }
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
         const float g = OpT<T>::to_f(dh[(size_t)r * ld + j]);
         a0 += g * times[2 * r]; a1 += g * times[2 * r + 1]; a2 += g;
       }
-      atomicAdd(dw + 2 * j, a0); atomicAdd(dw + 2 * j + 1, a1); atomicAdd(db + j, a2);
+      atomicAdd(dw + 2 * j, a0 * os); atomicAdd(dw + 2 * j + 1, a1 * os); atomicAdd(db + j, a2 * os);
     }
   }
   if (dt) {
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
         s0 += g * w[2 * j]; s1 += g * w[2 * j + 1];
       }
       s0 = wave_sum(s0); s1 = wave_sum(s1);
-      if (lane == 0) { dt[2 * r] = s0; dt[2 * r + 1] = s1; }
+      if (lane == 0) { dt[2 * r] = s0 * os; dt[2 * r + 1] = s1 * os; }
     }
   }
 }
@@ -706,16 +714,66 @@ __global__ void scatter_ranges_add_kernel(int B, int S, int E, float* __restrict
 struct CastMany {
   const float* src[RR_MAX]; void* dst[RR_MAX];
   int rows[RR_MAX], cols[RR_MAX], ld[RR_MAX];
+  const float* vscale;   // device scalar or NULL: factor on the values
 };
 template <typename T>
 __global__ void cast_many_kernel(CastMany cm) {
   const int i = blockIdx.z;
   const int r = blockIdx.y;
   if (r >= cm.rows[i]) return;
+  const float vs = cm.vscale ? *cm.vscale : 1.f;
   const float* src = cm.src[i] + (size_t)r * cm.cols[i];
   T* dst = (T*)cm.dst[i] + (size_t)r * cm.ld[i];
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cm.ld[i]; c += gridDim.x * blockDim.x)
-    dst[c] = OpT<T>::from_f(c < cm.cols[i] ? src[c] : 0.f);
+    dst[c] = OpT<T>::from_f(c < cm.cols[i] ? src[c] * vs : 0.f);
+}
+
+// ---------------------------------------------------------------------------
+// Gradient scale of the fp16 mode (timhip_grad_scale): S = the power of two that brings the largest |cotangent| to
+// `target`; out = {S, 1/S, scratch, scratch}.  One launch: every block folds its maximum into out[2] (float bits compare
+// like unsigned integers for non-negative values), the last block to arrive (ticket in out[3]) writes S and 1/S and
+// clears the scratch words for the next call.
+// ---------------------------------------------------------------------------
+constexpr int GS_MAX = 8;
+struct GsList { const float* p[GS_MAX]; long long n[GS_MAX]; int count; };
+__global__ __launch_bounds__(256) void grad_scale_kernel(GsList gl, float target, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = 0; i < gl.count; ++i) {
+    const float* __restrict__ p = gl.p[i];
+    const long long n = gl.n[i], n4 = n >> 2;
+    const bool al = (((uintptr_t)p) & 15) == 0;
+    if (al) {
+      for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
+    }
+    for (long long j = (al ? 4 * n4 : 0) + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long long)gridDim.x * blockDim.x)
+      m = fmaxf(m, fabsf(p[j]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    unsigned* w = reinterpret_cast<unsigned*>(out);
+    if (!(m <= 3.0e38f)) m = 3.0e38f;   // inf / nan cotangents: smallest scale
+    atomicMax(w + 2, __float_as_uint(m));
+    __threadfence();
+    const unsigned ticket = atomicAdd(w + 3, 1u);
+    if (ticket == gridDim.x - 1) {
+      const float amax = __uint_as_float(atomicMax(w + 2, 0u));
+      float S = 1.f;
+      if (amax > 0.f) {
+        int e = (int)floorf(log2f(target / amax));
+        e = e < -40 ? -40 : (e > 40 ? 40 : e);
+        S = exp2f((float)e);
+      }
+      out[0] = S; out[1] = 1.f / S;
+      atomicExch(w + 2, 0u); atomicExch(w + 3, 0u);
+    }
+  }
 }
 
 }  // namespace
@@ -723,11 +781,6 @@ __global__ void cast_many_kernel(CastMany cm) {
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-#define DISPATCH_T(prec, ...)                                    \
-  do {                                                           \
-    if (f32_storage(prec)) { using T = float; __VA_ARGS__; } \
-    else { using T = bf16_t; __VA_ARGS__; }                      \
-  } while (0)
 
 int tim_transpose(int precision, const void* src, int rows, int cols, int lds_, void* dst, int ld, float* colsum,
                   hipStream_t s) {
@@ -792,7 +845,7 @@ size_t tim_layernorm_bwd_ws(int rows, int cols) { return (size_t)((rows + 15) / 
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
                       float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, float* partial_ws,
-                      hipStream_t s, bool defer_colsum) {
+                      hipStream_t s, bool defer_colsum, const float* t_scale) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
     return TIMHIP_EUNSUPPORTED;
@@ -802,7 +855,7 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
-                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws)
+                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale)
   const int nv = (cols + 255) / 256;
   DISPATCH_T(precision, if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4); else LN_BWD(8));
 #undef LN_BWD
@@ -883,13 +936,13 @@ int timhip_colsum(int precision, const void* src, int rows, int cols, int ld, fl
 }
 
 int timhip_cast_rows(int precision, const float* src, int rows, int cols, int lds_, void* dst, int ld, float p_drop,
-                     uint64_t seed, uint32_t site, void* stream) {
+                     uint64_t seed, uint32_t site, const float* vscale, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0 || ld < cols || ld % 4) return TIMHIP_EINVAL;
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   dim3 grid((ld / 4 + 255) / 256, rows);
   DISPATCH_T(precision, hipLaunchKernelGGL(cast_rows_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, rows,
-                                           cols, lds_, (T*)dst, ld, thr, scale, seed, site));
+                                           cols, lds_, (T*)dst, ld, thr, scale, seed, site, vscale));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
@@ -921,9 +974,10 @@ int timhip_layernorm_fwd(int precision, const float* y, int rows, int cols, int 
 
 int timhip_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
                          int rows, int cols, int act, const float* w, float* dy_f32, int lddy, void* dy_T, int ldt,
-                         float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, void* stream) {
+                         float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, const float* t_scale,
+                         void* stream) {
   return tim_layernorm_bwd(precision, dx, lddx, y, ldy, stats, rows, cols, act, w, dy_f32, lddy, dy_T, ldt, p_drop,
-                           seed, site, dgamma, dbeta, nullptr, (hipStream_t)stream);
+                           seed, site, dgamma, dbeta, nullptr, (hipStream_t)stream, false, t_scale);
 }
 
 int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const float* w, const float* b, void* h,
@@ -937,12 +991,12 @@ int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const
 }
 
 int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const float* w, const void* dh, int ld,
-                       float* dw, float* db, float* dt, void* stream) {
+                       float* dw, float* db, float* dt, const float* out_scale, void* stream) {
   if (!times || !w || !dh || !dw || !db || rows <= 0) return TIMHIP_EINVAL;
   const int rpb = rows > 4096 ? 64 : 32;   // every block ends with 3*d memory-side atomics onto the same addresses
   dim3 grid((rows + rpb - 1) / rpb);
   DISPATCH_T(precision, hipLaunchKernelGGL(time_l1_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, times,
-                                           rows, d, w, (const T*)dh, ld, dw, db, dt, rpb));
+                                           rows, d, w, (const T*)dh, ld, dw, db, dt, rpb, out_scale));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
@@ -1025,9 +1079,10 @@ int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, con
 }
 
 int timhip_cast_rows_many(int precision, int count, const float* const* src, const int* rows, const int* cols,
-                          void* const* dst, const int* ld, void* stream) {
+                          void* const* dst, const int* ld, const float* scale, void* stream) {
   if (count < 1 || count > RR_MAX || !src || !rows || !cols || !dst || !ld) return TIMHIP_EINVAL;
   CastMany cm;
+  cm.vscale = scale;
   int maxr = 0, maxld = 0;
   for (int i = 0; i < RR_MAX; ++i) {
     const bool on = i < count;
@@ -1059,6 +1114,23 @@ int timhip_ln_partials_reduce(const float* partials, int nsets, int rows, int co
 int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, int n, float* dx, void* stream) {
   if (!d_rows || !dx || n <= 0 || E % 4) return TIMHIP_EINVAL;
   hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(B * n), dim3(256), 0, (hipStream_t)stream, d_rows, B, S, E, s0, n, dx);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_grad_scale(const float* const* cot, const long long* counts, int n, float target, float* out, void* stream) {
+  if (!cot || !counts || n < 1 || n > GS_MAX || !out || !(target > 0.f)) return TIMHIP_EINVAL;
+  GsList gl;
+  gl.count = n;
+  long long total = 0;
+  for (int i = 0; i < GS_MAX; ++i) {
+    gl.p[i] = i < n ? cot[i] : nullptr; gl.n[i] = i < n ? counts[i] : 0;
+    if (i < n && (!cot[i] || counts[i] < 0)) return TIMHIP_EINVAL;
+    total += gl.n[i];
+  }
+  long long blocks = (total / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gl, target, out);
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

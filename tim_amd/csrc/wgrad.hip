@@ -30,15 +30,18 @@ constexpr int WM = 64;    // contraction rows per step
 // One work item: the 128 x 128 tile (n0, k0) of dW over the contraction steps [s0, s1) of 64 rows.  `out` is an [N, K] fp32
 // matrix (a slab of partial sums, or dW itself when the contraction is not split), `db_out` an [N] vector (first k-tile
 // column only).  accumulate: out += / db_out += instead of =.
+template <typename HT>
 struct WgTile {
-  const bf16_t* dY; const bf16_t* X; float* out; float* db_out;
+  const HT* dY; const HT* X; float* out; float* db_out;
   int ldy, ldx, M, N, K, n0, k0, s0, s1, do_bias, accumulate;
+  float alpha;   // factor on what is written (1 for slabs; 1 / gradient scale for final outputs of the fp16 mode)
 };
 
-__device__ __forceinline__ void wgrad_tile(const WgTile& a, char* lds) {
+template <typename HT>
+__device__ __forceinline__ void wgrad_tile(const WgTile<HT>& a, char* lds) {
   constexpr int TILE_BYTES = WM * WT * 2;
-  const bf16_t* __restrict__ dY = a.dY;
-  const bf16_t* __restrict__ X = a.X;
+  const HT* __restrict__ dY = a.dY;
+  const HT* __restrict__ X = a.X;
   const int ldy = a.ldy, ldx = a.ldx, M = a.M, N = a.N, K = a.K, n0 = a.n0, k0 = a.k0, s0 = a.s0, s1 = a.s1;
   const bool do_bias = a.do_bias != 0;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -112,25 +115,25 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& a, char* lds) {
     char* sX = sY + TILE_BYTES;
     if (st * WM + WM > M) {  // last, partial step: zero the rows >= M of both tiles (uniform branch)
       const int first = M - st * WM;
-      bf16x8_t z;
+      vec8<HT> z;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) z[u] = (bf16_t)0.f;
+      for (int u = 0; u < 8; ++u) z[u] = (HT)0.f;
       for (int idx = tid; idx < (WM - first) * 16; idx += 256) {
         const int off = (first + idx / 16) * 256 + (idx % 16) * 16;  // whole rows: the chunk swizzle stays inside a row
-        *reinterpret_cast<bf16x8_t*>(sY + off) = z;
-        *reinterpret_cast<bf16x8_t*>(sX + off) = z;
+        *reinterpret_cast<vec8<HT>*>(sY + off) = z;
+        *reinterpret_cast<vec8<HT>*>(sX + off) = z;
       }
       __syncthreads();
     }
-    bf16x8_t xf[2][2], yf[2][2];
+    vec8<HT> xf[2][2], yf[2][2];
     auto load_frags = [&](int ms, int set) {
       // rows advance by 16 per ms (16*256 B) and swz<128>(row + 16) == swz<128>(row): immediates
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        xf[set][i] = cat8(tr_read(sX + xtr[i][0] + ms * 4096), tr_read(sX + xtr[i][1] + ms * 4096));
+        xf[set][i] = cat8<HT>(tr_read<HT>(sX + xtr[i][0] + ms * 4096), tr_read<HT>(sX + xtr[i][1] + ms * 4096));
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        yf[set][j] = cat8(tr_read(sY + ytr[j][0] + ms * 4096), tr_read(sY + ytr[j][1] + ms * 4096));
+        yf[set][j] = cat8<HT>(tr_read<HT>(sY + ytr[j][0] + ms * 4096), tr_read<HT>(sY + ytr[j][1] + ms * 4096));
     };
     load_frags(0, 0);
 #pragma unroll
@@ -141,7 +144,7 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& a, char* lds) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[ms & 1][i], yf[ms & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<HT>(xf[ms & 1][i], yf[ms & 1][j], acc[i][j]);
       if (do_bias && wk == 0) {  // bias gradient: column sums of dY straight from the B fragments
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -172,7 +175,8 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& a, char* lds) {
     for (int it = 0; it < 8; ++it) {
       const int idx = it * 64 + lane;
       const int row = idx >> 4, ch = idx & 15;
-      const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
+      float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
+      v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
       const int n = n0 + wn * 64 + j * 32 + row;
       const int k = k0 + wk * 64 + ch * 4;
       if (n < N) {
@@ -195,14 +199,15 @@ __device__ __forceinline__ void wgrad_tile(const WgTile& a, char* lds) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (do_bias && wk == 0) {
       const int n = n0 + wn * 64 + j * 32 + li;
-      const float t2 = bsum[j] + __shfl_xor(bsum[j], 32, 64);
+      const float t2 = (bsum[j] + __shfl_xor(bsum[j], 32, 64)) * a.alpha;
       if (g == 0 && n < N) a.db_out[n] = a.accumulate ? a.db_out[n] + t2 : t2;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __restrict__ dY, int ldy,
-                                                            const bf16_t* __restrict__ X, int ldx, int M, int N,
+template <typename HT>
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(const HT* __restrict__ dY, int ldy,
+                                                            const HT* __restrict__ X, int ldx, int M, int N,
                                                             int K, int steps_per_split, float* __restrict__ slab,
                                                             long long slab_stride, float* __restrict__ db_slab) {
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][sY 16 KB | sX 16 KB]
@@ -215,7 +220,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
   const int zsplit = w / ntiles;
   const int t = w - zsplit * ntiles;
   const int nsteps = (M + WM - 1) / WM;
-  WgTile a;
+  WgTile<HT> a;
+  a.alpha = 1.f;
   a.dY = dY; a.X = X; a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
   // consecutive work items share the dY panel (same n-tile): k-tile fastest
   a.n0 = (t / tiles_k) * WT; a.k0 = (t % tiles_k) * WT;
@@ -236,22 +242,24 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(const bf16_t* __rest
 // tail instead of four.
 constexpr int WG_MAX = 8;
 struct WgGroup {
-  const bf16_t* dY[WG_MAX]; const bf16_t* X[WG_MAX]; float* dW[WG_MAX]; float* db[WG_MAX];
+  const void* dY[WG_MAX]; const void* X[WG_MAX]; float* dW[WG_MAX]; float* db[WG_MAX];
   int ldy[WG_MAX], ldx[WG_MAX], N[WG_MAX], K[WG_MAX];
   int tile0[WG_MAX + 1];          // first work tile of every item (prefix sums), tile0[n] = total
   long long off[WG_MAX + 1];      // element offset of every item's [N, K] block inside one slab
   int boff[WG_MAX + 1];           // same for the bias slabs
   int n, M, steps_per_split, splits, accumulate;
   float* slab; float* db_slab;    // [splits][off[n]] and [splits][boff[n]] (splits > 1 only)
+  const float* out_scale;         // device scalar or NULL: factor on the final outputs (1 / gradient scale of the fp16 mode)
 };
 
+template <typename HT>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int ntiles = g.tile0[g.n];
   const int w = xcd_remap_w(blockIdx.x, gridDim.x);
   const int zsplit = w / ntiles;
   const int t = w - zsplit * ntiles;
-  WgTile a;
+  WgTile<HT> a;
   int tl = t, tiles_k = 1;
   long long off = 0;
   int boff = 0;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g) {
 #pragma unroll
   for (int i = 0; i < WG_MAX; ++i) {   // static indexing of the kernel-argument arrays (uniform select)
     if (i < g.n && t >= g.tile0[i]) {
-      a.dY = g.dY[i]; a.X = g.X[i]; a.ldy = g.ldy[i]; a.ldx = g.ldx[i]; a.N = g.N[i]; a.K = g.K[i];
+      a.dY = (const HT*)g.dY[i]; a.X = (const HT*)g.X[i]; a.ldy = g.ldy[i]; a.ldx = g.ldx[i]; a.N = g.N[i]; a.K = g.K[i];
       tl = t - g.tile0[i]; tiles_k = (g.K[i] + WT - 1) / WT;
       off = g.off[i]; boff = g.boff[i]; dW = g.dW[i]; db = g.db[i];
     }
@@ -273,7 +281,9 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g) {
   a.s1 = min(nsteps, a.s0 + g.steps_per_split);
   if (g.splits == 1) {
     a.out = dW; a.db_out = db; a.accumulate = g.accumulate;
+    a.alpha = g.out_scale ? *g.out_scale : 1.f;
   } else {
+    a.alpha = 1.f;
     a.out = g.slab + (long long)zsplit * g.off[g.n] + off;
     a.db_out = g.db_slab + (long long)zsplit * g.boff[g.n] + boff;
     a.accumulate = 0;
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g) {
 __global__ void wgrad_group_reduce_kernel(const WgGroup g) {
   const long long nq = g.off[g.n] >> 2;           // every N*K is a multiple of 4 (checked by the launcher)
   const int nb = g.boff[g.n];
+  const float alpha = g.out_scale ? *g.out_scale : 1.f;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq + nb; q += (long long)gridDim.x * blockDim.x) {
     if (q < nq) {
       const long long i = q << 2;
@@ -292,10 +303,15 @@ __global__ void wgrad_group_reduce_kernel(const WgGroup g) {
 #pragma unroll
       for (int it = 0; it < WG_MAX; ++it)
         if (it < g.n && i >= g.off[it]) dst = g.dW[it] + (i - g.off[it]);
-      float4 acc = g.accumulate ? *reinterpret_cast<const float4*>(dst) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int z = 0; z < g.splits; ++z) {
         const float4 v = *reinterpret_cast<const float4*>(g.slab + (long long)z * g.off[g.n] + i);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+      if (g.accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(dst);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
       }
       *reinterpret_cast<float4*>(dst) = acc;
     } else {
@@ -305,9 +321,9 @@ __global__ void wgrad_group_reduce_kernel(const WgGroup g) {
       for (int it = 0; it < WG_MAX; ++it)
         if (it < g.n && j >= g.boff[it]) dst = g.db[it] + (j - g.boff[it]);   // items without a bias have an empty range
       if (!dst) continue;
-      float acc = g.accumulate ? *dst : 0.f;
+      float acc = 0.f;
       for (int z = 0; z < g.splits; ++z) acc += g.db_slab[(long long)z * nb + j];
-      *dst = acc;
+      *dst = acc * alpha + (g.accumulate ? *dst : 0.f);
     }
   }
 }
@@ -315,33 +331,41 @@ __global__ void wgrad_group_reduce_kernel(const WgGroup g) {
 // dW[i] += sum_z slab[z*n + i] (float4) and db[j] += sum_z dbs[z*nb + j]: one launch for both
 // accumulate == 0: dW / db are WRITTEN (the caller's gradient buffer need not be zeroed nor read)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n, int nslab, float* __restrict__ dW,
-                                    const float* __restrict__ dbs, int nb, float* __restrict__ db, int accumulate) {
+                                    const float* __restrict__ dbs, int nb, float* __restrict__ db, int accumulate,
+                                    const float* __restrict__ out_scale) {
   const long long nq = n >> 2;
+  const float alpha = out_scale ? *out_scale : 1.f;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq + nb; q += (long long)gridDim.x * blockDim.x) {
     if (q < nq) {
       const long long i = q << 2;
-      float4 a = accumulate ? *reinterpret_cast<const float4*>(dW + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int z = 0; z < nslab; ++z) {
         const float4 v = *reinterpret_cast<const float4*>(slab + (long long)z * n + i);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
       }
+      a.x *= alpha; a.y *= alpha; a.z *= alpha; a.w *= alpha;
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(dW + i);
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
       *reinterpret_cast<float4*>(dW + i) = a;
     } else if (db) {
       const int j = (int)(q - nq);
-      float a = accumulate ? db[j] : 0.f;
+      float a = 0.f;
       for (int z = 0; z < nslab; ++z) a += dbs[(long long)z * nb + j];
-      db[j] = a;
+      db[j] = a * alpha + (accumulate ? db[j] : 0.f);
     }
   }
 }
 
 // out[i] += sum_z slab[z*stride + i]
 __global__ void slab_reduce2_kernel(const float* __restrict__ slab, long long n, long long stride, int nslab,
-                                    float* __restrict__ out, int accumulate) {
+                                    float* __restrict__ out, int accumulate, const float* __restrict__ out_scale) {
+  const float alpha = out_scale ? *out_scale : 1.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float a = accumulate ? out[i] : 0.f;
+    float a = 0.f;
     for (int z = 0; z < nslab; ++z) a += slab[(long long)z * stride + i];
-    out[i] = a;
+    out[i] = a * alpha + (accumulate ? out[i] : 0.f);
   }
 }
 
@@ -392,10 +416,12 @@ size_t tim_wgrad_group_ws(const TimWgradItem* it, int n, int M) {
   return align_up(sk * elems * 4, 256) + align_up(sk * bias * 4, 256);
 }
 
-int tim_wgrad_group_bf16(const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+int tim_wgrad_group_h16(int precision, const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes,
+                        const float* out_scale, hipStream_t s) {
+  if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
   if (!it || n < 1 || n > WG_MAX || M <= 0) return TIMHIP_EINVAL;
   WgGroup g;
-  g.n = n; g.M = M; g.accumulate = accumulate ? 1 : 0;
+  g.n = n; g.M = M; g.accumulate = accumulate ? 1 : 0; g.out_scale = out_scale;
   g.tile0[0] = 0; g.off[0] = 0; g.boff[0] = 0;
   double flops = 0.0;
   for (int i = 0; i < WG_MAX; ++i) {
@@ -408,7 +434,7 @@ int tim_wgrad_group_bf16(const TimWgradItem* it, int n, int M, int accumulate, v
     if (!t.dY || !t.X || !t.dW || t.Nout <= 0 || t.Kout <= 0) return TIMHIP_EINVAL;
     if ((t.ldy % 8) || (t.ldx % 8) || (((uintptr_t)t.dY | (uintptr_t)t.X | (uintptr_t)t.dW) & 15)) return TIMHIP_EALIGN;
     if (((long long)t.Nout * t.Kout) & 3) return TIMHIP_EUNSUPPORTED;
-    g.dY[i] = (const bf16_t*)t.dY; g.X[i] = (const bf16_t*)t.X; g.dW[i] = t.dW; g.db[i] = t.db;
+    g.dY[i] = t.dY; g.X[i] = t.X; g.dW[i] = t.dW; g.db[i] = t.db;
     g.ldy[i] = t.ldy; g.ldx[i] = t.ldx; g.N[i] = t.Nout; g.K[i] = t.Kout;
     g.tile0[i + 1] = g.tile0[i] + ((t.Nout + WT - 1) / WT) * ((t.Kout + WT - 1) / WT);
     g.off[i + 1] = g.off[i] + (long long)t.Nout * t.Kout;
@@ -428,7 +454,7 @@ int tim_wgrad_group_bf16(const TimWgradItem* it, int n, int M, int accumulate, v
   }
   TimGemmScope timing(flops, s);   // kernel (+ reduce)
   const size_t shmem = 2 * 2 * WM * WT * 2;
-  hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)(g.tile0[n] * sk_eff)), dim3(256), shmem, s, g);
+  DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_group_kernel<HT>, dim3((unsigned)(g.tile0[n] * sk_eff)), dim3(256), shmem, s, g));
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   if (sk_eff > 1) {
     long long blocks = ((g.off[n] >> 2) + g.boff[n] + 255) / 256;
@@ -445,8 +471,9 @@ size_t tim_wgrad_tn_ws(int Nout, int Kout, int M) {
   return align_up((size_t)sk * Nout * Kout * 4, 256) + align_up((size_t)sk * Nout * 4, 256);
 }
 
-int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW, float* db,
-                      void* ws, size_t ws_bytes, hipStream_t s, int accumulate) {
+int tim_wgrad_tn_h16(int precision, const void* dY, int ldy, int Nout, const void* X, int ldx, int Kout, int M, float* dW,
+                     float* db, void* ws, size_t ws_bytes, hipStream_t s, int accumulate, const float* out_scale) {
+  if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
   if (ws_bytes < tim_wgrad_tn_ws(Nout, Kout, M)) return TIMHIP_EWORKSPACE;
   if ((ldy % 8) || (ldx % 8) || (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)ws) & 15)) return TIMHIP_EALIGN;
   const int sk = tim_wgrad_splits(Nout, Kout, M);
@@ -459,21 +486,21 @@ int tim_wgrad_tn_bf16(const void* dY, int ldy, int Nout, const void* X, int ldx,
   const int sk_eff = (nsteps + per - 1) / per;  // no empty splits
   dim3 grid(((Nout + WT - 1) / WT) * ((Kout + WT - 1) / WT) * sk_eff, 1, 1);
   const size_t shmem = 2 * 2 * WM * WT * 2;
-  hipLaunchKernelGGL(wgrad_tn_bf16_kernel, grid, dim3(256), shmem, s, (const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, M,
-                     Nout, Kout, per, slab, (long long)Nout * Kout, db ? dbs : nullptr);
+  DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_tn_kernel<HT>, grid, dim3(256), shmem, s, (const HT*)dY, ldy, (const HT*)X, ldx,
+                                             M, Nout, Kout, per, slab, (long long)Nout * Kout, db ? dbs : nullptr));
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   const long long n = (long long)Nout * Kout;
   if ((n & 3) == 0) {
     long long blocks = (n / 4 + Nout + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, n, sk_eff, dW, dbs, Nout, db, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slab, n, sk_eff, dW, dbs, Nout, db, accumulate, out_scale);
     return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
   }
-  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(256), dim3(256), 0, s, slab, n, n, sk_eff, dW, accumulate);
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(256), dim3(256), 0, s, slab, n, n, sk_eff, dW, accumulate, out_scale);
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   if (db) {
     hipLaunchKernelGGL(slab_reduce2_kernel, dim3((Nout + 255) / 256), dim3(256), 0, s, dbs, (long long)Nout,
-                       (long long)Nout, sk_eff, db, accumulate);
+                       (long long)Nout, sk_eff, db, accumulate, out_scale);
     if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   }
   return TIMHIP_OK;

@@ -58,7 +58,16 @@ class Runtime:
             raise ValueError("precision must be one of %s" % list(L.PRECISIONS))
         self.precision_name = precision
         self.prec = L.PRECISIONS[precision]
-        self.op_dtype = torch.bfloat16 if precision == "bf16" else torch.float32  # bf16x3 stores fp32 and splits on the fly
+        # operand storage: bf16 / fp16 for the 16-bit MFMA modes, fp32 otherwise (bf16x3 splits on the fly)
+        self.op_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision, torch.float32)
+        self.h16 = self.prec in L.H16
+        # fp16: 11-bit operands bring the 6-layer logits within 1e-3 of the fp32 reference only if the two small sites that
+        # dominate the error budget - the time MLP (its LayerNorm amplifies) and the classification heads (they write the
+        # logits) - keep more bits (oracle site analysis): those run on the split-operand kernels.
+        self.hi = Runtime("bf16x3") if precision == "fp16" else None
+        # fp16 backward: gradient operands are stored times a power of two chosen per backward pass from the incoming
+        # cotangents (timhip_grad_scale): S * max|cotangent| ~ grad_scale_target
+        self.grad_scale_target = 64.0
         self._wcache = {}
         self._wparams = {}  # id(param) -> weakref: every weight this runtime has cast
         self.seed = 0x5EED
@@ -155,35 +164,52 @@ class Runtime:
             return (self.seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         return (self.seed * 0x9E3779B97F4A7C15 + self.step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
+    def grad_scale(self, cotangents, dev):
+        """fp16 only: device tensor {S, 1/S, 0, 0} for one backward pass (None in the other modes), S chosen on the device
+        from the largest |cotangent| - no host synchronisation."""
+        if self.prec != L.PREC_F16:
+            return None
+        gs = torch.zeros(4, dtype=torch.float32, device=dev)
+        cots = [c for c in cotangents if c is not None and c.numel() > 0]
+        if not cots:
+            gs[:2] = 1.0
+            return gs
+        for i0 in range(0, len(cots), 8):   # (more than 8 cotangent tensors: the last group decides - never the case for TIM)
+            grp = cots[i0:i0 + 8]
+            call("timhip_grad_scale", _parr(grp), (C.c_longlong * len(grp))(*[c.numel() for c in grp]), len(grp),
+                 float(self.grad_scale_target), ptr(gs), _stream())
+        return gs
+
     # ---- thin op wrappers ------------------------------------------------------------------------
     def gemm(self, epi, A, B, M, N, K, out0, ld0, out1=None, ld1=0, bias=None, res=None, ldres=0, aux=None,
-             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0, ln=None):
-        """ln = (stats[M,2], gamma[N], beta[N]): EPI_DROP_RES_F32 takes LayerNorm(res) as its residual (TimEpi.ln_*)"""
+             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0, ln=None, acc_scale=None):
+        """ln = (stats[M,2], gamma[N], beta[N]): EPI_DROP_RES_F32 takes LayerNorm(res) as its residual (TimEpi.ln_*);
+        acc_scale: device pointer (int) of a scalar multiplied into the accumulators, or None"""
         if M == 0 or N == 0:
             return
         st_, g_, b_ = ln if ln is not None else (None, None, None)
         e = L.TimEpi(ptr(out0), ptr(out1), ptr(bias), ptr(res), ptr(aux), ld0, ld1, ldres, ldaux,
-                     float(p_drop), site, seed, ptr(mask), ldmask, 0, ptr(st_), ptr(g_), ptr(b_))
+                     float(p_drop), site, seed, ptr(mask), ldmask, 0, ptr(st_), ptr(g_), ptr(b_), acc_scale)
         call("timhip_gemm_nt", self.prec, epi, ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K,
              C.byref(e), splitk, _stream())
 
-    def wgrad(self, dY, Nout, X, Kout, M, dW, db):
-        """dW[Nout,Kout] += dY[:M,:Nout]^T X[:M,:Kout]; db += colsum(dY)"""
+    def wgrad(self, dY, Nout, X, Kout, M, dW, db, out_scale=None):
+        """dW[Nout,Kout] += dY[:M,:Nout]^T X[:M,:Kout]; db += colsum(dY)   (out_scale: device pointer of a factor on both)"""
         if M == 0:
             return
         nbytes = L.load().timhip_wgrad_workspace_bytes(self.prec, Nout, Kout, M)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dY.device)
         call("timhip_wgrad", self.prec, ptr(dY), dY.stride(0), Nout, ptr(X), X.stride(0), Kout, M, ptr(dW),
-             ptr(db), ptr(ws), nbytes, _stream())
+             ptr(db), ptr(ws), nbytes, out_scale, _stream())
 
-    def gemm_many(self, epi, items):
+    def gemm_many(self, epi, items, acc_scale=None):
         """items: [dict(A, B, M, N, K, out0, ld0, bias=None, res=None, ldres=0)] - independent small problems with the same
-        epilogue; in bf16 up to six go out as one grouped launch (timhip_gemm_nt_group), otherwise one launch each"""
+        epilogue; with 16-bit operands up to six go out as one grouped launch (timhip_gemm_nt_group), otherwise one launch each"""
         items = [it for it in items if it["M"] > 0 and it["N"] > 0]
-        if self.prec != L.PREC_BF16 or len(items) < 2 or os.environ.get("TIM_AMD_NO_GEMM_GROUP", "0") == "1":  # (A/B switch)
+        if not self.h16 or len(items) < 2 or os.environ.get("TIM_AMD_NO_GEMM_GROUP", "0") == "1":  # (A/B switch)
             for it in items:
                 self.gemm(epi, it["A"], it["B"], it["M"], it["N"], it["K"], it["out0"], it["ld0"], bias=it.get("bias"),
-                          res=it.get("res"), ldres=it.get("ldres", 0))
+                          res=it.get("res"), ldres=it.get("ldres", 0), acc_scale=acc_scale)
             return
         for i0 in range(0, len(items), 6):
             grp = items[i0:i0 + 6]
@@ -193,15 +219,15 @@ class Runtime:
                 a.lda, a.ldb = it["A"].stride(0), it["B"].stride(0)
                 a.M, a.N, a.K = it["M"], it["N"], it["K"]
                 a.e = L.TimEpi(ptr(it["out0"]), None, ptr(it.get("bias")), ptr(it.get("res")), None, it["ld0"], 0,
-                               it.get("ldres", 0), 0, 0.0, 0, 0, None, 0, 0, None, None, None)
+                               it.get("ldres", 0), 0, 0.0, 0, 0, None, 0, 0, None, None, None, acc_scale)
             call("timhip_gemm_nt_group", self.prec, epi, C.cast(arr, C.c_void_p), len(grp), _stream())
 
-    def wgrad_many(self, items):
-        """items: [(dY, Nout, X, Kout, M, dW, db), ...] - accumulate every weight gradient; in bf16 the items that share M go
-        out as one grouped launch (front end, heads: many small GEMMs that each would need their own split-K + reduce)"""
-        if self.prec != L.PREC_BF16:
+    def wgrad_many(self, items, out_scale=None):
+        """items: [(dY, Nout, X, Kout, M, dW, db), ...] - accumulate every weight gradient; with 16-bit operands the items that
+        share M go out as one grouped launch (front end, heads: many small GEMMs that each would need their own split-K + reduce)"""
+        if not self.h16:
             for dY, Nout, X, Kout, M, dW, db in items:
-                self.wgrad(dY, Nout, X, Kout, M, dW, db)
+                self.wgrad(dY, Nout, X, Kout, M, dW, db, out_scale)
             return
         by_m = {}
         for it in items:
@@ -209,14 +235,14 @@ class Runtime:
             if M == 0:
                 continue
             if (Nout * Kout) % 4:
-                self.wgrad(dY, Nout, X, Kout, M, dW, db)
+                self.wgrad(dY, Nout, X, Kout, M, dW, db, out_scale)
             else:
                 by_m.setdefault(M, []).append((dY, Nout, X, Kout, dW, db))
         for M, grp in by_m.items():
             for i in range(0, len(grp), 8):
-                self.wgrad_group(grp[i:i + 8], M, accumulate=True)
+                self.wgrad_group(grp[i:i + 8], M, accumulate=True, out_scale=out_scale)
 
-    def wgrad_group(self, items, M, accumulate=True):
+    def wgrad_group(self, items, M, accumulate=True, out_scale=None):
         """items: [(dY, Nout, X, Kout, dW, db|None), ...] sharing M - the weight gradients of several Linear layers as one
         launch (bf16; timhip_wgrad_group)"""
         arr = (L.TimWgradItem * len(items))(*[L.TimWgradItem(ptr(dY), ptr(X), ptr(dW), ptr(db), dY.stride(0), X.stride(0),
@@ -224,16 +250,16 @@ class Runtime:
         pa = C.cast(arr, C.c_void_p)
         nbytes = L.load().timhip_wgrad_group_workspace_bytes(self.prec, pa, len(items), M)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=items[0][0].device)
-        call("timhip_wgrad_group", self.prec, pa, len(items), M, 1 if accumulate else 0, ptr(ws), nbytes, _stream())
+        call("timhip_wgrad_group", self.prec, pa, len(items), M, 1 if accumulate else 0, ptr(ws), nbytes, out_scale, _stream())
 
     def ln_fwd(self, y, rows, cols, act, w, b, xf=None, ldx=0, xt=None, ldt=0, stats=None):
         call("timhip_layernorm_fwd", self.prec, ptr(y), rows, cols, y.stride(0), act, ptr(w), ptr(b), ptr(xf), ldx,
              ptr(xt), ldt, ptr(stats), _stream())
 
-    def ln_bwd(self, dx, y, stats, rows, cols, act, w, dyf=None, dyt=None, dgamma=None, dbeta=None):
+    def ln_bwd(self, dx, y, stats, rows, cols, act, w, dyf=None, dyt=None, dgamma=None, dbeta=None, t_scale=None):
         call("timhip_layernorm_bwd", self.prec, ptr(dx), dx.stride(0), ptr(y), y.stride(0), ptr(stats), rows, cols,
              act, ptr(w), ptr(dyf), 0 if dyf is None else dyf.stride(0), ptr(dyt),
-             0 if dyt is None else dyt.stride(0), 0.0, 0, 0, ptr(dgamma), ptr(dbeta), _stream())
+             0 if dyt is None else dyt.stride(0), 0.0, 0, 0, ptr(dgamma), ptr(dbeta), t_scale, _stream())
 
 
 def _iarr(vals):
@@ -265,6 +291,8 @@ class TimeMlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, times, w0, b0, w2, b2, w4, b4, lnw, lnb):
         _require_gpu(times, "time_mlp")
+        if rt.hi is not None:
+            rt = rt.hi   # fp16 model: this site runs on the split-operand kernels (see Runtime.__init__)
         dev = times.device
         d = w0.shape[0]
         t2 = _f32c(times).reshape(-1, 2)
@@ -293,6 +321,8 @@ class TimeMlpFn(torch.autograd.Function):
         R, d = u3.shape
         ldd = _ru(d)
         g = _f32c(d_te).reshape(R, d)
+        gs = rt.grad_scale([g], dev)
+        gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
         # the eight (accumulated-into) gradient tensors as views of ONE zero-filled buffer
         shapes = [(d, 2), (d,), (d, d), (d,), (d, d), (d,), (d,), (d,)]
         sizes = [(int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
@@ -303,15 +333,15 @@ class TimeMlpFn(torch.autograd.Function):
             off += n
         dw0, db0, dw2, db2, dw4, db4, dlnw, dlnb = views
         du3 = rt.out_op(R, d, dev)
-        rt.ln_bwd(g, u3, stats, R, d, 1, _f32c(lnw), dyt=du3, dgamma=dlnw, dbeta=dlnb)
+        rt.ln_bwd(g, u3, stats, R, d, 1, _f32c(lnw), dyt=du3, dgamma=dlnw, dbeta=dlnb, t_scale=gs_in)
         du2 = rt.out_op(R, d, dev)
         rt.gemm(L.EPI_DRELU_T, du3, rt.weight(w4, True), R, d, d, du2, ldd, aux=h2, ldaux=ldd)
-        rt.wgrad_many([(du3, d, h2, d, R, dw4, db4), (du2, d, h1, d, R, dw2, db2)])
+        rt.wgrad_many([(du3, d, h2, d, R, dw4, db4), (du2, d, h1, d, R, dw2, db2)], out_scale=gs_out)
         du1 = rt.out_op(R, d, dev)
         rt.gemm(L.EPI_DRELU_T, du2, rt.weight(w2, True), R, d, d, du1, ldd, aux=h1, ldaux=ldd)
         d_times = torch.empty((R, 2), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         call("timhip_time_l1_bwd", rt.prec, ptr(t2), R, d, ptr(_f32c(w0)), ptr(du1), ldd, ptr(dw0), ptr(db0),
-             ptr(d_times), _stream())
+             ptr(d_times), gs_out, _stream())
         if d_times is not None:
             d_times = d_times.view(ctx.shape)
         return None, d_times, dw0, db0, dw2, db2, dw4, db4, dlnw, dlnb
@@ -419,6 +449,16 @@ class EncoderPlan:
 OUT_SLOTS = ("verb", "noun", "action", "audio", "feats", "reg_visual", "reg_audio")
 
 
+def _gather_head_rows(rt, x, B, S, E, ranges, st):
+    """ranges: [(s0, n, rows[B*n, E])]: rows = x[b, s0 + i, :] in rt's operand dtype (x: [B*S, E] of that dtype)"""
+    if 2 <= len(ranges) <= 6:
+        call("timhip_gather_ranges", rt.prec, ptr(x), B, S, E, len(ranges), _iarr([r[0] for r in ranges]),
+             _iarr([r[1] for r in ranges]), _parr([r[2] for r in ranges]), st)
+    else:
+        for s0, n, rows in ranges:
+            call("timhip_gather_rows", rt.prec, ptr(x), B, S, E, s0, n, ptr(rows), st)
+
+
 class EncoderFn(torch.autograd.Function):
     """forward(ctx, model, nv, na, visual, audio, te, *params) -> 7 outputs (OUT_SLOTS; None if absent).
     `params` is `model._encoder_param_list()` so that autograd tracks every parameter."""
@@ -458,7 +498,7 @@ class EncoderFn(torch.autograd.Function):
             R = B * nf
             xT = torch.empty((R, _ru(Cin)), dtype=rt.op_dtype, device=dev)
             site = L.SITE_FEAT_V if name == "visual" else L.SITE_FEAT_A
-            call("timhip_cast_rows", rt.prec, ptr(x2), R, Cin, Cin, ptr(xT), xT.shape[1], p_feat, seed, site, st)
+            call("timhip_cast_rows", rt.prec, ptr(x2), R, Cin, Cin, ptr(xT), xT.shape[1], p_feat, seed, site, None, st)
             w = P[fe + name + "_embedder.1.weight"]
             u = torch.empty((R, d), dtype=torch.float32, device=dev)
             emb_gemms.append(dict(A=xT, B=rt.weight(w), M=R, N=d, K=Cin, out0=u, ld0=d,
@@ -489,7 +529,7 @@ class EncoderFn(torch.autograd.Function):
              ptr(te_c), T, ptr(mod), p_seq, seed, L.SITE_SEQ, ptr(xs_f[0]), ptr(xs_t[0]), st)
 
         # ---- L post-norm encoder layers (transformers.py:44-45,92-111)
-        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, 0)
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, 0, None)
         saved_bytes = L.load().timhip_layer_saved_bytes(C.byref(desc))
         ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
         ws = model._workspace(ws_bytes, dev)
@@ -510,30 +550,28 @@ class EncoderFn(torch.autograd.Function):
                      ptr(layer_saved[l - 1]), ptr(xs_t[l]), ptr(xs_f[l + 1]), ptr(xs_t[l + 1]), ptr(sv), st)
             layer_saved.append(sv)
 
-        # ---- heads (head.py:17-38)
+        # ---- heads (head.py:17-38).  fp16 model: the logits are produced by the split-operand kernels from the fp32 rows of
+        # the last layer (hrt = rt.hi); the backward gathers the fp16 rows it needs itself
         xL_t = xs_t[Lyr]
+        hrt = rt.hi if rt.hi is not None else rt
+        xL_h = xs_f[Lyr] if rt.hi is not None else xL_t
         outs = {}
         head_saved = []
         head_gemms, head_ranges = [], []
         for slot, pname, s0, n in plan.heads:
             w = P["cls_head." + pname + ".weight"]
             Cn = w.shape[0]
-            rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
+            rows = torch.empty((B * n, E), dtype=hrt.op_dtype, device=dev)
             logits = torch.empty((B * n, Cn), dtype=torch.float32, device=dev)
             if n > 0:
                 head_ranges.append((s0, n, rows))
-                head_gemms.append(dict(A=rows, B=rt.weight(w), M=B * n, N=Cn, K=E, out0=logits, ld0=Cn,
+                head_gemms.append(dict(A=rows, B=hrt.weight(w), M=B * n, N=Cn, K=E, out0=logits, ld0=Cn,
                                        bias=_f32c(P["cls_head." + pname + ".bias"])))
             outs[slot] = logits
-            head_saved.append((slot, pname, s0, n, rows))
+            head_saved.append((slot, pname, s0, n, rows if rt.hi is None else None))
         # the heads' row gathers and GEMMs are independent and tiny: one launch of each kind for all of them
-        if 2 <= len(head_ranges) <= 6:
-            call("timhip_gather_ranges", rt.prec, ptr(xL_t), B, S, E, len(head_ranges), _iarr([r[0] for r in head_ranges]),
-                 _iarr([r[1] for r in head_ranges]), _parr([r[2] for r in head_ranges]), st)
-        else:
-            for s0, n, rows in head_ranges:
-                call("timhip_gather_rows", rt.prec, ptr(xL_t), B, S, E, s0, n, ptr(rows), st)
-        rt.gemm_many(L.EPI_STORE_F32, head_gemms)
+        _gather_head_rows(hrt, xL_h, B, S, E, head_ranges, st)
+        hrt.gemm_many(L.EPI_STORE_F32, head_gemms)
         del head_gemms, head_ranges
         reg_saved = []
         for slot, pname, s0, n in plan.reg:
@@ -588,7 +626,7 @@ class EncoderFn(torch.autograd.Function):
 
         # gradient buckets: one flat fp32 buffer per bucket, parameters are views into it
         # bf16: the layers' Linear gradients are written, not accumulated -> their buckets are not zero-filled (nor read)
-        overwrite = rt.prec == L.PREC_BF16
+        overwrite = rt.h16
         grads = model._alloc_grad_buckets(names, params, dev, layer_overwrite=overwrite)
         G = grads.views
 
@@ -596,11 +634,26 @@ class EncoderFn(torch.autograd.Function):
         if g["feats"] is not None:
             dx.view(B, S, E)[:, :F] += g["feats"]  # tiny add of an incoming cotangent (plumbing)
         xL_t = ctx.xs_t[Lyr]
+        # fp16: scale of the gradient operands for this pass, from the cotangents that enter it (device side, no sync).  The
+        # fp32 stream dx and every parameter gradient stay true-scale; only fp16 tensors carry the factor.
+        gs = rt.grad_scale([_f32c(v) for v in gouts if v is not None], dev)
+        gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
+        if rt.hi is not None:   # the forward fed the heads from the fp32 rows: gather their fp16 copies for the weight gradients
+            hranges, hs2 = [], []
+            for slot, pname, s0, n, _ in ctx.head_saved:
+                rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
+                if n > 0 and g[slot] is not None:
+                    hranges.append((s0, n, rows))
+                hs2.append((slot, pname, s0, n, rows))
+            _gather_head_rows(rt, xL_t, B, S, E, hranges, st)
+            head_saved = hs2
+        else:
+            head_saved = ctx.head_saved
 
         # ---- heads (their weight gradients are collected and launched grouped by row count)
         wg_items = []
         head_dgrads, head_scatter, head_casts = [], [], []
-        for slot, pname, s0, n, rows in ctx.head_saved:
+        for slot, pname, s0, n, rows in head_saved:
             go = g[slot]
             if go is None or n == 0:
                 continue
@@ -617,11 +670,11 @@ class EncoderFn(torch.autograd.Function):
         if 2 <= len(head_casts) <= 6:
             call("timhip_cast_rows_many", rt.prec, len(head_casts), _parr([c[0] for c in head_casts]),
                  _iarr([c[1] for c in head_casts]), _iarr([c[2] for c in head_casts]), _parr([c[3] for c in head_casts]),
-                 _iarr([c[3].shape[1] for c in head_casts]), st)
+                 _iarr([c[3].shape[1] for c in head_casts]), gs_in, st)
         else:
             for go, r_, c_, gT in head_casts:
-                call("timhip_cast_rows", rt.prec, ptr(go), r_, c_, c_, ptr(gT), gT.shape[1], 0.0, 0, 0, st)
-        rt.gemm_many(L.EPI_ADD_F32, head_dgrads)
+                call("timhip_cast_rows", rt.prec, ptr(go), r_, c_, c_, ptr(gT), gT.shape[1], 0.0, 0, 0, gs_in, st)
+        rt.gemm_many(L.EPI_ADD_F32, head_dgrads, acc_scale=gs_out)
         spans = sorted((h[1], h[1] + h[2]) for h in head_scatter)
         disjoint = all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))   # detection: several heads read one row
         if 2 <= len(head_scatter) <= 6 and disjoint:
@@ -640,7 +693,7 @@ class EncoderFn(torch.autograd.Function):
             # sigmoid backward on the [B*n, 2] outputs (2 columns: not worth a kernel of its own)
             gz = _f32c(go) * y * (1.0 - y)
             gzT = torch.empty((B * n, 64), dtype=rt.op_dtype, device=dev)
-            call("timhip_cast_rows", rt.prec, ptr(gz), B * n, 2, 2, ptr(gzT), 64, 0.0, 0, 0, st)
+            call("timhip_cast_rows", rt.prec, ptr(gz), B * n, 2, 2, ptr(gzT), 64, 0.0, 0, 0, gs_in, st)
             wg_items.append((gzT, 2, h2, hid, B * n, G[pre + "4.weight"], G[pre + "4.bias"]))
             dh2 = torch.zeros_like(h2)
             rt.gemm(L.EPI_DRELU_T, gzT, rt.weight(P[pre + "4.weight"], True), B * n, hid, 2, dh2, dh2.shape[1],
@@ -651,9 +704,9 @@ class EncoderFn(torch.autograd.Function):
                     aux=h1, ldaux=h1.shape[1])
             wg_items.append((dh1, hid, rows, E, B * n, G[pre + "0.weight"], G[pre + "0.bias"]))
             d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
-            rt.gemm(L.EPI_ADD_F32, dh1, rt.weight(P[pre + "0.weight"], True), B * n, E, hid, d_rows, E)
+            rt.gemm(L.EPI_ADD_F32, dh1, rt.weight(P[pre + "0.weight"], True), B * n, E, hid, d_rows, E, acc_scale=gs_out)
             call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
-        rt.wgrad_many(wg_items)
+        rt.wgrad_many(wg_items, out_scale=gs_out)
         del wg_items
         grads.done("heads")
 
@@ -661,7 +714,8 @@ class EncoderFn(torch.autograd.Function):
         # weight-gradient GEMMs on a side stream (they overlap the data chain of the next layer);
         # each layer's bucket is handed to the hook as soon as its weight gradients are enqueued.
         desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0,
-                         (L.DESC_WGRAD_OVERWRITE if overwrite else 0) | (L.DESC_WGRAD_SEPARATE if rt.separate_wgrad else 0))
+                         (L.DESC_WGRAD_OVERWRITE if overwrite else 0) | (L.DESC_WGRAD_SEPARATE if rt.separate_wgrad else 0),
+                         gs_in)
         lib = L.load()
         dx2 = torch.empty_like(dx)
         stack = model._stack_prefix
@@ -752,15 +806,15 @@ class EncoderFn(torch.autograd.Function):
             w = P[fe + name + "_embedder.1.weight"]
             duT = rt.out_op(R, d, dev)
             rt.ln_bwd(d_e[slot], u, stats, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), dyt=duT,
-                      dgamma=G[fe + name + "_embedder.3.weight"], dbeta=G[fe + name + "_embedder.3.bias"])
+                      dgamma=G[fe + name + "_embedder.3.weight"], dbeta=G[fe + name + "_embedder.3.bias"], t_scale=gs_in)
             emb_items.append((duT, d, xT, Cin, R, G[fe + name + "_embedder.1.weight"], G[fe + name + "_embedder.1.bias"]))
             if need_in[name]:
                 gx = torch.empty((R, Cin), dtype=torch.float32, device=dev)
-                rt.gemm(L.EPI_ADD_F32, duT, rt.weight(w, True), R, Cin, d, gx, Cin)
+                rt.gemm(L.EPI_ADD_F32, duT, rt.weight(w, True), R, Cin, d, gx, Cin, acc_scale=gs_out)
                 dxin = torch.empty((R, Cin), dtype=torch.float32, device=dev)
                 call("timhip_dropout_rows_bwd", ptr(gx), R, Cin, Cin, ptr(dxin), Cin, p_feat, seed, site, st)
                 d_inputs[name] = dxin.view(B, nf, Cin)
-        rt.wgrad_many(emb_items)
+        rt.wgrad_many(emb_items, out_scale=gs_out)
         del emb_items
         grads.done("front")
         if overlap:

@@ -118,7 +118,7 @@ def _mlp_bwd(rt, gy, xT, h1, h2, w0, w2, w4, need_dx):
     dw0, db0, dw2, db2, dw4, db4 = z(d, K0), z(d), z(d, d), z(d), z(1, d), z(1)
     g = _f32c(gy).reshape(R, 1)
     gT = torch.empty((R, 64), dtype=rt.op_dtype, device=dev)
-    call("timhip_cast_rows", rt.prec, ptr(g), R, 1, 1, ptr(gT), 64, 0.0, 0, 0, st)
+    call("timhip_cast_rows", rt.prec, ptr(g), R, 1, 1, ptr(gT), 64, 0.0, 0, 0, None, st)
     dh2 = torch.zeros_like(h2)
     rt.gemm(L.EPI_DRELU_T, gT, rt.weight(w4, True), R, d, 1, dh2, dh2.shape[1], aux=h2, ldaux=h2.shape[1])
     dh1 = torch.zeros_like(h1)
@@ -143,7 +143,7 @@ class DrlocMlpFn(torch.autograd.Function):
         xT = torch.empty((R, _ru(K0)), dtype=rt.op_dtype, device=x.device)
         if _ru(K0) != K0:
             xT.zero_()
-        call("timhip_cast_rows", rt.prec, ptr(x2), R, K0, K0, ptr(xT), xT.shape[1], 0.0, 0, 0, _stream())
+        call("timhip_cast_rows", rt.prec, ptr(x2), R, K0, K0, ptr(xT), xT.shape[1], 0.0, 0, 0, None, _stream())
         h1, h2, y = _mlp_fwd(rt, xT, R, w0, b0, w2, b2, w4, b4)
         ctx.rt, ctx.xshape = rt, tuple(x.shape)
         ctx.save_for_backward(xT, h1, h2, w0, w2, w4)
