@@ -366,6 +366,22 @@ int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, con
 int timhip_cast_rows_many(int precision, int count, const float* const* src, const int* rows, const int* cols,
                           void* const* dst, const int* ld, const float* scale, void* stream);
 
+/* ---------------------------------------------------------------- detection query labelling */
+/* TIM.label_queries of the detection model (detection/time_interval_machine/models/tim.py:214-270, with get_query_ious
+ * :186-212): every query [b, q] is matched to the ground-truth segment of window b with the largest 1-D IoU (first maximum,
+ * as torch.argmax; all intervals of a window are first shifted by |min(0, earliest segment start)|).  queries [B,Nq,2] and
+ * segs [B,Ng,2] fp32, labels [B,Ng,NL] int64.  Writes targets [B*Nq,2] (the matched - shifted - segment, +inf for queries whose
+ * best IoU is < iou_threshold), ious [B*Nq] and qlabels [B*Nq,NL] (-1 for those negatives).  fp32 results are the
+ * reference's bit for bit. */
+int timhip_label_queries(const float* queries, const float* segs, const int64_t* labels, int B, int Nq, int Ng, int NL,
+                         float iou_threshold, float* targets, float* ious, int64_t* qlabels, void* stream);
+/* The label-smoothed one-hot classification targets of TIM.assign_positive_labels (tim.py:157-184) for label column `col`
+ * of qlabels [rows, ld]: out[r, c] = (c == label) ? on : base for c < n (a label of -1 leaves the row at `base`).  The caller
+ * passes on = fp32(fp32(smoothing) + base), base = fp32((1 - smoothing) / (n + 1)), the two values the reference's expression
+ * takes.  out [rows, n] fp32, 16-byte aligned. */
+int timhip_smooth_one_hot(const int64_t* qlabels, int ld, int col, int64_t rows, int n, float on, float base, float* out,
+                          void* stream);
+
 /* ---------------------------------------------------------------- loss tail of the training step */
 /* Label-smoothed cross entropy under mixup, as recognition/scripts/train.py:46-49,218-316 applies it through
  * utils/mixup.py:24-39:  loss = lam * mean_{r: ta[r] != -1} CE(logits[r], ta[r]) + (1-lam) * mean_{r: tb[r] != -1}

@@ -279,6 +279,57 @@ def generate_queries(query_size):
     return torch.cat(qs, 0).unsqueeze(0)
 
 
+# ----------------------------------------------------------------------------
+# detection query labelling (det tim.py:157-270).  Pinned by tests/golden/labels_*.npz, generated from the reference's own
+# TIM.label_queries by tests/golden/make_golden_r2.py.
+# ----------------------------------------------------------------------------
+def query_ious(queries, segs):
+    """det tim.py:186-212.  queries [B,Nq,2], segs [B,Ng,2] (fp32) -> (ious [B,Nq,Ng], shifted segs [B,Ng,2]).
+    Every interval of a window is shifted by |min(0, earliest ground-truth start)| first (:196-203); the reference does that
+    in place on its expanded copies, so the segments it later hands back as regression targets are the SHIFTED ones."""
+    off = torch.abs(torch.clamp(segs[:, :, 0].min(dim=-1)[0], max=0.0))[:, None]        # [B,1]
+    q_s, q_e = queries[:, :, 0] + off, queries[:, :, 1] + off                             # [B,Nq]
+    g_s, g_e = segs[:, :, 0] + off, segs[:, :, 1] + off                                   # [B,Ng]
+    i_s = torch.maximum(q_s[:, :, None], g_s[:, None, :])
+    i_e = torch.minimum(q_e[:, :, None], g_e[:, None, :])
+    inter = torch.clamp(i_e - i_s, min=0.0)
+    unions = (g_e - g_s)[:, None, :] + (q_e - q_s)[:, :, None] - inter
+    return inter / unions, torch.stack([g_s, g_e], -1)
+
+
+def smooth_one_hot(idx, n, ls):
+    """(F.one_hot(idx, n+1) * ls + (1-ls)/(n+1))[:, :-1] as det tim.py:170-183 evaluates it: the int64 one-hot times a Python
+    float is an fp32 tensor, the second Python float is rounded to fp32 before the add."""
+    on = torch.tensor(float(ls), dtype=torch.float32)
+    base = torch.tensor((1.0 - float(ls)) / (n + 1), dtype=torch.float32)
+    out = base.expand(idx.shape[0], n).clone()
+    rows = torch.nonzero(idx < n).flatten()
+    out[rows, idx[rows]] = on + base
+    return out
+
+
+def label_queries(queries, segs, gt_labels, iou_threshold, label_smoothing, num_classes):
+    """det tim.py:214-270.  queries [B,Nq,2] fp32; segs [B,Ng,2] fp32; gt_labels [B,Ng,NL] int64 (-1 = padding);
+    num_classes: NL class counts.  Returns (targets [B*Nq,2] - inf for negatives, [smoothed label matrix per label column],
+    ious [B*Nq]).  The first maximum wins ties (torch.argmax)."""
+    B, Nq = queries.shape[:2]
+    ious, shifted = query_ious(queries, segs)
+    idx = ious.argmax(-1)                                                   # [B,Nq]
+    best = torch.gather(ious, 2, idx[..., None]).squeeze(-1)
+    tg = torch.gather(shifted[:, None].expand(-1, Nq, -1, -1), 2, idx[..., None, None].expand(-1, -1, 1, 2)).squeeze(2).clone()
+    lab = torch.gather(gt_labels[:, None].expand(-1, Nq, -1, -1), 2,
+                       idx[..., None, None].expand(-1, -1, 1, gt_labels.shape[-1])).squeeze(2).clone()
+    neg = best < iou_threshold
+    tg[neg] = float("inf")
+    lab[neg] = -1
+    lab = lab.reshape(B * Nq, -1)
+    mats = []
+    for c, n in enumerate(num_classes):
+        col = torch.where(lab[:, c] == -1, torch.full_like(lab[:, c], n), lab[:, c])     # "no object" -> the dropped column n
+        mats.append(smooth_one_hot(col, n, label_smoothing))
+    return tg.reshape(B * Nq, 2), mats, best.reshape(-1)
+
+
 def to_torch(sd_np, dtype=torch.float32):
     return {k: torch.from_numpy(v).to(dtype) for k, v in sd_np.items()}
 

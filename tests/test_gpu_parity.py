@@ -418,3 +418,100 @@ def test_c4_detection_bf16_long_sequence():
             pred = maxerr(clsbf[2], cls32[2])
             assert maxerr(a, cls32[2]) <= max(2.0 * pred, 1e-3), (maxerr(a, cls32[2]), pred)
             assert maxerr(r, reg32[0]) <= 2e-2
+
+
+def test_c4_detection_backward_at_real_size():
+    """C4 (399 dense queries, S = 499, B = 2) forward AND backward: logits / regression outputs against the committed slices of
+    the fp32 reference, every parameter-gradient norm against the reference's (tests/golden/make_golden_r2.py).  The 399-query
+    attention backward runs 16 row blocks on 8 waves here, not the toy head width of the tiny fixtures."""
+    g = np.load(os.path.join(H.GOLDEN, "C4_det_grads_summary.npz"))
+    cfg = named_config("C4")
+    B = 2
+    sd, inp = H.synth_torch(cfg, B, 0, 0, seed=4, dtype=torch.float32)
+    for prec, tol_out, tol_g in (("fp32", 2e-5, 5e-4), ("fp16", 1e-3, 2e-2)):
+        m = build(cfg, prec, sd)
+        vis = inp["visual"].to(DEV).requires_grad_(True)
+        (cls, reg, feats), _, _, _, _ = m([vis, inp["audio"].to(DEV)], "encoder", inp["times"].to(DEV), None, label_queries=False)
+        outs = H.named_outputs(cls, feats, reg)
+        assert maxerr(outs["action"][:, :8].detach().cpu(), torch.from_numpy(g["out/action/slice"])) <= tol_out, prec
+        assert maxerr(outs["reg_visual"].detach().cpu(), torch.from_numpy(g["out/reg_visual/slice"])) <= tol_out, prec
+        R = H.cotangents(cfg, B, 0, 0, {k: v.detach() for k, v in outs.items()}, seed=4, dtype=torch.float32)
+        sum((outs[k] * R[k].to(DEV)).sum() for k in outs).backward()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for k in g.files:
+            if k.startswith("grad/") and k.endswith("/stats"):
+                name = k[5:-6]
+                n = dict(m.named_parameters())[name].grad.double().norm().item()
+                worst = max(worst, abs(n - g[k][3]) / max(1.0, g[k][3]))
+                assert abs(n - g[k][3]) <= tol_g * max(1.0, g[k][3]), (prec, name, n, g[k][3])
+        assert abs(vis.grad.double().norm().item() - g["gin/visual/stats"][3]) <= tol_g * max(1.0, g["gin/visual/stats"][3])
+        print("C4 backward %s: worst gradient-norm deviation %.3g" % (prec, worst))
+
+
+@pytest.mark.parametrize("prec,tol_out,tol_g", [("fp32", 2e-5, 5e-4), ("fp16", 1e-3, 2e-2)])
+def test_c2b_baseline_shaped_window(prec, tol_out, tol_g):
+    """C2b = the window BASELINE.json words (75 + 75 feature tokens, S = 205: 7 row blocks, 5 key blocks per head): logit
+    slices and gradient norms of the imported reference (tests/golden/C2b_rec_summary.npz)."""
+    g = np.load(os.path.join(H.GOLDEN, "C2b_rec_summary.npz"))
+    cfg = named_config("C2b")
+    B, nv, na = 2, 15, 10
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
+    m = build(cfg, prec, sd)
+    shapes = {k: tuple(g["out/%s/slice" % k].shape[:1]) + (n,) for k, n in (("verb", 97), ("noun", 300), ("action", 3806), ("audio", 44))}
+    shapes["feats"] = (B, cfg.F, cfg.E)
+    R = {k: torch.from_numpy(v).float() for k, v in
+         __import__("tim_amd.synth", fromlist=["x"]).make_cotangents(cfg, B, nv, na, shapes, seed=2, dtype=np.float64).items()}
+    res = run_model(m, inp, nv, na, True, R)
+    for k in ("verb", "noun", "action", "audio"):
+        assert maxerr(res["outs"][k][:, :8], torch.from_numpy(g["out/%s/slice" % k])) <= tol_out, (prec, k)
+        assert abs(res["outs"][k].double().abs().max().item() - g["out/%s/stats" % k][2]) <= 10 * tol_out, (prec, k)
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith("/stats"):
+            name = k[5:-6]
+            n = res["grads"][name].double().norm().item()
+            assert abs(n - g[k][3]) <= tol_g * max(1.0, g[k][3]), (prec, name, n, g[k][3])
+
+
+_B64 = {}
+
+
+def _c2a_b64_oracle():
+    """fp32 CPU oracle, forward and backward, of the batch bench.py times (64 windows): computed once per test session"""
+    if not _B64:
+        cfg = named_config("C2a")
+        B, nv, na = 64, 15, 10
+        sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
+        with torch.no_grad():
+            o32 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+        R = H.cotangents(cfg, B, nv, na, o32, seed=2, dtype=torch.float32)
+        _, _, g32, _ = oracle_run(cfg, sd, inp, nv, na, R, torch.float32)
+        _B64.update(cfg=cfg, sd=sd, inp=inp, o32=o32, R=R, gnorm={k: v.double().norm().item() for k, v in g32.items()})
+    return _B64
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+def test_c2a_production_batch_end_to_end(prec):
+    """The launch shapes bench.py times - B = 64 windows, M = 9920 rows: the 160 x 128 GEMM tile, the un-split 512-tile grouped
+    weight gradient, timhip_layer_fwd_chained, grouped head launches - compared as a WHOLE MODEL with the fp32 CPU oracle:
+    every logit, every parameter-gradient norm."""
+    c = _c2a_b64_oracle()
+    cfg, nv, na = c["cfg"], 15, 10
+    m = build(cfg, prec, c["sd"])
+    res = run_model(m, c["inp"], nv, na, True, c["R"])
+    tol_out = {"fp32": TOL_FP32, "fp16": TOL_BF16, "bf16": 3e-2}[prec]
+    tol_g = {"fp32": 5e-4, "fp16": 1e-2, "bf16": 8e-2}[prec]
+    worst = 0.0
+    for k, v in res["outs"].items():
+        if k == "feats":
+            continue
+        e = maxerr(v, c["o32"][k])
+        worst = max(worst, e)
+        assert e <= tol_out * (max(1.0, amax(c["o32"][k])) if prec == "fp32" else 1.0), (prec, k, e)
+    wg = 0.0
+    for k, n32 in c["gnorm"].items():
+        n = res["grads"][k].double().norm().item()
+        wg = max(wg, abs(n - n32) / max(1.0, n32))
+        assert abs(n - n32) <= tol_g * max(1.0, n32), (prec, k, n, n32)
+    print("C2a B=64 %s: worst |dlogit| %.3g over %d logits, worst gradient-norm deviation %.3g"
+          % (prec, worst, sum(v.numel() for k, v in res["outs"].items() if k != "feats"), wg))

@@ -1,14 +1,15 @@
 """Detection variant of TIM (detection/time_interval_machine/models/tim.py:17-430).
 
-The encoder, heads and regression heads run on the HIP path; the multi-scale query
-pyramid (tim.py:144-155) and the IoU labelling of queries (tim.py:157-270) are
-no-grad fp32/int64 bookkeeping on a few hundred intervals and stay host-side torch
-ops (adjacent, not a kernel target).
+The encoder, heads and regression heads run on the HIP path, and so does the IoU labelling
+of the queries (tim.py:157-270 -> csrc/labels.hip: fp32 interval arithmetic bit-identical to
+the reference's).  The multi-scale query pyramid itself
+(tim.py:144-155) is a constant built once on the host.
 """
+import numpy as np
 import torch
-import torch.nn.functional as F
 
-from .functional import EncoderFn, OUT_SLOTS
+from ._lib import call, ptr
+from .functional import EncoderFn, OUT_SLOTS, _require_gpu, _stream
 from .tim import TIM as _TIMBase
 
 
@@ -50,62 +51,59 @@ class TIM(_TIMBase):
             query_size *= 2
         return torch.concat(queries, dim=0).unsqueeze(0)
 
-    # ---- tim.py:157-184
+    # ---- tim.py:157-270: IoU matching and label-smoothed targets, on the device (csrc/labels.hip)
     def assign_positive_labels(self, modality, query_labels):
-        ls = self.label_smoothing
+        """query_labels [R, NL] int64 with -1 for negatives -> the reference's structure: [verb, noun, action] smoothed target
+        matrices for "visual" (the first two empty when the model has no verb / noun heads), one matrix for "audio"."""
+        _require_gpu(query_labels, "assign_positive_labels")
+        ql = query_labels.contiguous()
+        R, NL = ql.shape
+        ls = float(self.label_smoothing)
 
-        def smooth(lbl, n):
-            return ((F.one_hot(lbl, n + 1) * ls) + ((1 - ls) / (n + 1)))[:, :-1]
+        def smooth(col, n):
+            out = torch.empty((R, n), dtype=torch.float32, device=ql.device)
+            if R == 0:
+                return out
+            base = np.float32((1.0 - ls) / (n + 1))            # the Python float the reference adds, rounded to fp32 by the add
+            on = np.float32(np.float32(ls) + base)             # one_hot * smoothing is an fp32 tensor
+            call("timhip_smooth_one_hot", ptr(ql), NL, col, R, n, float(on), float(base), ptr(out), _stream())
+            return out
 
         if modality == "visual":
-            verb_labels = torch.empty(size=(0,)).to(device=query_labels.device)
-            noun_labels = torch.empty(size=(0,)).to(device=query_labels.device)
+            verb_labels = torch.empty(size=(0,)).to(device=ql.device)
+            noun_labels = torch.empty(size=(0,)).to(device=ql.device)
             num_actions = self.num_class[0]
             if self.include_verb_noun:
                 num_verbs, num_nouns, num_actions = self.num_class[0]
-                query_labels[:, 0].masked_fill_(query_labels[:, 0] == -1, num_verbs)
-                query_labels[:, 1].masked_fill_(query_labels[:, 1] == -1, num_nouns)
-                verb_labels = smooth(query_labels[:, 0], num_verbs)
-                noun_labels = smooth(query_labels[:, 1], num_nouns)
-            query_labels[:, 2].masked_fill_(query_labels[:, 2] == -1, num_actions)
-            return [verb_labels, noun_labels, smooth(query_labels[:, 2], num_actions)]
-        num_actions = self.num_class[1]
-        query_labels.masked_fill_(query_labels == -1, num_actions)
-        return smooth(query_labels[:, -1], num_actions)
+                verb_labels, noun_labels = smooth(0, num_verbs), smooth(1, num_nouns)
+            return [verb_labels, noun_labels, smooth(2, num_actions)]
+        return smooth(NL - 1, self.num_class[1])
 
-    # ---- tim.py:186-212
-    def get_query_ious(self, queries, target_segs):
-        q_s, q_e = queries[:, :, :, 0], queries[:, :, :, 1]
-        g_s, g_e = target_segs[:, :, :, 0], target_segs[:, :, :, 1]
-        neg = torch.abs(torch.clamp(g_s.min(dim=-1)[0], max=0.0))[:, :, None]
-        q_s, q_e, g_s, g_e = q_s + neg, q_e + neg, g_s + neg, g_e + neg
-        inter = torch.clamp(torch.minimum(q_e, g_e) - torch.maximum(q_s, g_s), min=0.0)
-        unions = (g_e - g_s) + (q_e - q_s) - inter
-        return inter / unions
-
-    # ---- tim.py:214-270
     def label_queries(self, queries, target, modality, iou_threshold):
+        """queries [B, Nq, 2]; returns (query_targets [B*Nq, 2], query_labels, query_ious [B*Nq]) as tim.py:214-270 does:
+        the matched ground-truth segment (+inf for queries under the IoU threshold), the smoothed classification targets and
+        the IoU of the match."""
         if modality == "visual":
             target_segs = target['v_gt_segments']
             gt_labels = torch.stack([target['verb'], target['noun'], target['action']], dim=-1)
         else:
             target_segs = target['a_gt_segments']
             gt_labels = target['class_id'].unsqueeze(-1)
-        nq, ng = queries.shape[1], target_segs.shape[1]
-        q = queries[:, :, None].expand(-1, -1, ng, -1)
-        t = target_segs[:, None].expand(-1, nq, -1, -1)
-        lab = gt_labels[:, None].expand(-1, nq, -1, -1)
-        ious = self.get_query_ious(q, t)
-        idx = ious.argmax(-1)
-        ious = torch.gather(ious, 2, idx[..., None]).squeeze(-1)
-        query_targets = torch.gather(t, 2, idx[..., None, None].expand(-1, -1, 1, 2)).squeeze(2).clone()
-        query_labels = torch.gather(lab, 2, idx[..., None, None].expand(-1, -1, 1, lab.shape[-1])).squeeze(2).clone()
-        negatives = ious < iou_threshold
-        query_targets.masked_fill_(negatives[:, :, None], float("inf"))
-        query_labels.masked_fill_(negatives[:, :, None], -1)
-        query_targets = torch.flatten(query_targets, 0, 1)
-        query_labels = torch.flatten(query_labels, 0, 1)
-        return query_targets, self.assign_positive_labels(modality, query_labels), torch.flatten(ious)
+        _require_gpu(queries, "label_queries")
+        dev = queries.device
+        B, Nq = queries.shape[:2]
+        Ng, NL = target_segs.shape[1], gt_labels.shape[-1]
+        if Ng == 0:
+            raise ValueError("label_queries: the batch holds no (padded) ground-truth segment slots")
+        q = queries.detach().to(torch.float32).contiguous()
+        sg = target_segs.detach().to(device=dev, dtype=torch.float32).contiguous()
+        lab = gt_labels.detach().to(device=dev, dtype=torch.int64).contiguous()
+        query_targets = torch.empty((B * Nq, 2), dtype=torch.float32, device=dev)
+        query_ious = torch.empty((B * Nq,), dtype=torch.float32, device=dev)
+        query_labels = torch.empty((B * Nq, NL), dtype=torch.int64, device=dev)
+        call("timhip_label_queries", ptr(q), ptr(sg), ptr(lab), B, Nq, Ng, NL, float(np.float32(iou_threshold)),
+             ptr(query_targets), ptr(query_ious), ptr(query_labels), _stream())
+        return query_targets, self.assign_positive_labels(modality, query_labels), query_ious
 
     # ---- tim.py:272-400
     def _run(self, inputs, feature_times, target, train, label_queries):
