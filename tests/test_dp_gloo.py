@@ -29,20 +29,22 @@ def _worker(rank, world, port, q):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        torch.manual_seed(0)
-        from tim_amd.dp import DataParallel
+        torch.manual_seed(rank)          # ranks are seeded DIFFERENTLY: construction must broadcast rank 0's weights
+        from tim_amd.dp import DataParallel, allreduce_buckets_reference
         from tim_amd.tim import TIM, _GradBuckets
         cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
         m = TIM(cfg.num_class, visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2, num_feats=6)
-        dp = DataParallel(m)
-        assert dp.world == world and m.rt.bucket_hook is not None
+        before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+        dp = DataParallel(m, wire_dtype=torch.float32)
+        assert dp.world == world and dp.active and m.rt.bucket_hook is not None
         names = m._encoder_param_names
         params = m._encoder_param_list()
-        # every rank has the same parameters (same seed) ...
-        flat0 = torch.cat([p.detach().reshape(-1) for p in params])
+        # every rank now holds rank 0's parameters
+        flat0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
         ref = flat0.clone()
         dist.broadcast(ref, 0)
         assert torch.equal(ref, flat0)
+        assert rank == 0 or not torch.equal(before, flat0)
         # ... buckets: one per layer + front + heads, views alias the flat buffers
         gb = _GradBuckets(m.rt, names, params, torch.device("cpu"), m._bucket_of)
         assert set(gb.flat) == {"front", "heads", "layer0", "layer1"}
@@ -55,13 +57,34 @@ def _worker(rank, world, port, q):
             v = gb.views[n]
             assert v.shape == dict(zip(names, params))[n].shape
             assert torch.allclose(v, torch.full_like(v, (i + 1) * mean)), n
-        # the few parameters outside the encoder Function (time MLP, DRLoc MLP): one flat all-reduce
+        # the few parameters outside the encoder Function (time MLP, DRLoc MLP): one flat exchange
         for j, p in enumerate(dp._small):
             p.grad = torch.full_like(p, float(j + 1) * (rank + 1))
         dp._reduce_small()
         for j, p in enumerate(dp._small):
             assert torch.allclose(p.grad, torch.full_like(p, (j + 1) * mean))
         assert len(dp._small) == 8 + 6
+        # bf16 on the wire, fp32 accumulation: random gradients of an odd length against the exact fp32 mean
+        g = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(100003, generator=g) * 1e-3
+        exact = x.clone()
+        allreduce_buckets_reference([exact], world)
+        dp.wire_dtype = torch.bfloat16
+        dp._stage.clear()
+        got = x.clone()
+        dp._exchange(got)
+        # two roundings to bf16 (each rank's contribution, then the mean): 2^-8 relative to the larger of the two
+        assert (got - exact).abs().max().item() <= 2.0 ** -8 * x.abs().max().item() * 1.01
+        assert (got - exact).abs().mean().item() <= 2.0 ** -9 * x.abs().mean().item()
+        both = got.clone()
+        dist.broadcast(both, 0)
+        assert torch.equal(both, got)          # every rank ends with the SAME gradients (all-gather of the reduced shards)
+        assert dp.bytes_on_wire > 0
+        # no_sync(): gradients stay local
+        with dp.no_sync():
+            y = torch.full((64,), float(rank + 1))
+            dp._on_bucket("layer0", y)
+            assert torch.equal(y, torch.full((64,), float(rank + 1)))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

@@ -1,6 +1,7 @@
-"""Data-parallel wrapper on a real GPU: a 1-rank RCCL group, with the wrapper told world=2, drives every gradient
-bucket through the comm-stream all-reduce (identity on one rank) and the 1/world scaling; gradients must be exactly
-half of a plain run with the same dropout seed.  (The 2-rank arithmetic itself is covered on CPU/gloo.)"""
+"""Data-parallel wrapper on a real GPU: a 1-rank RCCL group with the exchange forced on drives every gradient bucket through
+the comm-stream narrow / all-to-all / fp32-sum / all-gather / widen sequence (copies on one rank) while the backward runs;
+the gradients must be the bf16 rounding of a plain run's with the same dropout seed, and the cost of the side-stream work to
+the data chain is printed.  (The 2-rank arithmetic itself is covered on CPU/gloo and by the two-process test below.)"""
 import os
 import subprocess
 import sys
@@ -16,6 +17,8 @@ def test_dp_bucket_allreduce_path_on_one_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_single_gpu_check.py")], env=env,
                          capture_output=True, text=True, timeout=600)
     assert "RESULT params 102 mismatches 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "INTERFERENCE" in out.stdout
+    print([ln for ln in out.stdout.splitlines() if ln.startswith("INTERFERENCE")][0])
 
 
 def test_two_ranks_sharing_one_gpu_average_their_gradients():

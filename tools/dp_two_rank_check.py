@@ -58,7 +58,8 @@ if rank == 0:
     g_full = run(m2, full, Rfull)
     for n, b in g_full.items():
         a = g_dp[n]
-        tol = 3e-3 * b.abs().max().item() + 1e-12   # bf16 GEMMs over B vs 2B rows: different split-K partitions / summation order
+        tol = (3e-3 + 2.0 ** -7) * b.abs().max().item() + 1e-12   # bf16 GEMMs over B vs 2B rows: different split-K partitions /
+        # summation order; plus the bf16 wire format of the exchange (each contribution and the mean rounded once)
         if (a - 0.5 * b).abs().max().item() > tol:
             bad += 1
             print("MISMATCH", n, (a - 0.5 * b).abs().max().item(), b.abs().max().item())
