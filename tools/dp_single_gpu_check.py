@@ -25,7 +25,9 @@ bad = 0
 for n, p in m2.named_parameters():
     if p.grad is None: continue
     a, b = g1[n], p.grad
-    if not torch.equal(a, b.bfloat16().float()):   # one rank: the mean is the value itself, rounded once to the wire dtype
+    # one rank: the mean is the value itself, rounded once to the wire dtype (half a bf16 ulp; the LayerNorm / token gradients
+    # are summed with atomics, so the two runs may differ in the last fp32 bits BEFORE that rounding: allow a whole ulp)
+    if not bool(((a - b).abs() <= 2.0 ** -8 * b.abs() + 1e-30).all()):
         bad += 1; print("MISMATCH", n, (a - b).abs().max().item(), b.abs().max().item())
 print("RESULT params", len(g1), "mismatches", bad)
 
