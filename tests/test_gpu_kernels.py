@@ -440,3 +440,59 @@ def test_fp16_scaled_gradient_operands():
     assert (dW.cpu().double() - ref_dW).abs().max().item() <= 1e-5 * ref_dW.abs().max().item()
     assert (db.cpu().double() - gq.sum(0)).abs().max().item() <= 1e-5 * gq.sum(0).abs().max().item()
     assert ref_dx.abs().max().item() > 0 and float(g.cpu().to(torch.float16).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("M,N,K", [(9920, 1024, 1024), (9920, 3072, 1024), (9920, 1024, 2048), (9925, 1000, 192), (3000, 2056, 64)])
+def test_gemm_pingpong_kernel(prec, M, N, K):
+    """gemm_pp.hip (one 8-wave block per CU, 160 x 256 tiles, three-stage LDS ring): every epilogue it carries, on the encoder
+    layer's shapes and on ragged edges (rows past M, columns past N, one / two / three contraction steps), against fp64"""
+    rt = Runtime(prec)
+    A, Ar = to_op(rt, rnd(M, K, seed=1))
+    B, Br = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3).to(DEV)
+    lin = (Ar.to(DEV).double() @ Br.to(DEV).double().t()).cpu()
+    ref = lin + bias.cpu().double()
+    t = tol(prec, ref) * 2
+    ld = _ru(N)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    rt.gemm(L.EPI_STORE_F32, A, B, M, N, K, out, N, bias=bias)
+    assert (out.cpu().double() - ref).abs().max().item() <= t
+    oT = torch.zeros((M, ld), dtype=rt.op_dtype, device=DEV)
+    rt.gemm(L.EPI_STORE_T, A, B, M, N, K, oT, ld, bias=bias)
+    assert (oT[:, N:] == 0).all()
+    assert (oT[:, :N].float().cpu().double() - ref).abs().max().item() <= t + HALF_ULP[prec] * float(ref.abs().max())
+    rt.gemm(L.EPI_RELU_T, A, B, M, N, K, oT, ld, bias=bias)
+    assert (oT[:, :N].float().cpu().double() - ref.clamp(min=0)).abs().max().item() <= t + HALF_ULP[prec] * float(ref.abs().max())
+    res = rnd(M, N, seed=4).to(DEV)
+    rt.gemm(L.EPI_ADD_F32, A, B, M, N, K, out, N, res=res, ldres=N)
+    assert (out.cpu().double() - (lin + res.cpu().double())).abs().max().item() <= t
+    sc = torch.tensor([0.25], device=DEV)
+    rt.gemm(L.EPI_ADD_F32, A, B, M, N, K, out, N, res=res, ldres=N, acc_scale=L.ptr(sc))
+    assert (out.cpu().double() - (0.25 * lin + res.cpu().double())).abs().max().item() <= t
+    if N % 4 == 0:
+        p, seed, site = 0.3, 1234567, 42
+        mask = torch.empty((M, N), dtype=torch.uint8, device=DEV)
+        L.call("timhip_dropout_mask", seed, site, p, M, N, L.ptr(mask), st())
+        rt.gemm(L.EPI_DROP_RES_F32, A, B, M, N, K, out, N, bias=bias, res=res, ldres=N, p_drop=p, seed=seed, site=site)
+        want = res.cpu().double() + ref * mask.cpu().double() / (1 - p)
+        assert (out.cpu().double() - want).abs().max().item() <= t * 2
+        aux = rnd(M, ld, seed=9).to(DEV).to(rt.op_dtype)
+        rt.gemm(L.EPI_MULAUX_T, A, B, M, N, K, oT, ld, aux=aux, ldaux=ld)
+        want = lin * aux[:, :N].float().cpu().double()
+        assert (oT[:, :N].float().cpu().double() - want).abs().max().item() <= t * 4 + HALF_ULP[prec] * float(want.abs().max())
+        # GELU + dropout with the keep-bits drawn ahead of time, two outputs (h = mask * gelu(u), g = mask * gelu'(u))
+        ldm = (N + 7) // 8
+        padded = torch.zeros((M, ldm * 8), dtype=torch.uint8, device=DEV)
+        padded[:, :N] = mask
+        bits = (padded.view(M, ldm, 8).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+        h = torch.zeros((M, ld), dtype=rt.op_dtype, device=DEV)
+        g2 = torch.zeros((M, ld), dtype=rt.op_dtype, device=DEV)
+        rt.gemm(L.EPI_GELU_DROP_G2, A, B, M, N, K, h, ld, out1=g2, ld1=ld, bias=bias, p_drop=p, seed=seed, site=site, mask=bits,
+                ldmask=ldm)
+        mk = mask.cpu().double() / (1 - p)
+        u = ref.clone().requires_grad_(True)
+        O._gelu(u).sum().backward()
+        assert (h[:, :N].float().cpu().double() - O._gelu(ref) * mk).abs().max().item() <= t * 4 + HALF_ULP[prec] * float(ref.abs().max()) * 2
+        assert (g2[:, :N].float().cpu().double() - u.grad * mk).abs().max().item() <= t * 4 + HALF_ULP[prec] * 4
+    torch.cuda.synchronize()

@@ -52,6 +52,16 @@ template <> __device__ __forceinline__ f32x16_t mfma16<f16_t>(vec8<f16_t> a, vec
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_{bf16,f16}: D[16x16] += A[16x32] B[32x16]; lane l holds A[l & 15][8 (l >> 4) .. +7], the same of B^T,
+// and D[4 (l >> 4) + r][l & 15], r = 0..3
+template <typename HT> __device__ __forceinline__ f32x4_t mfma16x16(vec8<HT> a, vec8<HT> b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t mfma16x16<bf16_t>(vec8<bf16_t> a, vec8<bf16_t> b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t mfma16x16<f16_t>(vec8<f16_t> a, vec8<f16_t> b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <>
@@ -315,6 +325,10 @@ struct TimGemmScope {
 int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
                 int K, const TimEpi& e, int splitk, hipStream_t s);
 int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, hipStream_t s);
+// gemm_pp.hip: the one-block-per-CU ping-pong kernel for the encoder-layer shapes (epi_dev: the caller's EpiDev)
+bool tim_gemm_pp_wins(int M, int N, int K, int splitk);
+int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
+                   hipStream_t s);
 int tim_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,
                   float* colsum, hipStream_t s);
 int tim_slab_reduce(const float* slab, long long n, int nslab, float* dW, hipStream_t s);

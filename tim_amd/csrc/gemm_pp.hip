@@ -1,0 +1,364 @@
+// NT GEMM  C[M,N] = A[M,K] B[N,K]^T  for the encoder-layer shapes: the one-workgroup-per-CU "ping-pong" kernel.
+//
+// Why a second kernel.  gemm.hip's 160 x 128 tile runs two 4-wave blocks per CU; its main loop is bound by the operand path
+// (71 FLOP per staged byte, 1.2 LDS fragment reads per MFMA - DESIGN.md section 5: 30-36 % MFMA busy).  This kernel is shaped
+// for the matrix pipes instead:
+//   * 160 x 256 output tile, ONE 8-wave block per CU (2 x 4 waves of 80 x 64): 98 FLOP per staged byte; M = 9920 = 62 x 160
+//     rows give 248 / 496 / 744 tiles for N = 1024 / 2048 / 3072 - one, two, three full rounds of the 256 CUs;
+//   * v_mfma_f32_16x16x32: an 80 x 64 wave tile is 5 x 4 MFMA tiles -> 9 fragment reads (ds_read_b128) feed 20 MFMAs per
+//     32-deep contraction step (0.45 reads per MFMA), accumulators 80 VGPRs;
+//   * the two waves that share a SIMD alternate roles ("ping-pong"): while one issues its 20 MFMAs the other reads its next
+//     fragments; the LDS-DMA pieces of the stage two contraction steps ahead are issued between a wave's own MFMAs, where
+//     issue slots are free.  The roles are kept apart by raw
+//     s_barriers - waves 4-7 run one barrier (half a phase) behind waves 0-3 - so the matrix pipe of every SIMD always has
+//     a wave in its MFMA phase and no wave has to interleave loads between its own MFMAs;
+//   * 3-stage LDS ring of 52 KiB stages (156 KiB), filled by global_load_lds (inline asm, counted vmcnt: a stage stays in
+//     flight across four barriers), XOR swizzle on the source address as in gemm.hip (conflict-free ds_read_b128).
+// Epilogues: gemm_epi.h (shared with gemm.hip), on 16-row blocks transposed through a wave-private LDS region.
+//
+// Hazards (phase p = 2 t + s: contraction step t, half s; G0 = waves 0-3, G1 = waves 4-7, G1 one barrier behind):
+//   RAW  stage t+1 is first read by G0 after the barrier that ends its second MFMA phase of step t; every wave has waited
+//        (vmcnt) for its own DMA pieces of stage t+1 in its second LOAD phase of step t, i.e. at least one barrier earlier.
+//   WAR  stage (t+2) % 3 = (t-1) % 3 is refilled from G0's first MFMA phase of step t on; the last fragment reads of step
+//        t-1 (G1's second LOAD phase) were waited for (lgkmcnt) BEFORE a barrier G0 has to pass to get there.
+#include <stdlib.h>
+
+#include "gemm_epi.h"
+
+namespace {
+
+constexpr int PP_BN = 256, PP_ROWB = 128, PP_NST = 3, PP_TNW = 4;
+
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// ---- epilogue: one wave's TMW x 4 accumulator tiles (16 x 16 each, D[n][m] orientation) ------------------------------------
+template <typename HT, int EPI, int TMW>
+__device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc)[PP_TNW][TMW], int mw0, int nw0, int M, int N,
+                                            float* ep, int lane) {
+  constexpr int EP_COLS = 64, EP_LD = EP_COLS + 4, CPR = EP_COLS / 4, OPR = EP_COLS / 8, RBS = 16;
+  constexpr int NITQ = RBS * CPR / 64, NITO = RBS * OPR / 64;     // 4 quads / 2 octs per lane per row block
+  const float asc = e.acc_scale ? *e.acc_scale : 1.f;
+  const int frow = lane & 15, fq = lane >> 4;
+
+  // dropout keep-bits drawn ahead of time (e.mask): this lane's bytes of every row block
+  uint32_t mbyte[TMW][NITO];
+  const bool use_mask = epi_uses_dropout(EPI) && epi_has_oct(EPI) && e.vec8 && e.mask && e.thr != 0u;
+  static_for<TMW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+#pragma unroll
+    for (int it = 0; it < NITO; ++it) {
+      const int idx = it * 64 + lane;
+      const int m = mw0 + j * RBS + idx / OPR, n = nw0 + (idx % OPR) * 8;
+      mbyte[j][it] = (use_mask && m < M && n + 7 < N) ? (uint32_t)e.mask[(size_t)m * e.ldmask + (n >> 3)] : 0u;
+    }
+  });
+  // operands the epilogue reads per chunk (fp32 residual, 16-bit aux) are fetched for ALL row blocks before the first store:
+  // a load placed after a store cannot be hoisted above it (possible aliasing) and would cost a memory latency per chunk
+  constexpr bool PRE_RES = (EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_ADD_F32);
+  constexpr bool PRE_AUX = (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_MULAUX_T);
+  float4 rbuf[TMW][PRE_RES ? NITQ : 1];
+  float2 sbuf[TMW][PRE_RES ? NITQ : 1];
+  vec8<HT> abuf[TMW][PRE_AUX ? NITO : 1];
+  const bool pre_res = PRE_RES && e.vec && e.res != nullptr;
+  const bool pre_ln = pre_res && EPI == TIMHIP_EPI_DROP_RES_F32 && e.ln_stats != nullptr;
+  const bool pre_aux = PRE_AUX && e.vec8;
+  static_for<TMW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (PRE_RES) {
+      if (pre_res) {
+#pragma unroll
+        for (int it = 0; it < NITQ; ++it) {
+          const int idx = it * 64 + lane;
+          const int m = mw0 + j * RBS + idx / CPR, n = nw0 + (idx % CPR) * 4;
+          rbuf[j][it] = (m < M && n + 3 < N) ? *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pre_ln) sbuf[j][it] = m < M ? *reinterpret_cast<const float2*>(e.ln_stats + 2 * (size_t)m) : make_float2(0.f, 1.f);
+        }
+      }
+    }
+    if constexpr (PRE_AUX) {
+      if (pre_aux) {
+#pragma unroll
+        for (int it = 0; it < NITO; ++it) {
+          const int idx = it * 64 + lane;
+          const int m = mw0 + j * RBS + idx / OPR, n = nw0 + (idx % OPR) * 8;
+          if (m < M && n + 7 < N) abuf[j][it] = *reinterpret_cast<const vec8<HT>*>((const HT*)e.aux + (size_t)m * e.ldaux + n);
+        }
+      }
+    }
+  });
+  // per-lane constants: the lane's output columns are the same in every chunk it handles
+  float4 bias8[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, bias4 = bias8[0];
+  bool pre_b8 = false, pre_b4 = false;
+  if (e.bias && e.vec) {
+    const int n8 = nw0 + (lane % OPR) * 8, n4 = nw0 + (lane % CPR) * 4;
+    if (epi_has_oct(EPI) && e.vec8 && n8 + 7 < N) {
+      bias8[0] = *reinterpret_cast<const float4*>(e.bias + n8);
+      bias8[1] = *reinterpret_cast<const float4*>(e.bias + n8 + 4);
+      pre_b8 = true;
+    }
+    if (n4 + 3 < N) { bias4 = *reinterpret_cast<const float4*>(e.bias + n4); pre_b4 = true; }
+  }
+  float4 lng = make_float4(1.f, 1.f, 1.f, 1.f), lnb = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool pre_gb = false;
+  if (pre_ln) {
+    const int n4 = nw0 + (lane % CPR) * 4;
+    if (n4 + 3 < N) {
+      lng = *reinterpret_cast<const float4*>(e.ln_w + n4);
+      lnb = *reinterpret_cast<const float4*>(e.ln_b + n4);
+      pre_gb = true;
+    }
+  }
+
+  static_for<TMW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    // lane (frow = m, fq): the 4 consecutive columns 16 i + 4 fq .. + 3 of row m, for the 4 column tiles i
+#pragma unroll
+    for (int i = 0; i < PP_TNW; ++i)
+      *reinterpret_cast<float4*>(ep + frow * EP_LD + i * 16 + 4 * fq) =
+          make_float4(acc[i][j][0] * asc, acc[i][j][1] * asc, acc[i][j][2] * asc, acc[i][j][3] * asc);
+    pp_wait_lds();   // wave-private region: no block barrier needed
+    if (epi_has_oct(EPI) && e.vec8) {
+#pragma unroll
+      for (int it = 0; it < NITO; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / OPR, ch = idx % OPR;
+        const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 8 + 4);
+        const int m = mw0 + j * RBS + row, n = nw0 + ch * 8;
+        if (m < M && n + 7 < N) {
+          epi_oct<EPI, HT>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j][PRE_AUX ? it : 0], pre_b8, bias8[0], bias8[1]);
+        } else if (m < M) {
+          if (n < N) epi_quad<EPI, HT>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
+          if (n + 4 < N) epi_quad<EPI, HT>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NITQ; ++it) {
+        const int idx = it * 64 + lane;
+        const int row = idx / CPR, ch = idx % CPR;
+        const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
+        const int m = mw0 + j * RBS + row, n = nw0 + ch * 4;
+        if (m < M && n < N)
+          epi_quad<EPI, HT>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j][PRE_RES ? it : 0], pre_b4 && n + 3 < N,
+                            bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j][PRE_RES ? it : 0], lng, lnb);
+      }
+    }
+    pp_wait_lds();   // reads done before the next row block overwrites the region
+  });
+}
+
+// ---- main loop of one wave group (G = 0: waves 0-3; G = 1: waves 4-7, one barrier behind) ---------------------------------
+// A stage is 20 + 32 = 52 LDS-DMA pieces of 1 KiB (8 rows x 128 B): the A tile's pieces first, then the B tile's, in LDS as
+// in this numbering.  G0 waves issue 7 of them per contraction step (4 during their first MFMA phase, 3 during the second),
+// G1 waves 6 (3 + 3): the issue slots between a wave's own MFMAs are free (the matrix pipe is busy for 16 cycles per MFMA),
+// while a DMA piece issued in a LOAD phase lengthens the phase the partner's MFMAs have to cover.
+template <int TMW, int G> struct PpShare {
+  static constexpr int CNT = G == 0 ? 7 : 6, P0 = G == 0 ? 4 : 3;   // pieces per step, of which in the first MFMA phase
+  static_assert(4 * 7 + 4 * 6 == 2 * TMW * 2 + 32, "the share table is written for the 160 x 256 tile");
+};
+
+template <typename HT, int TMW, int G, bool PROF = false>
+__device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* __restrict__ B, int nk, const char* lds, uint32_t lds0,
+                                            const uint32_t (&off)[7], int first_piece, int a_frag, int b_frag, int c0, int c1,
+                                            f32x4_t (&acc)[PP_TNW][TMW], long long* prof = nullptr) {
+  constexpr int BM = 32 * TMW, A_PIECES = BM / 8;
+  constexpr int A_BYTES = BM * PP_ROWB, B_BYTES = PP_BN * PP_ROWB, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int CNT = PpShare<TMW, G>::CNT, P0 = PpShare<TMW, G>::P0;
+
+  // this wave's i-th piece of stage `kt`, into ring slot `slot`
+  auto piece = [&](int kt, int slot, int i) {
+    const int p = first_piece + i;
+    const char* g = reinterpret_cast<const char*>(p < A_PIECES ? (const void*)A : (const void*)B) + (size_t)kt * PP_ROWB;
+    glds16_s(uniform_ptr(g), off[i], lds0 + slot * ST_BYTES + p * 1024);
+  };
+
+  // prologue: stages 0 and 1 in flight, stage 0 landed
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) piece(0, 0, i);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) piece(1, 1, i);
+    glds_wait<CNT>();
+  } else {
+    glds_wait<0>();
+  }
+  pp_barrier();
+  if constexpr (G == 1) pp_barrier();   // half a phase behind G0 from here on
+
+  vec8<HT> xa[TMW], wb[PP_TNW];
+  int slot = 0;
+  long long tp = 0, t_load = 0, t_bar_a = 0, t_mma = 0, t_bar_b = 0;   // PROF (tuning builds): shader cycles per phase part
+  if constexpr (PROF) tp = __builtin_readcyclecounter();
+  auto lap = [&](long long& acc_t) {
+    if constexpr (PROF) { const long long now = __builtin_readcyclecounter(); acc_t += now - tp; tp = now; }
+  };
+  // one contraction step; MORE: stage t + 2 exists and is issued during this step's MFMA phases (a compile-time flag: the
+  // last two steps run a copy of the loop body without the DMA pieces instead of branching around each of them)
+  auto step = [&](int t, auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
+    const char* base = lds + slot * ST_BYTES;
+    const int nslot = slot >= 1 ? slot - 1 : PP_NST - 1;   // (t + 2) % 3
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      // ---- LOAD phase: the fragments of (step t, half)
+      const int cc = half == 0 ? c0 : c1;
+#pragma unroll
+      for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + cc);
+#pragma unroll
+      for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + cc);
+      if (half == 1) {   // every piece of stage t + 1 issued by this wave has landed (the P0 pieces of t + 2 may stay in flight)
+        if constexpr (MORE) glds_wait<P0>(); else glds_wait<0>();
+      }
+      pp_wait_lds();
+      lap(t_load);
+      pp_barrier();
+      lap(t_bar_a);
+      // ---- MFMA phase, with this wave's DMA pieces for step t + 2 between the MFMAs (after every fifth one)
+#pragma unroll
+      for (int j = 0; j < TMW; ++j)
+#pragma unroll
+        for (int i = 0; i < PP_TNW; ++i) {
+          acc[i][j] = mfma16x16<HT>(wb[i], xa[j], acc[i][j]);
+          const int q = j * PP_TNW + i, k = q / 5;
+          if (MORE && q % 5 == 2 && k < (half == 0 ? P0 : CNT - P0)) {
+            __builtin_amdgcn_sched_barrier(0);
+            piece(t + 2, nslot, half == 0 ? k : P0 + k);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      lap(t_mma);
+      pp_barrier();
+      lap(t_bar_b);
+    }
+    slot = slot + 1 == PP_NST ? 0 : slot + 1;
+  };
+  int t = 0;
+  for (; t + 2 < nk; ++t) step(t, std::true_type{});
+  for (; t < nk; ++t) step(t, std::false_type{});
+  if constexpr (G == 0) pp_barrier();   // as many barriers as G1
+  if constexpr (PROF) { prof[0] = t_load; prof[1] = t_bar_a; prof[2] = t_mma; prof[3] = t_bar_b; }
+}
+
+template <typename HT, int EPI, int TMW, bool PROF = false>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                         int M, int N, int K, EpiDev e) {
+  constexpr int BM = 32 * TMW;
+  constexpr int A_BYTES = BM * PP_ROWB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [3][A tile BM x 128 B | B tile 256 x 128 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = (N + PP_BN - 1) / PP_BN, tiles_m = (M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * PP_BN;
+
+  // LDS-DMA source offsets of this wave's pieces (PpShare): a 1-KiB piece = 8 rows x 128 B, lane -> (row, 16-B chunk); the
+  // chunk index is swizzled on the SOURCE side so that the LDS image stays lane-linear
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  const int first_piece = wm == 0 ? 7 * wn : 28 + 6 * wn;
+  uint32_t off[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int p = first_piece + i;
+    const bool is_a = p < BM / 8;
+    const int row = (is_a ? p : p - BM / 8) * 8 + lrow;    // row of the A / B tile
+    const int c = (lchunk ^ kswz<64>(row)) * 8;
+    off[i] = is_a ? (uint32_t)(((size_t)min(m0 + row, M - 1) * lda + c) * 2) : (uint32_t)(((size_t)min(n0 + row, N - 1) * ldb + c) * 2);
+  }
+  // fragment reads: lane -> (row = lane & 15 of a 16-row tile, 16-B chunk 4 half + (lane >> 4)), swizzled like the stage
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+  const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
+  const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+
+  f32x4_t acc[PP_TNW][TMW];
+#pragma unroll
+  for (int i = 0; i < PP_TNW; ++i)
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / 64;
+  long long prof[4] = {0, 0, 0, 0}, t_begin = 0, w_begin = 0;
+  if constexpr (PROF) { t_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
+  if (wm == 0) pp_mainloop<HT, TMW, 0, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof);
+  else pp_mainloop<HT, TMW, 1, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof);
+  long long t_loop = 0;
+  if constexpr (PROF) t_loop = __builtin_readcyclecounter();
+
+  __syncthreads();   // every wave is done with the stage ring: it becomes the epilogue's transposition space
+  float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
+  pp_epilogue<HT, EPI, TMW>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
+  if constexpr (PROF) {   // tools/pp_phase.py: e.aux -> 16 counters, [0..7] wave 0 (G0), [8..15] wave 4 (G1), summed over blocks
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t_end = __builtin_readcyclecounter();
+    if (lane == 0 && (wave == 0 || wave == 4) && e.aux) {
+      unsigned long long* c = (unsigned long long*)e.aux + (wave == 4 ? 8 : 0);
+      for (int i = 0; i < 4; ++i) atomicAdd(c + i, (unsigned long long)prof[i]);
+      atomicAdd(c + 4, (unsigned long long)(t_loop - t_begin));
+      atomicAdd(c + 5, 1ull);
+      atomicAdd(c + 6, (unsigned long long)(wall_clock64() - w_begin));
+      atomicAdd(c + 7, (unsigned long long)(t_end - t_loop));
+    }
+  }
+}
+
+template <typename HT, int EPI>
+void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, hipStream_t s) {
+  constexpr int TMW = 5, BM = 32 * TMW;
+  const size_t shmem = (size_t)PP_NST * (BM + PP_BN) * PP_ROWB;
+#ifdef TIMHIP_TUNING   // per-phase cycle counters (tools/pp_phase.py)
+  if constexpr (EPI == TIMHIP_EPI_STORE_T) {
+    if (getenv("TIMHIP_PP_PROF")) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW, true>), dim3(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN)), dim3(512), shmem, s,
+                         (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+      return;
+    }
+  }
+#endif
+  static bool attr_set = false;   // idempotent; a benign race sets it twice at worst
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    attr_set = true;
+  }
+  const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+}
+
+}  // namespace
+
+// Is this problem one for the ping-pong kernel?  It needs enough 160 x 256 tiles to fill the 256 CUs about evenly: the
+// encoder-layer GEMMs of a production batch (M = B * S in the thousands, N a multiple of 256 from 1024 up).
+bool tim_gemm_pp_wins(int M, int N, int K, int splitk) {
+  if (splitk != 1 || N < 512 || M < 1280) return false;
+  const long long tiles = (long long)((M + 159) / 160) * ((N + PP_BN - 1) / PP_BN);
+  const long long rounds = (tiles + 255) / 256;
+  return tiles >= 192 && tiles * 100 >= rounds * 256 * 75;   // the last round at least three quarters full on average
+}
+
+int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
+                   hipStream_t s) {
+  const EpiDev& e = *reinterpret_cast<const EpiDev*>(epi_dev);
+  if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
+  switch (epi) {
+#define CASE(X) case X: DISPATCH_H16(precision, (launch_pp<HT, X>(A, lda, B, ldb, M, N, K, e, s))); break;
+    CASE(TIMHIP_EPI_STORE_T)
+    CASE(TIMHIP_EPI_RELU_T)
+    CASE(TIMHIP_EPI_STORE_F32)
+    CASE(TIMHIP_EPI_DROP_RES_F32)
+    CASE(TIMHIP_EPI_ADD_F32)
+    CASE(TIMHIP_EPI_GELU_DROP_G2)
+    CASE(TIMHIP_EPI_MULAUX_T)
+#undef CASE
+    default: return TIMHIP_EUNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
