@@ -341,6 +341,9 @@ size_t tim_wgrad_group_ws(const TimWgradItem* it, int n, int M);
 int tim_wgrad_group_splits(const TimWgradItem* it, int n, int M);
 int tim_wgrad_group_h16(int precision, const TimWgradItem* it, int n, int M, int accumulate, void* ws, size_t ws_bytes,
                         const float* out_scale, hipStream_t s);
+// wgrad_pp.hip: the grouped weight gradients as one-block-per-CU ping-pong blocks (no split of the contraction, no workspace)
+bool tim_wgrad_pp_wins(const TimWgradItem* it, int n, int M);
+int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int accumulate, const float* out_scale, hipStream_t s);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
 // mask_out != NULL: additionally writes the dropout keep-bits of a [rows, mask_cols] site (1 bit per element, row stride
 // mask_cols / 8 bytes, element index r * mask_cols + c as in the GEMM epilogues) - see drop_bits32

@@ -15,6 +15,10 @@
 //   * 3-stage LDS ring of 52 KiB stages (156 KiB), filled by global_load_lds (inline asm, counted vmcnt: a stage stays in
 //     flight across four barriers), XOR swizzle on the source address as in gemm.hip (conflict-free ds_read_b128).
 // Epilogues: gemm_epi.h (shared with gemm.hip), on 16-row blocks transposed through a wave-private LDS region.
+// Measured alternative (round 2, same box): the same tile without phase barriers - one barrier per contraction step, the two
+// waves of a SIMD interleaving through the hardware scheduler - is 5-12 % slower per launch on the layer shapes (in-proj
+// input gradient 67.6 vs 60.2 us), although an 8-wave s_barrier costs ~150 cycles (tools/wgpp_abl.py): for ds_read_b128
+// operands the explicit alternation pays; for the transposing-read weight-gradient kernel (wgrad_pp.hip) it does not.
 //
 // Hazards (phase p = 2 t + s: contraction step t, half s; G0 = waves 0-3, G1 = waves 4-7, G1 one barrier behind):
 //   RAW  stage t+1 is first read by G0 after the barrier that ends its second MFMA phase of step t; every wave has waited
