@@ -207,6 +207,15 @@ int timhip_transpose(int precision, const void* src, int rows, int cols, int lds
 int timhip_colsum(int precision, const void* src, int rows, int cols, int ld, float* out,
                   void* stream);
 
+/* Split operands: src_i [rows_i, cols_i] fp32 (row stride lds_i) -> dst_i [rows_i, ldd_i] (T = bf16 / fp16), ldd_i = 3 * block
+ * width, block width = cols_i rounded up to a multiple of 64 (zero padded).  With hi = T(x), lo = T(x - hi) the three column
+ * blocks are [hi | lo | hi] (mode 0: activations; relu != 0 applies max(x, 0) first) or [hi | hi | lo] (mode 1: weights), so a
+ * 16-bit NT GEMM of a mode-0 matrix with a mode-1 matrix over K = ldd computes x w^T to ~22 bits (x_hi w_hi + x_lo w_hi +
+ * x_hi w_lo).  count <= 6 matrices per launch; HOST arrays.  What TIMHIP_PREC_F16 models use for the time MLP and the
+ * classification heads (the two small sites that dominate the 16-bit error budget). */
+int timhip_split3_many(int precision, int count, const float* const* src, const int* rows, const int* cols, const int* lds,
+                       void* const* dst, const int* ldd, int mode, int relu, void* stream);
+
 /* Gradient scale of the fp16 mode.  fp16 has 5 exponent bits: gradient operands would underflow (the reference's GPU recipe
  * wraps its step in a GradScaler for that reason, recognition/scripts/train.py:82,355-363).  Here the scale is chosen per
  * backward pass ON THE DEVICE from the cotangents entering it: S = 2^floor(log2(target / max|cot|)), out[0] = S,

@@ -496,3 +496,37 @@ def test_gemm_pingpong_kernel(prec, M, N, K):
         assert (h[:, :N].float().cpu().double() - O._gelu(ref) * mk).abs().max().item() <= t * 4 + HALF_ULP[prec] * float(ref.abs().max()) * 2
         assert (g2[:, :N].float().cpu().double() - u.grad * mk).abs().max().item() <= t * 4 + HALF_ULP[prec] * 4
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("prec", H16)
+def test_split_operand_gemm(prec):
+    """timhip_split3_many: [hi | lo | hi] activations x [hi | hi | lo] weights through the plain 16-bit GEMM over K' = 3 K gives
+    the fp32 product to ~2^-20 (what the fp16 model's time MLP and heads rely on); weights of the size the model has
+    (|w| < 1/32: their lo parts are fp16 SUBNORMALS - the matrix pipe must honour them), ragged K"""
+    rt = Runtime(prec)
+    M, N, K = 960, 300, 1000
+    x = rnd(M, K, seed=1) * 1.5
+    w = (torch.rand(N, K, generator=torch.Generator().manual_seed(2)) * 2 - 1) / 32
+    xd, wd = x.to(DEV), w.to(DEV)
+    Kp = _ru(K)
+    A3 = torch.empty((M, 3 * Kp), dtype=rt.op_dtype, device=DEV)
+    B3 = torch.empty((N, 3 * Kp), dtype=rt.op_dtype, device=DEV)
+    rt.split3([(xd, M, K, K, A3)], mode=0)
+    rt.split3([(wd, N, K, K, B3)], mode=1)
+    out = torch.empty((M, N), device=DEV)
+    rt.gemm(L.EPI_STORE_F32, A3, B3, M, N, 3 * Kp, out, N)
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t()
+    plain = x.to(rt.op_dtype).double() @ w.to(rt.op_dtype).double().t()
+    err = (out.cpu().double() - ref).abs().max().item()
+    err_plain = (plain - ref).abs().max().item()
+    lim = {"fp16": 3e-6, "bf16": 2e-4}[prec] * float(ref.abs().max())
+    assert err <= lim, (err, err_plain)
+    assert err_plain > 20 * err
+    # relu variant and the layout of the blocks
+    rt.split3([(xd, M, K, K, A3)], mode=0, relu=True)
+    torch.cuda.synchronize()
+    hi = A3[:, :K].float().cpu()
+    assert torch.equal(hi, x.clamp(min=0).to(rt.op_dtype).float())
+    assert torch.equal(A3[:, 2 * Kp:2 * Kp + K].float().cpu(), hi)
+    assert (A3[:, K:Kp] == 0).all() and (A3[:, Kp + K:2 * Kp] == 0).all()

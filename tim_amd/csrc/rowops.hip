@@ -729,6 +729,36 @@ __global__ void cast_many_kernel(CastMany cm) {
 }
 
 // ---------------------------------------------------------------------------
+// Split operands (timhip_split3_many): an fp32 matrix as THREE 16-bit column blocks so that a plain 16-bit GEMM over the
+// tripled contraction length computes the product to ~22 bits:  x = hi + lo, hi = T(x), lo = T(x - hi);
+//   activations (mode 0): [hi | lo | hi]      weights (mode 1): [hi | hi | lo]
+//   sum over the three blocks = x_hi w_hi + x_lo w_hi + x_hi w_lo   (the lo * lo term is below 2^-22 relative).
+// The fp16 mode uses it at the two small sites that dominate its error budget (time MLP, classification heads).
+// ---------------------------------------------------------------------------
+struct Split3Many {
+  const float* src[RR_MAX]; void* dst[RR_MAX];
+  int rows[RR_MAX], cols[RR_MAX], lds[RR_MAX], ldd[RR_MAX];   // ldd = 3 * block width (block width = cols rounded up to 64)
+  int mode, relu;
+};
+template <typename T>
+__global__ void split3_kernel(Split3Many sm) {
+  const int i = blockIdx.z, r = blockIdx.y;
+  if (r >= sm.rows[i]) return;
+  const int cols = sm.cols[i], cp = sm.ldd[i] / 3;
+  const float* src = sm.src[i] + (size_t)r * sm.lds[i];
+  T* dst = (T*)sm.dst[i] + (size_t)r * sm.ldd[i];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cp; c += gridDim.x * blockDim.x) {
+    float v = c < cols ? src[c] : 0.f;
+    if (sm.relu) v = fmaxf(v, 0.f);
+    const T hi = OpT<T>::from_f(v);
+    const T lo = OpT<T>::from_f(v - OpT<T>::to_f(hi));
+    dst[c] = hi;
+    dst[cp + c] = sm.mode == 0 ? lo : hi;
+    dst[2 * cp + c] = sm.mode == 0 ? hi : lo;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Gradient scale of the fp16 mode (timhip_grad_scale): S = the power of two that brings the largest |cotangent| to
 // `target`; out = {S, 1/S, scratch, scratch}.  One launch: every block folds its maximum into out[2] (float bits compare
 // like unsigned integers for non-negative values), the last block to arrive (ticket in out[3]) writes S and 1/S and
@@ -1114,6 +1144,28 @@ int timhip_ln_partials_reduce(const float* partials, int nsets, int rows, int co
 int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, int n, float* dx, void* stream) {
   if (!d_rows || !dx || n <= 0 || E % 4) return TIMHIP_EINVAL;
   hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(B * n), dim3(256), 0, (hipStream_t)stream, d_rows, B, S, E, s0, n, dx);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_split3_many(int precision, int count, const float* const* src, const int* rows, const int* cols, const int* lds_,
+                       void* const* dst, const int* ldd, int mode, int relu, void* stream) {
+  if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
+  if (count < 1 || count > RR_MAX || !src || !rows || !cols || !lds_ || !dst || !ldd || (mode != 0 && mode != 1)) return TIMHIP_EINVAL;
+  Split3Many sm;
+  sm.mode = mode; sm.relu = relu ? 1 : 0;
+  int maxr = 0, maxc = 0;
+  for (int i = 0; i < RR_MAX; ++i) {
+    const bool on = i < count;
+    if (on && (!src[i] || !dst[i] || rows[i] <= 0 || cols[i] <= 0 || lds_[i] < cols[i] || ldd[i] % 192 || ldd[i] / 3 < cols[i]))
+      return TIMHIP_EINVAL;
+    sm.src[i] = on ? src[i] : nullptr; sm.dst[i] = on ? dst[i] : nullptr;
+    sm.rows[i] = on ? rows[i] : 0; sm.cols[i] = on ? cols[i] : 0; sm.lds[i] = on ? lds_[i] : 0; sm.ldd[i] = on ? ldd[i] : 0;
+    if (on && rows[i] > maxr) maxr = rows[i];
+    if (on && ldd[i] / 3 > maxc) maxc = ldd[i] / 3;
+  }
+  dim3 grid((maxc + 255) / 256 > 8 ? 8 : (maxc + 255) / 256, maxr, count);
+  DISPATCH_H16(precision, hipLaunchKernelGGL(split3_kernel<HT>, grid, dim3(256), 0, (hipStream_t)stream, sm));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

@@ -63,8 +63,10 @@ class Runtime:
         self.h16 = self.prec in L.H16
         # fp16: 11-bit operands bring the 6-layer logits within 1e-3 of the fp32 reference only if the two small sites that
         # dominate the error budget - the time MLP (its LayerNorm amplifies) and the classification heads (they write the
-        # logits) - keep more bits (oracle site analysis): those run on the split-operand kernels.
-        self.hi = Runtime("bf16x3") if precision == "fp16" else None
+        # logits) - keep more bits (oracle site analysis).  Those two run with SPLIT operands: every
+        # fp32 value as hi + lo fp16 column blocks, one fp16 GEMM over the tripled contraction length (timhip_split3_many).
+        self.split = precision == "fp16"
+        self._wsplit = {}
         # fp16 backward: gradient operands are stored times a power of two chosen per backward pass from the incoming
         # cotangents (timhip_grad_scale): S * max|cotangent| ~ grad_scale_target
         self.grad_scale_target = 64.0
@@ -149,10 +151,35 @@ class Runtime:
             call("timhip_cast_weights", self.prec, C.cast(arr, C.c_void_p), len(items), _stream())
             self._wcache.update(fresh)
 
+    def weight_split(self, p):
+        """[N, 3 ru(K)] split copy [hi | hi | lo] of an fp32 weight [N, K] (split-operand sites of the fp16 mode)"""
+        ent = self._wsplit.get(id(p))
+        ver = (p.data_ptr(), p._version)
+        if ent is None or ent[0] != ver or ent[1].device != p.device:
+            N, K = p.shape
+            src = _f32c(p)
+            buf = ent[1] if ent is not None and ent[1].device == p.device else \
+                torch.empty((N, 3 * _ru(K)), dtype=self.op_dtype, device=p.device)
+            self.split3([(src, N, K, K, buf)], mode=1)
+            ent = (ver, buf, src)
+            self._wsplit[id(p)] = ent
+        return ent[1]
+
+    def split3(self, items, mode, relu=False):
+        """items: [(src fp32 [rows, cols] with row stride lds, rows, cols, lds, dst [rows, 3 ru(cols)])]"""
+        items = [it for it in items if it[1] > 0]
+        for i0 in range(0, len(items), 6):
+            grp = items[i0:i0 + 6]
+            call("timhip_split3_many", self.prec, len(grp), _parr([g[0] for g in grp]), _iarr([g[1] for g in grp]),
+                 _iarr([g[2] for g in grp]), _iarr([g[3] for g in grp]), _parr([g[4] for g in grp]),
+                 _iarr([g[4].shape[1] for g in grp]), mode, 1 if relu else 0, _stream())
+
     def invalidate_weights(self):
         """force the operand copies to be rebuilt (bench: emulate the state after an optimizer step)"""
         for k, ent in list(self._wcache.items()):
             self._wcache[k] = (None, ent[1], ent[2])
+        for k, ent in list(self._wsplit.items()):
+            self._wsplit[k] = (None, ent[1], ent[2])
 
     def next_seed(self):
         self.step += 1
@@ -291,20 +318,30 @@ class TimeMlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rt, times, w0, b0, w2, b2, w4, b4, lnw, lnb):
         _require_gpu(times, "time_mlp")
-        if rt.hi is not None:
-            rt = rt.hi   # fp16 model: this site runs on the split-operand kernels (see Runtime.__init__)
         dev = times.device
         d = w0.shape[0]
         t2 = _f32c(times).reshape(-1, 2)
         R = t2.shape[0]
         ldd = _ru(d)
         w0c, b0c, b2c, b4c, lnwc, lnbc = [_f32c(t) for t in (w0, b0, b2, b4, lnw, lnb)]
-        h1 = rt.out_op(R, d, dev)
-        call("timhip_time_l1_fwd", rt.prec, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(h1), ldd, _stream())
-        h2 = rt.out_op(R, d, dev)
-        rt.gemm(L.EPI_RELU_T, h1, rt.weight(w2), R, d, d, h2, ldd, bias=b2c)
         u3 = torch.empty((R, d), dtype=torch.float32, device=dev)
-        rt.gemm(L.EPI_STORE_F32, h2, rt.weight(w4), R, d, d, u3, d, bias=b4c)
+        if rt.split:
+            # fp16 model: split operands (Runtime.__init__).  h1 / h2 are kept as [hi | lo | hi] blocks; their first block is
+            # the plain fp16 operand the backward reads (row stride 3 ldd)
+            f1 = torch.empty((R, d), dtype=torch.float32, device=dev)
+            call("timhip_time_l1_fwd", L.PREC_FP32, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(f1), d, _stream())
+            h1 = torch.empty((R, 3 * ldd), dtype=rt.op_dtype, device=dev)
+            rt.split3([(f1, R, d, d, h1)], mode=0)
+            rt.gemm(L.EPI_STORE_F32, h1, rt.weight_split(w2), R, d, 3 * ldd, f1, d, bias=b2c)
+            h2 = torch.empty((R, 3 * ldd), dtype=rt.op_dtype, device=dev)
+            rt.split3([(f1, R, d, d, h2)], mode=0, relu=True)
+            rt.gemm(L.EPI_STORE_F32, h2, rt.weight_split(w4), R, d, 3 * ldd, u3, d, bias=b4c)
+        else:
+            h1 = rt.out_op(R, d, dev)
+            call("timhip_time_l1_fwd", rt.prec, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(h1), ldd, _stream())
+            h2 = rt.out_op(R, d, dev)
+            rt.gemm(L.EPI_RELU_T, h1, rt.weight(w2), R, d, d, h2, ldd, bias=b2c)
+            rt.gemm(L.EPI_STORE_F32, h2, rt.weight(w4), R, d, d, u3, d, bias=b4c)
         te = torch.empty((R, d), dtype=torch.float32, device=dev)
         stats = torch.empty((R, 2), dtype=torch.float32, device=dev)
         rt.ln_fwd(u3, R, d, 1, lnwc, lnbc, xf=te, ldx=d, stats=stats)
@@ -335,10 +372,10 @@ class TimeMlpFn(torch.autograd.Function):
         du3 = rt.out_op(R, d, dev)
         rt.ln_bwd(g, u3, stats, R, d, 1, _f32c(lnw), dyt=du3, dgamma=dlnw, dbeta=dlnb, t_scale=gs_in)
         du2 = rt.out_op(R, d, dev)
-        rt.gemm(L.EPI_DRELU_T, du3, rt.weight(w4, True), R, d, d, du2, ldd, aux=h2, ldaux=ldd)
+        rt.gemm(L.EPI_DRELU_T, du3, rt.weight(w4, True), R, d, d, du2, ldd, aux=h2, ldaux=h2.stride(0))
         rt.wgrad_many([(du3, d, h2, d, R, dw4, db4), (du2, d, h1, d, R, dw2, db2)], out_scale=gs_out)
         du1 = rt.out_op(R, d, dev)
-        rt.gemm(L.EPI_DRELU_T, du2, rt.weight(w2, True), R, d, d, du1, ldd, aux=h1, ldaux=ldd)
+        rt.gemm(L.EPI_DRELU_T, du2, rt.weight(w2, True), R, d, d, du1, ldd, aux=h1, ldaux=h1.stride(0))
         d_times = torch.empty((R, 2), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         call("timhip_time_l1_bwd", rt.prec, ptr(t2), R, d, ptr(_f32c(w0)), ptr(du1), ldd, ptr(dw0), ptr(db0),
              ptr(d_times), gs_out, _stream())
@@ -449,14 +486,15 @@ class EncoderPlan:
 OUT_SLOTS = ("verb", "noun", "action", "audio", "feats", "reg_visual", "reg_audio")
 
 
-def _gather_head_rows(rt, x, B, S, E, ranges, st):
-    """ranges: [(s0, n, rows[B*n, E])]: rows = x[b, s0 + i, :] in rt's operand dtype (x: [B*S, E] of that dtype)"""
+def _gather_head_rows(rt, x, B, S, E, ranges, st, prec=None):
+    """ranges: [(s0, n, rows[B*n, E])]: rows = x[b, s0 + i, :] (x: [B*S, E]; element type of precision `prec`, default rt's)"""
+    prec = rt.prec if prec is None else prec
     if 2 <= len(ranges) <= 6:
-        call("timhip_gather_ranges", rt.prec, ptr(x), B, S, E, len(ranges), _iarr([r[0] for r in ranges]),
+        call("timhip_gather_ranges", prec, ptr(x), B, S, E, len(ranges), _iarr([r[0] for r in ranges]),
              _iarr([r[1] for r in ranges]), _parr([r[2] for r in ranges]), st)
     else:
         for s0, n, rows in ranges:
-            call("timhip_gather_rows", rt.prec, ptr(x), B, S, E, s0, n, ptr(rows), st)
+            call("timhip_gather_rows", prec, ptr(x), B, S, E, s0, n, ptr(rows), st)
 
 
 class EncoderFn(torch.autograd.Function):
@@ -550,29 +588,40 @@ class EncoderFn(torch.autograd.Function):
                      ptr(layer_saved[l - 1]), ptr(xs_t[l]), ptr(xs_f[l + 1]), ptr(xs_t[l + 1]), ptr(sv), st)
             layer_saved.append(sv)
 
-        # ---- heads (head.py:17-38).  fp16 model: the logits are produced by the split-operand kernels from the fp32 rows of
-        # the last layer (hrt = rt.hi); the backward gathers the fp16 rows it needs itself
+        # ---- heads (head.py:17-38).  fp16 model: the logits are produced with split operands from the fp32 rows of the last
+        # layer; the backward gathers the fp16 rows it needs itself
         xL_t = xs_t[Lyr]
-        hrt = rt.hi if rt.hi is not None else rt
-        xL_h = xs_f[Lyr] if rt.hi is not None else xL_t
         outs = {}
         head_saved = []
-        head_gemms, head_ranges = [], []
+        head_gemms, head_ranges, head_splits = [], [], []
         for slot, pname, s0, n in plan.heads:
             w = P["cls_head." + pname + ".weight"]
             Cn = w.shape[0]
-            rows = torch.empty((B * n, E), dtype=hrt.op_dtype, device=dev)
             logits = torch.empty((B * n, Cn), dtype=torch.float32, device=dev)
-            if n > 0:
-                head_ranges.append((s0, n, rows))
-                head_gemms.append(dict(A=rows, B=hrt.weight(w), M=B * n, N=Cn, K=E, out0=logits, ld0=Cn,
-                                       bias=_f32c(P["cls_head." + pname + ".bias"])))
+            bias = _f32c(P["cls_head." + pname + ".bias"])
+            if rt.split:   # fp32 rows of the last layer -> [hi | lo | hi] fp16 blocks, weights [hi | hi | lo]: K = 3 E
+                rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
+                rows3 = torch.empty((B * n, 3 * E), dtype=rt.op_dtype, device=dev)
+                if n > 0:
+                    head_ranges.append((s0, n, rows))
+                    head_splits.append((rows, B * n, E, E, rows3))
+                    head_gemms.append(dict(A=rows3, B=rt.weight_split(w), M=B * n, N=Cn, K=3 * E, out0=logits, ld0=Cn, bias=bias))
+                head_saved.append((slot, pname, s0, n, None))
+            else:
+                rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
+                if n > 0:
+                    head_ranges.append((s0, n, rows))
+                    head_gemms.append(dict(A=rows, B=rt.weight(w), M=B * n, N=Cn, K=E, out0=logits, ld0=Cn, bias=bias))
+                head_saved.append((slot, pname, s0, n, rows))
             outs[slot] = logits
-            head_saved.append((slot, pname, s0, n, rows if rt.hi is None else None))
         # the heads' row gathers and GEMMs are independent and tiny: one launch of each kind for all of them
-        _gather_head_rows(hrt, xL_h, B, S, E, head_ranges, st)
-        hrt.gemm_many(L.EPI_STORE_F32, head_gemms)
-        del head_gemms, head_ranges
+        if rt.split:
+            _gather_head_rows(rt, xs_f[Lyr], B, S, E, head_ranges, st, prec=L.PREC_FP32)
+            rt.split3(head_splits, mode=0)
+        else:
+            _gather_head_rows(rt, xL_t, B, S, E, head_ranges, st)
+        rt.gemm_many(L.EPI_STORE_F32, head_gemms)
+        del head_gemms, head_ranges, head_splits
         reg_saved = []
         for slot, pname, s0, n in plan.reg:
             pre = "reg_head." + pname + "."
@@ -638,7 +687,7 @@ class EncoderFn(torch.autograd.Function):
         # fp32 stream dx and every parameter gradient stay true-scale; only fp16 tensors carry the factor.
         gs = rt.grad_scale([_f32c(v) for v in gouts if v is not None], dev)
         gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
-        if rt.hi is not None:   # the forward fed the heads from the fp32 rows: gather their fp16 copies for the weight gradients
+        if rt.split:   # the forward fed the heads from the fp32 rows: gather their fp16 copies for the weight gradients
             hranges, hs2 = [], []
             for slot, pname, s0, n, _ in ctx.head_saved:
                 rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
