@@ -2,7 +2,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/traffic/f -o p --output-format csv -- python bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/traffic/w -o p --output-format csv -- python bench.py ...
-    python tools/pmc_traffic.py gpurun_out/traffic profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/traffic profiles/r02_pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so it is doubled
 (MI355X_MICROARCH.md, section HBM).  Infinity-Cache hits are included (fabric-side counters).
@@ -11,15 +11,11 @@ import collections, csv, glob, json, sys
 root, out = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: {"fetch_kib": 0.0, "write_kib": 0.0, "n_f": 0, "n_w": 0})
 def fam(name, row=None):
-    # the encoder layers' launches only: their NT GEMMs run the 160 x 128 tile, their grouped weight gradient is the
-    # 512-block grid; the front end / heads use the same kernels on small problems and are kept apart
-    if "gemm_nt_bf16_kernel" in name:
-        return "gemm_nt_bf16_kernel" if "160, 128" in name or "ELi160ELi128" in name else "gemm_nt_bf16_kernel(small tiles)"
-    if "wgrad_group_kernel" in name and row is not None:
-        g = int(float(row.get("Grid_Size", row.get("Grid_Size_X", 0)) or 0))
-        return "wgrad_group_kernel" if g == 512 * 256 else "wgrad_group_kernel(small)"
-    for k in ("gemm_nt_bf16_kernel", "wgrad_group_kernel", "wgrad_tn_bf16_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "ln_fwd_kernel",
-              "ln_bwd_kernel", "wgrad_reduce_kernel", "cast_weights_kernel", "attn_bwd_rows", "attn_bwd_keys"):
+    # the encoder layers' launches: their NT GEMMs run the ping-pong kernel (gemm_nt_pp_kernel), their grouped weight gradient
+    # wgrad_pp_kernel; the front end / heads / small models use gemm_nt_h16_kernel, gemm_nt_group_kernel, wgrad_group_kernel
+    for k in ("gemm_nt_pp_kernel", "wgrad_pp_kernel", "gemm_nt_h16_kernel", "gemm_nt_group_kernel", "wgrad_group_kernel", "wgrad_tn_kernel",
+              "attn_fwd_mfma", "attn_bwd_mfma", "ln_fwd_kernel", "ln_bwd_kernel", "wgrad_reduce_kernel", "cast_weights_kernel",
+              "attn_bwd_rows", "attn_bwd_keys", "split3_kernel", "grad_scale_kernel"):
         if k in name:
             return k
     return None
