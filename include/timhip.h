@@ -172,7 +172,8 @@ typedef struct TimEpi {
   const void* mask; /* optional: the site's keep-bits drawn ahead of time (bit c%8 of byte [r*ldmask + c/8] = element (r,c)
                        kept; what timhip_layer_fwd has LayerNorm-1 write for the FFN dropout).  NULL: drawn in the epilogue */
   int32_t ldmask;   /* row stride of mask in bytes */
-  int32_t reserved;
+  int32_t reserved; /* 0, or the operand replication factor of a split-operand product (3 for timhip_split3_many operands):
+                       only divides the FLOP count the timing hooks attribute to the launch */
   /* TIMHIP_EPI_DROP_RES_F32 only, optional: the residual is LayerNorm(res).  res then holds the PRE-norm fp32 rows, ln_stats
    * the (mean, rstd) pair of every row as timhip_layernorm_fwd writes them, ln_w / ln_b the affine parameters; the epilogue
    * normalises what it reads, so the normalised fp32 rows need not exist in memory.  NULL: res is used as it is. */
@@ -189,7 +190,7 @@ typedef struct TimEpi {
  * _RELU_T): what the classification heads use - four under-filled GEMMs each way (head.py:17-38).  items is a HOST array. */
 typedef struct TimGemmItem {
   const void* A; const void* B;
-  int32_t lda, ldb, M, N, K, reserved;
+  int32_t lda, ldb, M, N, K, reserved;   /* reserved: as TimEpi.reserved */
   TimEpi e;
 } TimGemmItem;
 int timhip_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, void* stream);

@@ -760,7 +760,7 @@ int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, h
     g.A[i] = t.A; g.B[i] = t.B; g.lda[i] = t.lda; g.ldb[i] = t.ldb;
     g.M[i] = t.M; g.N[i] = t.N; g.K[i] = round_up(t.K, 64);
     g.tile0[i + 1] = g.tile0[i] + ((t.M + 63) / 64) * ((t.N + 127) / 128);
-    flops += 2.0 * t.M * t.N * t.K;
+    flops += 2.0 * t.M * t.N * t.K / (t.reserved > 1 ? t.reserved : 1);   // reserved: operand replication of a split GEMM
   }
   TimGemmScope timing(flops, s);
   if (g.tile0[n] <= 512 && epi == TIMHIP_EPI_ADD_F32) {
@@ -793,7 +793,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   const int rc0 = prepare_gemm(precision, epi, A, lda, B, ldb, M, N, K, te, splitk, e);
   if (rc0) return rc0;
   const int Kp = round_up(K, 64);
-  TimGemmScope timing(2.0 * M * N * K, s);
+  TimGemmScope timing(2.0 * M * N * K / (te.reserved > 1 ? te.reserved : 1), s);   // te.reserved: operand replication (split GEMM)
   // production-batch layer shapes: the one-block-per-CU ping-pong kernel (TIMHIP_GEMM_PP=0 turns it off: A/B switch)
   static const bool pp_on = [] { const char* v = getenv("TIMHIP_GEMM_PP"); return !(v && v[0] == '0'); }();
   if (pp_on && h16_storage(precision) && tim_gemm_pp_wins(M, N, Kp, splitk)) {

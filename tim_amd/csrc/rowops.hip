@@ -1180,8 +1180,8 @@ int timhip_grad_scale(const float* const* cot, const long long* counts, int n, f
     if (i < n && (!cot[i] || counts[i] < 0)) return TIMHIP_EINVAL;
     total += gl.n[i];
   }
-  long long blocks = (total / 4 + 255) / 256;
-  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  long long blocks = (total / 4 + 255) / 256 / 4;   // ~4 float4 per thread: enough loads in flight to run at HBM rate
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gl, target, out);
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;

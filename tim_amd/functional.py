@@ -209,14 +209,14 @@ class Runtime:
 
     # ---- thin op wrappers ------------------------------------------------------------------------
     def gemm(self, epi, A, B, M, N, K, out0, ld0, out1=None, ld1=0, bias=None, res=None, ldres=0, aux=None,
-             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0, ln=None, acc_scale=None):
+             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0, ln=None, acc_scale=None, rep=0):
         """ln = (stats[M,2], gamma[N], beta[N]): EPI_DROP_RES_F32 takes LayerNorm(res) as its residual (TimEpi.ln_*);
         acc_scale: device pointer (int) of a scalar multiplied into the accumulators, or None"""
         if M == 0 or N == 0:
             return
         st_, g_, b_ = ln if ln is not None else (None, None, None)
         e = L.TimEpi(ptr(out0), ptr(out1), ptr(bias), ptr(res), ptr(aux), ld0, ld1, ldres, ldaux,
-                     float(p_drop), site, seed, ptr(mask), ldmask, 0, ptr(st_), ptr(g_), ptr(b_), acc_scale)
+                     float(p_drop), site, seed, ptr(mask), ldmask, rep, ptr(st_), ptr(g_), ptr(b_), acc_scale)
         call("timhip_gemm_nt", self.prec, epi, ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K,
              C.byref(e), splitk, _stream())
 
@@ -236,7 +236,7 @@ class Runtime:
         if not self.h16 or len(items) < 2 or os.environ.get("TIM_AMD_NO_GEMM_GROUP", "0") == "1":  # (A/B switch)
             for it in items:
                 self.gemm(epi, it["A"], it["B"], it["M"], it["N"], it["K"], it["out0"], it["ld0"], bias=it.get("bias"),
-                          res=it.get("res"), ldres=it.get("ldres", 0), acc_scale=acc_scale)
+                          res=it.get("res"), ldres=it.get("ldres", 0), acc_scale=acc_scale, rep=it.get("rep", 0))
             return
         for i0 in range(0, len(items), 6):
             grp = items[i0:i0 + 6]
@@ -244,7 +244,7 @@ class Runtime:
             for a, it in zip(arr, grp):
                 a.A, a.B = ptr(it["A"]), ptr(it["B"])
                 a.lda, a.ldb = it["A"].stride(0), it["B"].stride(0)
-                a.M, a.N, a.K = it["M"], it["N"], it["K"]
+                a.M, a.N, a.K, a.reserved = it["M"], it["N"], it["K"], it.get("rep", 0)
                 a.e = L.TimEpi(ptr(it["out0"]), None, ptr(it.get("bias")), ptr(it.get("res")), None, it["ld0"], 0,
                                it.get("ldres", 0), 0, 0.0, 0, 0, None, 0, 0, None, None, None, acc_scale)
             call("timhip_gemm_nt_group", self.prec, epi, C.cast(arr, C.c_void_p), len(grp), _stream())
@@ -332,10 +332,10 @@ class TimeMlpFn(torch.autograd.Function):
             call("timhip_time_l1_fwd", L.PREC_FP32, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(f1), d, _stream())
             h1 = torch.empty((R, 3 * ldd), dtype=rt.op_dtype, device=dev)
             rt.split3([(f1, R, d, d, h1)], mode=0)
-            rt.gemm(L.EPI_STORE_F32, h1, rt.weight_split(w2), R, d, 3 * ldd, f1, d, bias=b2c)
+            rt.gemm(L.EPI_STORE_F32, h1, rt.weight_split(w2), R, d, 3 * ldd, f1, d, bias=b2c, rep=3)
             h2 = torch.empty((R, 3 * ldd), dtype=rt.op_dtype, device=dev)
             rt.split3([(f1, R, d, d, h2)], mode=0, relu=True)
-            rt.gemm(L.EPI_STORE_F32, h2, rt.weight_split(w4), R, d, 3 * ldd, u3, d, bias=b4c)
+            rt.gemm(L.EPI_STORE_F32, h2, rt.weight_split(w4), R, d, 3 * ldd, u3, d, bias=b4c, rep=3)
         else:
             h1 = rt.out_op(R, d, dev)
             call("timhip_time_l1_fwd", rt.prec, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(h1), ldd, _stream())
@@ -605,7 +605,7 @@ class EncoderFn(torch.autograd.Function):
                 if n > 0:
                     head_ranges.append((s0, n, rows))
                     head_splits.append((rows, B * n, E, E, rows3))
-                    head_gemms.append(dict(A=rows3, B=rt.weight_split(w), M=B * n, N=Cn, K=3 * E, out0=logits, ld0=Cn, bias=bias))
+                    head_gemms.append(dict(A=rows3, B=rt.weight_split(w), M=B * n, N=Cn, K=3 * E, out0=logits, ld0=Cn, bias=bias, rep=3))
                 head_saved.append((slot, pname, s0, n, None))
             else:
                 rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
