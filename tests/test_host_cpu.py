@@ -132,3 +132,38 @@ def test_token_row_plan_matches_oracle_assembly(fname, im, dm, vn, nv, na):
         w, b = sd["cls_head." + pname + ".weight"], sd["cls_head." + pname + ".bias"]
         mine = (want[:, s0:s0 + n] @ w.t() + b).reshape(-1, w.shape[0])
         np.testing.assert_allclose(mine.numpy(), ref.numpy(), atol=1e-12)
+
+
+def test_avga_pooling_prestep_matches_reference():
+    """pool_features=True (AVE recipe): same state_dict keys as the reference model, and the pooling module - stock torch, an
+    input pre-step outside the HIP path - reproduces the reference module's output (tests/golden/make_golden_r2.py)"""
+    from tim_amd.tim import TIM
+    g = np.load(os.path.join(H.GOLDEN, "avga_tiny.npz"))
+    m = TIM([[7, 11, 13], 5], visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2, num_feats=6,
+            pool_features=True)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    m.pool.load_state_dict({k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("pool/")})
+    out = m.pool(torch.from_numpy(g["audio"]), torch.from_numpy(g["video"]))
+    assert (out - torch.from_numpy(g["pooled"])).abs().max().item() <= 1e-6
+
+
+def test_constructor_rejects_shapes_the_kernels_do_not_cover():
+    from tim_amd.tim import TIM
+    with pytest.raises(ValueError, match="feature tokens"):
+        TIM([[7, 11, 13], 5], d_model=32, nhead=2, num_layers=1, num_feats=100)      # 200 keys per head > 192
+    TIM([[7, 11, 13], 5], d_model=32, nhead=2, num_layers=1, num_feats=96)
+
+
+def test_workspaces_captured_by_a_graph_are_retired_not_freed():
+    from tim_amd.tim import TIM
+    m = TIM([[7, 11, 13], 5], visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=1, num_feats=6)
+    dev = torch.device("cpu")
+    a = m._workspace(1000, dev)
+    assert m._workspace(500, dev) is a
+    m._ws_pinned = True                      # what GraphedStep sets
+    b = m._workspace(5000, dev)
+    assert b is not a and any(w is a for w in m._ws_retired)      # the captured buffer stays alive
+    st = m.dropout_rng_state()
+    m.rt.step = 17
+    m.set_dropout_rng_state(st)
+    assert m.rt.step == st["dropout_step"]

@@ -55,7 +55,7 @@ class DataParallel(nn.Module):
         rt.bucket_hook = self._on_bucket
         rt.finish_hook = self._on_encoder_done
         self._small = [p for n, p in module.named_parameters()
-                       if n.startswith("time_mlp.") or n.startswith("drloc_mlp.")]
+                       if n.startswith("time_mlp.") or n.startswith("drloc_mlp.") or n.startswith("pool.")]
         self._small_flat = None
         self._hook_handles = []
         if self.active:

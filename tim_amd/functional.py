@@ -72,7 +72,15 @@ class Runtime:
         self.grad_scale_target = 64.0
         self._wcache = {}
         self._wparams = {}  # id(param) -> weakref: every weight this runtime has cast
-        self.seed = 0x5EED
+        # dropout stream: seeded from torch's generator (torch.manual_seed / args.seed select the run's masks, as they do in the
+        # reference) and from the rank (data-parallel replicas draw different masks); TIM.dropout_rng_state() /
+        # set_dropout_rng_state() let a checkpoint resume the sequence instead of replaying it
+        try:
+            import torch.distributed as _dist
+            rank = _dist.get_rank() if _dist.is_available() and _dist.is_initialized() else 0
+        except Exception:  # noqa: BLE001
+            rank = 0
+        self.seed = ((torch.initial_seed() & 0xFFFFFFFFFFFF) * 0x9E3779B1 + rank * 0x85EBCA6B + 0x5EED) & 0x7FFFFFFFFFFFFFFF
         self.step = 0
         self.bucket_hook = None  # callable(bucket_name, flat_grad_tensor) -> None
         self.finish_hook = None  # callable() -> None, called at the end of the encoder backward
@@ -83,6 +91,7 @@ class Runtime:
         self.overlap_wgrad = os.environ.get("TIM_AMD_OVERLAP_WGRAD", "0") == "1"
         self.separate_wgrad = os.environ.get("TIM_AMD_WGRAD_SEPARATE", "0") == "1"  # A/B: per-Linear weight-gradient launches
         self._aux = {}
+        self.recast_every_forward = False
 
     def aux_stream(self, dev):
         st = self._aux.get(dev)
@@ -175,7 +184,12 @@ class Runtime:
                  _iarr([g[4].shape[1] for g in grp]), mode, 1 if relu else 0, _stream())
 
     def invalidate_weights(self):
-        """force the operand copies to be rebuilt (bench: emulate the state after an optimizer step)"""
+        """Force the operand copies to be rebuilt.  The copies are keyed on (data_ptr, version counter) of the parameter:
+        optimizer steps and every in-place op on the parameter bump the version and are picked up automatically; writes
+        through `p.data` (custom init, EMA / weight surgery code, `load_state_dict` goes through copy_ and IS tracked) do not
+        bump it - call this (also exported as `TIM.invalidate_weights()`) after such a write, or set
+        `rt.recast_every_forward = True` to rebuild the copies at every training forward (one grouped launch, ~0.1 ms at
+        C2a)."""
         for k, ent in list(self._wcache.items()):
             self._wcache[k] = (None, ent[1], ent[2])
         for k, ent in list(self._wsplit.items()):
@@ -515,6 +529,8 @@ class EncoderFn(torch.autograd.Function):
         S, F = plan.S, plan.F
         M = B * S
         training = model.training
+        if training and rt.recast_every_forward:
+            rt.invalidate_weights()
         seed = rt.next_seed() if training else 0
         p_feat = cfg.feat_drop if training else 0.0
         p_seq = cfg.seq_drop if training else 0.0

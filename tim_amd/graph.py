@@ -43,6 +43,7 @@ class GraphedStep:
     def __init__(self, model, fn, warmup=3):
         inner = model.module if hasattr(model, "module") else model
         self.rt = inner.rt
+        inner._ws_pinned = True   # the graph keeps raw pointers into the model's workspaces: they are retired, never freed
         dev = next(inner.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("GraphedStep needs the model on a GPU; the HIP path has no CPU fallback")

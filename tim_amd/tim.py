@@ -146,6 +146,34 @@ class _EncoderStackParams(nn.Module):
         self.num_layers = num_layers
 
 
+class _AVGAParams(nn.Module):
+    """Audio-guided visual attention pooling of the AVE recipe (pool.py:6-43; `pool_features=True`): collapses a [B, T, 7, 7,
+    Cv] visual feature map to [B, T, Cv] before the hot path starts.  An input pre-step outside the encoder path (SURVEY 2,
+    row 9): parameter names / shapes / initialisation as the reference's so that checkpoints round-trip; evaluated with stock
+    torch ops (autograd included)."""
+
+    def __init__(self, a_dim, v_dim, hidden_size, map_size=49):
+        super().__init__()
+        self.affine_audio = nn.Linear(a_dim, hidden_size)
+        self.affine_video = nn.Linear(v_dim, hidden_size)
+        self.affine_v = nn.Linear(hidden_size, map_size, bias=False)
+        self.affine_g = nn.Linear(hidden_size, map_size, bias=False)
+        self.affine_h = nn.Linear(map_size, 1, bias=False)
+        for lin in (self.affine_v, self.affine_g, self.affine_h, self.affine_audio, self.affine_video):
+            nn.init.xavier_uniform_(lin.weight)
+        nn.init.constant_(self.affine_audio.bias, 0)
+        nn.init.constant_(self.affine_video.bias, 0)
+
+    def forward(self, audio, video):
+        B, T, C = video.shape[0], video.shape[1], video.shape[-1]
+        cells = video.reshape(B * T, -1, C)                                   # [B*T, 49, Cv] spatial cells of one time step
+        hv = torch.relu(self.affine_video(cells))
+        ha = torch.relu(self.affine_audio(audio.reshape(B * T, -1)))
+        score = self.affine_h(torch.tanh(self.affine_v(hv) + self.affine_g(ha).unsqueeze(2))).squeeze(2)
+        attn = torch.softmax(score, dim=-1)                                   # one weight per spatial cell
+        return torch.einsum("rs,rsc->rc", attn, cells).reshape(B, T, C)
+
+
 class _GradBuckets:
     def __init__(self, rt, names, params, dev, bucket_of, layer_overwrite=False):
         """layer_overwrite: the encoder layers' Linear weight/bias gradients are written by the kernels
@@ -206,9 +234,6 @@ class TIM(nn.Module):
                  precision="bf16",
                  _variant="recognition"):
         super().__init__()
-        if pool_features:
-            # AVGA pooling (pool.py:6-43) is an AVE-only pre-step outside the hot path
-            raise NotImplementedError("pool_features=True (AVGA, AVE dataset only) is outside the MI355X hot path")
         if d_model % 32 != 0:
             raise ValueError("d_model must be a multiple of 32 for the gfx950 kernels")
         self.cfg = TimConfig(num_class=num_class, visual_input_dim=visual_input_dim, audio_input_dim=audio_input_dim,
@@ -240,13 +265,39 @@ class TIM(nn.Module):
             self.transformer_encoder = stack
         self._stack_prefix = "backbone" if _variant == "detection" else "transformer_encoder"
         self.drloc_mlp = nn.Sequential(nn.Linear(4 * d, d), nn.ReLU(), nn.Linear(d, d), nn.ReLU(), nn.Linear(d, 1))
-        self.pool = None
+        # AVGA pooling of the AVE recipe: an input pre-step in stock torch, outside the hot path (tim.py:137-144,155-156)
+        self.pool = _AVGAParams(audio_input_dim, visual_input_dim, visual_input_dim) if pool_features else None
 
         self.rt = Runtime(precision)
         self._plans = {}
         self._ws = {}
+        self._ws_pinned = False   # set by GraphedStep: workspaces captured in a graph are never freed
+        self._ws_retired = []
+        self._check_kernel_limits()
         self._encoder_param_names = [n for n, _ in self.named_parameters()
-                                     if not (n.startswith("time_mlp.") or n.startswith("drloc_mlp."))]
+                                     if not (n.startswith("time_mlp.") or n.startswith("drloc_mlp.") or n.startswith("pool."))]
+
+    def _check_kernel_limits(self):
+        """Shapes the gfx950 kernels do not cover fail HERE, with the reason, not at the first forward."""
+        cfg = self.cfg
+        if cfg.F > 192:
+            raise ValueError("num_feats gives %d feature tokens per window; the attention kernels keep a head's keys and values "
+                             "in LDS and cover at most 192 (num_feats <= 96 for audio_visual, <= 192 for one modality)" % cfg.F)
+        if cfg.E % cfg.nhead != 0:
+            raise ValueError("nhead must divide the transformer width 2 * d_model = %d" % cfg.E)
+        if self.rt.h16 and (cfg.E // cfg.nhead) not in (32, 64, 128):
+            import warnings
+            warnings.warn("head dimension %d: the MFMA attention kernels cover 32 / 64 / 128; this model runs the (much slower) "
+                          "fp32-arithmetic attention kernels" % (cfg.E // cfg.nhead))
+
+    # ---- dropout RNG state: NOT part of state_dict() (its keys must stay the reference's, SURVEY 8b); a checkpoint that
+    # should resume the mask sequence stores this beside it, as the reference's loop would store torch's RNG state
+    def dropout_rng_state(self):
+        return {"dropout_seed": int(self.rt.seed), "dropout_step": int(self.rt.step)}
+
+    def set_dropout_rng_state(self, state):
+        self.rt.seed = int(state["dropout_seed"])
+        self.rt.step = int(state["dropout_step"])
 
     # ---- helpers used by tim_amd.functional --------------------------------------------------------
     def _encoder_param_list(self):
@@ -262,9 +313,16 @@ class TIM(nn.Module):
         return p
 
     def _workspace(self, nbytes, dev, slot="main"):
+        """Scratch buffer of at least `nbytes`, cached per (device, slot) and grown on demand.  A captured HIP graph
+        (tim_amd.graph.GraphedStep) holds raw pointers into the buffers it was captured with: once a graph exists on this
+        model (`_ws_pinned`), an outgrown buffer is retired - kept alive, never handed back to the allocator - instead of
+        freed, so a larger eager call between replays (validation at another batch size, a longer sequence) cannot make
+        the graph write into memory that now belongs to other tensors."""
         key = (dev, slot)
         w = self._ws.get(key)
         if w is None or w.numel() < nbytes:
+            if w is not None and self._ws_pinned:
+                self._ws_retired.append(w)
             w = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
             self._ws[key] = w
         return w
@@ -281,6 +339,10 @@ class TIM(nn.Module):
                                              "norm2.bias")]
         return L.TimLayerParams(*[t.data_ptr() for t in keep]), keep
 
+    def invalidate_weights(self):
+        """call after writing parameters through `.data` (see Runtime.invalidate_weights)"""
+        self.rt.invalidate_weights()
+
     def _bucket_of(self, name):
         pre = self._stack_prefix + ".layers."
         if name.startswith(pre):
@@ -294,6 +356,8 @@ class TIM(nn.Module):
 
     # ---- the reference's public interface ------------------------------------------------------------
     def forward_encoder(self, inputs, time_encodings, num_v_queries, num_a_queries):
+        if self.pool is not None:
+            inputs = [self.pool(inputs[1], inputs[0]), inputs[1]]
         outs = EncoderFn.apply(self, int(num_v_queries or 0), int(num_a_queries or 0), inputs[0], inputs[1],
                                time_encodings, *self._encoder_param_list())
         o = dict(zip(OUT_SLOTS, outs))
