@@ -31,7 +31,7 @@ class TIM(_TIMBase):
                  include_verb_noun=True,
                  iou_threshold=0.25,
                  label_smoothing=0.9,
-                 precision="bf16"):
+                 precision="fp16"):
         super().__init__(num_class, visual_input_dim, audio_input_dim, feat_drop, seq_drop, d_model,
                          feedfoward_scale, nhead, num_layers, enc_dropout, input_modality, data_modality,
                          num_feats, include_verb_noun, False, precision, _variant="detection")

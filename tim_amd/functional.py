@@ -53,7 +53,7 @@ class Runtime:
     the weights (plain and transposed, refreshed when a parameter's version changes),
     the Philox step counter, and the gradient-bucket hook used by data parallelism."""
 
-    def __init__(self, precision="bf16"):
+    def __init__(self, precision="fp16"):
         if precision not in L.PRECISIONS:
             raise ValueError("precision must be one of %s" % list(L.PRECISIONS))
         self.precision_name = precision

@@ -231,7 +231,7 @@ class TIM(nn.Module):
                  num_feats=50,
                  include_verb_noun=True,
                  pool_features=False,
-                 precision="bf16",
+                 precision="fp16",
                  _variant="recognition"):
         super().__init__()
         if d_model % 32 != 0:
