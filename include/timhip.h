@@ -217,6 +217,11 @@ int timhip_colsum(int precision, const void* src, int rows, int cols, int ld, fl
 int timhip_split3_many(int precision, int count, const float* const* src, const int* rows, const int* cols, const int* lds,
                        void* const* dst, const int* ldd, int mode, int relu, void* stream);
 
+/* Data-parallel gradient exchange (tim_amd/dp.py; replaces the DistributedDataParallel wrap of models/build.py:58-63): after
+ * the all-to-all, recv [world][per] (bf16 if wire_bf16 else fp32) holds this rank's chunk of every rank's bucket;
+ * out[per] (same dtype) = scale * sum over ranks, accumulated in fp32.  per % 4 == 0, 16-byte aligned buffers. */
+int timhip_dp_reduce(int wire_bf16, const void* recv, int world, long long per, float scale, void* out, void* stream);
+
 /* Gradient scale of the fp16 mode.  fp16 has 5 exponent bits: gradient operands would underflow (the reference's GPU recipe
  * wraps its step in a GradScaler for that reason, recognition/scripts/train.py:82,355-363).  Here the scale is chosen per
  * backward pass ON THE DEVICE from the cotangents entering it: S = 2^floor(log2(target / max|cot|)), out[0] = S,

@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
         cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
         m = TIM(cfg.num_class, visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2, num_feats=6)
         before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
-        dp = DataParallel(m, wire_dtype=torch.float32)
+        dp = DataParallel(m, wire_dtype=torch.float32, buckets_per_exchange=3)
         assert dp.world == world and dp.active and m.rt.bucket_hook is not None
         names = m._encoder_param_names
         params = m._encoder_param_list()
@@ -52,6 +52,9 @@ def _worker(rank, world, port, q):
             gb.views[n].fill_(float(i + 1) * (rank + 1))  # what the kernels would have accumulated
         for b in ("heads", "layer1", "layer0", "front"):  # order in which the backward completes them
             gb.done(b)
+        assert len(dp._pending) == 1                      # three buckets travelled as one contiguous range, one is waiting
+        m.rt.finish_hook()                                # end of the encoder backward: the rest is exchanged
+        assert not dp._pending
         mean = (1 + world) / 2.0
         for i, n in enumerate(names):
             v = gb.views[n]

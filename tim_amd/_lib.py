@@ -128,6 +128,7 @@ _SIGS = {
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),
+    "timhip_dp_reduce": (C.c_int, [i32, vp, i32, C.c_longlong, f32, vp, vp]),
     "timhip_split3_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "timhip_label_queries": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
     "timhip_smooth_one_hot": (C.c_int, [vp, i32, i32, C.c_int64, i32, f32, f32, vp, vp]),

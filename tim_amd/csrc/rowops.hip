@@ -759,6 +759,24 @@ __global__ void split3_kernel(Split3Many sm) {
 }
 
 // ---------------------------------------------------------------------------
+// Data-parallel gradient exchange, step 3 of tim_amd/dp.py: rank r holds chunk r of every rank's bucket (recv [W][per], wire
+// dtype) after the all-to-all; out[i] = T(scale * sum_w float(recv[w][i])) - fp32 accumulation whatever travelled on the wire.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dp_reduce_kernel(const T* __restrict__ recv, int W, long long per, float scale,
+                                                        T* __restrict__ out) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < per; i += (long long)gridDim.x * blockDim.x * 4) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int w = 0; w < W; ++w) {
+      float v0, v1, v2, v3;
+      load4<T>(recv + (long long)w * per + i, v0, v1, v2, v3);
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    store4<T>(out + i, a0 * scale, a1 * scale, a2 * scale, a3 * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Gradient scale of the fp16 mode (timhip_grad_scale): S = the power of two that brings the largest |cotangent| to
 // `target`; out = {S, 1/S, scratch, scratch}.  One launch: every block folds its maximum into out[2] (float bits compare
 // like unsigned integers for non-negative values), the last block to arrive (ticket in out[3]) writes S and 1/S and
@@ -1166,6 +1184,21 @@ int timhip_split3_many(int precision, int count, const float* const* src, const 
   }
   dim3 grid((maxc + 255) / 256 > 8 ? 8 : (maxc + 255) / 256, maxr, count);
   DISPATCH_H16(precision, hipLaunchKernelGGL(split3_kernel<HT>, grid, dim3(256), 0, (hipStream_t)stream, sm));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_dp_reduce(int wire_bf16, const void* recv, int world, long long per, float scale, void* out, void* stream) {
+  if (!recv || !out || world < 1 || per <= 0 || (per & 3)) return TIMHIP_EINVAL;
+  if ((((uintptr_t)recv | (uintptr_t)out) & 15) != 0) return TIMHIP_EALIGN;
+  long long blocks = (per / 4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  if (wire_bf16)
+    hipLaunchKernelGGL(dp_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)recv, world,
+                       per, scale, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(dp_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)recv, world,
+                       per, scale, (float*)out);
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

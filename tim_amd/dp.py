@@ -34,9 +34,18 @@ from torch import nn
 
 
 class DataParallel(nn.Module):
-    def __init__(self, module, process_group=None, wire_dtype=torch.bfloat16, broadcast_parameters=True, force=False):
+    def __init__(self, module, process_group=None, wire_dtype=torch.bfloat16, broadcast_parameters=True, force=False,
+                 buckets_per_exchange=4):
         """force: run the exchange even in a one-rank group (every collective is then a copy) - the single-GPU
-        test of how the side-stream work interferes with the backward uses it."""
+        test of how the side-stream work interferes with the backward uses it.
+        buckets_per_exchange: consecutive gradient buckets (contiguous in memory, tim.py:_GradBuckets) travel as one range.
+        Every exchange is ~5 enqueues on the comm stream and the host is close to being the bottleneck of the step (330
+        launches in ~6 ms), so nine separate exchanges cost the step 0.70 ms on one GPU (1-rank group: every
+        collective a copy) although their kernels run only 0.55 ms off the critical path; 2 / 3 / 4 per exchange: +0.49 /
+        0.47 / 0.43 ms with 0.39 / 0.34 / 0.32 ms of comm-stream kernel time; everything as ONE exchange at the end (no
+        overlap at all) +0.43 ms - the floor on one GPU is the exchange's own memory passes (narrow, sum, widen: ~0.8 GB)
+        plus the tail (the last range and the time-MLP parameters cannot overlap anything).  Measured with
+        tools/dp_single_gpu_check.py, C2a, B = 64, 5.65 ms step."""
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -51,6 +60,8 @@ class DataParallel(nn.Module):
         self.comm_events = []      # (start, end) event pairs of this step's exchanges (timing=True only)
         self.timing = False
         self.bytes_on_wire = 0     # per rank and step: bytes sent + received by the last step's exchanges
+        self.buckets_per_exchange = max(1, int(buckets_per_exchange))
+        self._pending = []         # buckets completed but not yet exchanged: (flat, ready)
         rt = module.rt
         rt.bucket_hook = self._on_bucket
         rt.finish_hook = self._on_encoder_done
@@ -112,9 +123,14 @@ class DataParallel(nn.Module):
         per = st["per"]
         st["send"][:n].copy_(flat)                                             # 1. narrow
         dist.all_to_all_single(st["recv"], st["send"], group=self.pg)          # 2. chunk r of every rank -> rank r
-        torch.sum(st["recv"].view(W, per), dim=0, dtype=torch.float32, out=st["acc"])   # 3. fp32 accumulation
-        st["acc"].mul_(1.0 / W)
-        st["shard"].copy_(st["acc"])
+        if flat.is_cuda and self.wire_dtype in (torch.bfloat16, torch.float32):        # 3. fp32 accumulation: one launch
+            from ._lib import call, ptr
+            call("timhip_dp_reduce", 1 if self.wire_dtype == torch.bfloat16 else 0, ptr(st["recv"]), W, per, 1.0 / W,
+                 ptr(st["shard"]), torch.cuda.current_stream().cuda_stream)
+        else:                                                                          # (gloo / CPU tests of the logic)
+            torch.sum(st["recv"].view(W, per), dim=0, dtype=torch.float32, out=st["acc"])
+            st["acc"].mul_(1.0 / W)
+            st["shard"].copy_(st["acc"])
         dist.all_gather_into_tensor(st["send"], st["shard"], group=self.pg)    # 4. (send is free again: reuse it)
         flat.copy_(st["send"][:n])                                             # 5. widen
         esz = st["send"].element_size()
@@ -128,10 +144,28 @@ class DataParallel(nn.Module):
     def _on_bucket(self, name, flat, ready=None):
         if not (self.active and self.sync):
             return
+        # consecutive buckets are contiguous in memory (same storage, ascending addresses): collect them into one range
+        if self._pending and self._pending[-1][0].data_ptr() + self._pending[-1][0].numel() * 4 != flat.data_ptr():
+            self._flush()      # (a bucket from elsewhere: exchange what is pending on its own)
+        self._pending.append((flat, ready))
+        if len(self._pending) >= self.buckets_per_exchange:
+            self._flush()
+
+    def _flush(self):
+        if not self._pending:
+            return
+        first = self._pending[0][0]
+        n = sum(f.numel() for f, _ in self._pending)
+        flat = torch.as_strided(first, (n,), (1,))     # the range first .. last of the shared base buffer
+        readies = [r for _, r in self._pending if r is not None]
+        self._pending = []
+        self._exchange_async(flat, readies)
+
+    def _exchange_async(self, flat, readies=()):
         if flat.is_cuda:
             comm = self._comm_stream(flat.device)
             comm.wait_stream(torch.cuda.current_stream())
-            if ready is not None:
+            for ready in readies:
                 comm.wait_event(ready)  # weight gradients written on the side stream
             with torch.cuda.stream(comm):
                 if self.timing:
@@ -146,6 +180,8 @@ class DataParallel(nn.Module):
             self._exchange(flat)
 
     def _on_encoder_done(self):
+        if self.active and self.sync:
+            self._flush()
         if self.active and self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
 

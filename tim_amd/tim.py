@@ -186,9 +186,22 @@ class _GradBuckets:
         for n, p in zip(names, params):
             b = bucket_of(n)
             sizes[b] = sizes.get(b, 0) + (p.numel() + 3) // 4 * 4
-        for b, sz in sizes.items():
-            lazy = layer_overwrite and b.startswith("layer")
-            self.flat[b] = (torch.empty if lazy else torch.zeros)(sz, dtype=torch.float32, device=dev)
+        # ONE allocation, the buckets laid out in the order the backward completes them (heads, last layer ... first layer,
+        # front end): consecutive buckets are contiguous, so the data-parallel exchange can take several as one range
+        def order(b):
+            return (0, 0) if b == "heads" else ((1, -int(b[5:])) if b.startswith("layer") else (2, 0))
+        self.order = sorted(sizes, key=order)
+        total = sum((sizes[b] + 63) // 64 * 64 for b in self.order)
+        self.base = torch.empty(total, dtype=torch.float32, device=dev)
+        pos = 0
+        for b in self.order:
+            n = (sizes[b] + 63) // 64 * 64                 # 256-byte aligned bucket starts (the tail padding is exchanged too)
+            self.flat[b] = self.base[pos:pos + n]
+            if not (layer_overwrite and b.startswith("layer")):
+                self.flat[b].zero_()
+            else:
+                self.flat[b][sizes[b]:].zero_()
+            pos += n
         off = {b: 0 for b in sizes}
         accumulated = []
         for n, p in zip(names, params):
@@ -208,6 +221,13 @@ class _GradBuckets:
         """`ready`: event after which the side-stream part of the bucket is complete (None: current stream)"""
         if self.rt.bucket_hook is not None and bucket in self.flat:
             self.rt.bucket_hook(bucket, self.flat[bucket], ready)
+
+    def range_of(self, first, last):
+        """the contiguous fp32 range covering buckets first..last (in completion order)"""
+        a, b = self.flat[first], self.flat[last]
+        start = (a.data_ptr() - self.base.data_ptr()) // 4
+        end = (b.data_ptr() - self.base.data_ptr()) // 4 + b.numel()
+        return self.base[start:end]
 
 
 class TIM(nn.Module):
