@@ -21,9 +21,12 @@
  *
  * Conventions
  *   - Plain C: pointers and sizes only.  Every device buffer is allocated and owned by the caller;
- *     the library never allocates device memory, never synchronises, never keeps a pointer after
- *     the call returns, and has no global mutable state (re-entrant; forward is called from the
- *     Python main thread and backward from PyTorch's autograd thread).
+ *     the library never allocates device memory and keeps no pointer after the call returns
+ *     (re-entrant; forward is called from the Python main thread and backward from PyTorch's
+ *     autograd thread).  Exceptions, all opt-in: two process-wide switches - the dropout salt
+ *     pointer registered by timhip_dropout_salt() (HIP-graph replay) and the measurement hooks
+ *     timhip_gemm_timing_start/stop() (bench.py) - and timhip_softnms_1d(), which synchronises its
+ *     stream once (it returns the number of kept segments to the host).
  *   - All work is enqueued on the `stream` argument (a hipStream_t passed as void*).
  *   - Return value: 0 on success, a negative TIMHIP_E* code otherwise (timhip_strerror()).
  *     No exception crosses the ABI.
