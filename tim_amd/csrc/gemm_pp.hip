@@ -20,11 +20,11 @@
 // input gradient 67.6 vs 60.2 us), although an 8-wave s_barrier costs ~150 cycles (tools/wgpp_abl.py): for ds_read_b128
 // operands the explicit alternation pays; for the transposing-read weight-gradient kernel (wgrad_pp.hip) it does not.
 //
-// Hazards (phase p = 2 t + s: contraction step t, half s; G0 = waves 0-3, G1 = waves 4-7, G1 one barrier behind):
-//   RAW  stage t+1 is first read by G0 after the barrier that ends its second MFMA phase of step t; every wave has waited
-//        (vmcnt) for its own DMA pieces of stage t+1 in its second LOAD phase of step t, i.e. at least one barrier earlier.
-//   WAR  stage (t+2) % 3 = (t-1) % 3 is refilled from G0's first MFMA phase of step t on; the last fragment reads of step
-//        t-1 (G1's second LOAD phase) were waited for (lgkmcnt) BEFORE a barrier G0 has to pass to get there.
+// Hazards (one LOAD + one MFMA phase per contraction step t; G0 = waves 0-3, G1 = waves 4-7, G1 one barrier behind):
+//   RAW  stage t+1 is first read by G0 after the barrier that ends its MFMA phase of step t; every wave has waited (vmcnt)
+//        for its own DMA pieces of stage t+1 in its LOAD phase of step t, i.e. at least one barrier earlier.
+//   WAR  stage (t+2) % 3 = (t-1) % 3 is refilled from G0's MFMA phase of step t on; the last fragment reads of step t-1
+//        (G1's LOAD phase) were waited for (lgkmcnt) BEFORE a barrier G0 has to pass to get there.
 #include <stdlib.h>
 
 #include "gemm_epi.h"
@@ -164,7 +164,7 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
 // G1 waves 6 (3 + 3): the issue slots between a wave's own MFMAs are free (the matrix pipe is busy for 16 cycles per MFMA),
 // while a DMA piece issued in a LOAD phase lengthens the phase the partner's MFMAs have to cover.
 template <int TMW, int G> struct PpShare {
-  static constexpr int CNT = G == 0 ? 7 : 6, P0 = G == 0 ? 4 : 3;   // pieces per step, of which in the first MFMA phase
+  static constexpr int CNT = G == 0 ? 7 : 6, P0 = G == 0 ? 4 : 3;   // pieces per step (P0: unused since the phases were merged)
   static_assert(4 * 7 + 4 * 6 == 2 * TMW * 2 + 32, "the share table is written for the 160 x 256 tile");
 };
 
@@ -174,7 +174,7 @@ __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* 
                                             f32x4_t (&acc)[PP_TNW][TMW], long long* prof = nullptr) {
   constexpr int BM = 32 * TMW, A_PIECES = BM / 8;
   constexpr int A_BYTES = BM * PP_ROWB, B_BYTES = PP_BN * PP_ROWB, ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int CNT = PpShare<TMW, G>::CNT, P0 = PpShare<TMW, G>::P0;
+  constexpr int CNT = PpShare<TMW, G>::CNT;
 
   // this wave's i-th piece of stage `kt`, into ring slot `slot`
   auto piece = [&](int kt, int slot, int i) {
@@ -205,42 +205,46 @@ __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* 
   };
   // one contraction step; MORE: stage t + 2 exists and is issued during this step's MFMA phases (a compile-time flag: the
   // last two steps run a copy of the loop body without the DMA pieces instead of branching around each of them)
+  // One LOAD and one MFMA phase per contraction step (the fragments of both 32-deep halves are read in one go: 18
+  // ds_read_b128, 72 VGPRs; 40 MFMAs per phase): two barriers per step.  An 8-wave s_barrier costs ~150 cycles
+  // (tools/wgpp_abl.py), so with a phase per half step the four barriers were a third of the loop's time.
+  vec8<HT> xb[TMW], wc[PP_TNW];   // second half's fragments
   auto step = [&](int t, auto more_c) {
     constexpr bool MORE = decltype(more_c)::value;
     const char* base = lds + slot * ST_BYTES;
     const int nslot = slot >= 1 ? slot - 1 : PP_NST - 1;   // (t + 2) % 3
+    // ---- LOAD phase: the fragments of step t
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      // ---- LOAD phase: the fragments of (step t, half)
-      const int cc = half == 0 ? c0 : c1;
+    for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c0);
 #pragma unroll
-      for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + cc);
+    for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c0);
 #pragma unroll
-      for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + cc);
-      if (half == 1) {   // every piece of stage t + 1 issued by this wave has landed (the P0 pieces of t + 2 may stay in flight)
-        if constexpr (MORE) glds_wait<P0>(); else glds_wait<0>();
-      }
-      pp_wait_lds();
-      lap(t_load);
-      pp_barrier();
-      lap(t_bar_a);
-      // ---- MFMA phase, with this wave's DMA pieces for step t + 2 between the MFMAs (after every fifth one)
+    for (int j = 0; j < TMW; ++j) xb[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c1);
+#pragma unroll
+    for (int i = 0; i < PP_TNW; ++i) wc[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c1);
+    glds_wait<0>();   // every piece of stage t + 1 issued by this wave (during the previous MFMA phase) has landed
+    pp_wait_lds();
+    lap(t_load);
+    pp_barrier();
+    lap(t_bar_a);
+    // ---- MFMA phase, with this wave's DMA pieces for step t + 2 between the MFMAs (after every fifth one)
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int j = 0; j < TMW; ++j)
 #pragma unroll
         for (int i = 0; i < PP_TNW; ++i) {
-          acc[i][j] = mfma16x16<HT>(wb[i], xa[j], acc[i][j]);
-          const int q = j * PP_TNW + i, k = q / 5;
-          if (MORE && q % 5 == 2 && k < (half == 0 ? P0 : CNT - P0)) {
+          acc[i][j] = half == 0 ? mfma16x16<HT>(wb[i], xa[j], acc[i][j]) : mfma16x16<HT>(wc[i], xb[j], acc[i][j]);
+          const int q = half * (TMW * PP_TNW) + j * PP_TNW + i, k = q / 5;
+          if (MORE && q % 5 == 2 && k < CNT) {
             __builtin_amdgcn_sched_barrier(0);
-            piece(t + 2, nslot, half == 0 ? k : P0 + k);
+            piece(t + 2, nslot, k);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-      lap(t_mma);
-      pp_barrier();
-      lap(t_bar_b);
-    }
+    lap(t_mma);
+    pp_barrier();
+    lap(t_bar_b);
     slot = slot + 1 == PP_NST ? 0 : slot + 1;
   };
   int t = 0;

@@ -23,8 +23,8 @@ for (M, N, K) in ((9920, 1024, 3072), (9920, 3072, 1024), (9920, 1024, 1024), (9
     print("M%d N%d K%d: %.1f us %.0f TF" % (M, N, K, us, 2.0 * M * N * K / us / 1e6))
     for gi, name in ((0, "G0"), (8, "G1")):
         nb = max(c[gi + 5], 1)
-        ph = 2 * nk
-        print("   %s per phase: load %.0f | barrier %.0f | mfma %.0f | barrier %.0f  (sum %.0f cyc; ideal mfma phase 320)   block: "
+        ph = nk   # one LOAD + one MFMA phase per contraction step
+        print("   %s per step: load %.0f | barrier %.0f | mfma %.0f | barrier %.0f  (sum %.0f cyc per contraction step and wave; 40 MFMAs = 640 cyc of matrix pipe)   block: "
               "loop+prologue %.0f cyc, epilogue %.0f cyc, clock %.2f GHz, life %.1f us"
               % (name, c[gi] / nb / ph, c[gi + 1] / nb / ph, c[gi + 2] / nb / ph, c[gi + 3] / nb / ph,
                  (c[gi] + c[gi + 1] + c[gi + 2] + c[gi + 3]) / nb / ph, c[gi + 4] / nb, c[gi + 7] / nb,
