@@ -275,8 +275,14 @@ def test_gemm_dropout_keep_bits(epi, M, N, prec):
     (9920, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # C2a: 512 tiles, no split, direct writes
     (4100, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # same, ragged last step of 64 rows
 ])
-def test_wgrad_group(M, shapes, accumulate, prec):
-    """several Linear weight gradients sharing M in one launch == the per-layer reference; biases optional"""
+@pytest.mark.parametrize("loaders", [True, False])
+def test_wgrad_group(M, shapes, accumulate, prec, loaders, monkeypatch):
+    """several Linear weight gradients sharing M in one launch == the per-layer reference; biases optional.
+    loaders: the one-block-per-CU kernel with four DMA loader waves (default) / its 8-wave form (TIMHIP_WGRAD_LD=0)"""
+    if not loaders:
+        if M < 2048:
+            pytest.skip("small groups do not take the one-block-per-CU kernels")
+        monkeypatch.setenv("TIMHIP_WGRAD_LD", "0")
     rt = Runtime(prec)
     items, refs = [], []
     for i, (N, K) in enumerate(shapes):

@@ -655,7 +655,7 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
       }
 #undef ABLV
     }
-    if constexpr (tunable<EPI>()) {
+    if (tunable<EPI>() && variant != 0) {   // (bf16 tile variants of tools/gemm_tune.py; variant 0 = the production dispatch below)
       switch (variant) {
         case 1: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 64, 2, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;
         case 2: launch_h16<bf16_t, EPI, 128, 128, 2, 2, 32, 4, 8>(A, lda, B, ldb, M, N, K, e, splitk, s); break;

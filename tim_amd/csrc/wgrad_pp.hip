@@ -12,13 +12,17 @@
 //     64 rows per stage as three 16-KiB sub-tiles [64][128 columns] (dY, X left half, X right half), by global_load_lds into a
 //     3-stage ring (144 KiB); the MFMA fragments (8 consecutive m per lane) come out of two transposing reads each;
 //   * the two waves of a SIMD alternate LOAD (fragment reads) and MFMA phases as in gemm_pp.hip (waves 4-7 one barrier
-//     behind waves 0-3); every wave issues 3 of the stage's 48 DMA pieces between the MFMAs of each of its MFMA phases.
-//     That form is kept (MODE 0); the default (MODE 1) drops the phase barriers - one barrier per 64-row step is all the ring
-//     needs - and lets the hardware scheduler interleave the two waves of a SIMD: measured 217 vs 232 us for the C2a layer
-//     on one box (tools/wgpp_abl.py; the old two-blocks-per-CU kernel: 243).  The kernel stays bound by the LDS: its 256
-//     transposing reads per 64-row step cost ~4 LDS cycles each (half the bytes per instruction of ds_read_b128) - as long
-//     as the MFMAs of the step - and the stage's DMA writes share the same LDS.
-// Hazard bookkeeping of MODE 0: see gemm_pp.hip (identical phase structure).
+//     behind waves 0-3).
+// Four schedules of that tile exist (tools/wgpp_abl.py interleaves them on one box; C2a layer launch, us):
+//     MODE 0  a LOAD and an MFMA phase per 32-row half step, 3 DMA pieces between the MFMAs of each phase   196-213
+//     MODE 1  no phase barriers (one barrier per 64-row step), hardware interleaving of a SIMD's two waves  205-229
+//     MODE 2  ONE LOAD and ONE MFMA phase per 64-row step (32 reads / 32 MFMAs, two barriers instead of four) 187-207
+//     wgrad_ld_kernel  MODE 2's phases on 8 consumer waves + 4 loader waves that issue every DMA piece      156-159
+//   The last one is the default (1.05 PFLOP/s on the layer).  What it removes: a global_load_lds stalls the issuing wave
+//   for 60-180 cycles, and between a consumer's MFMAs that is matrix-pipe time - MODE 2 runs 134 us with its DMA pieces
+//   ablated, 187+ with them.  (Round-2 note, superseded: MODE 1 was measured ahead of MODE 0 on one box, 217 vs 232; with
+//   the modes interleaved in one process MODE 0 is ahead on every box tried.)
+// Hazard bookkeeping of MODES 0 / 2: see gemm_pp.hip (identical phase structure); of the loader form: at wl_consume below.
 #include <stdlib.h>
 
 #include "common.h"
@@ -169,6 +173,120 @@ __device__ __forceinline__ void wp_mainloop(const WpTile& a, int M, const char* 
   if constexpr (G == 0) wp_barrier();
 }
 
+// Merged-phase ping-pong (MODE 2): ONE LOAD phase (the 32 transposing reads of both 32-row halves, 64 fragment VGPRs) and ONE
+// MFMA phase (32 MFMAs, this wave's six DMA pieces of stage t + 2 between them) per 64-row step - two barriers per step
+// instead of four, phases long enough (512 matrix-pipe cycles) to carry an 8-wave barrier's ~150 cycles.  Same hazard
+// bookkeeping as gemm_pp.hip's loop (its header): G1 runs one barrier behind G0.
+// (Issuing the six pieces in the LOAD phase instead, right behind the fragment reads, measured 3-5 % slower: piece issue and
+// the transposing reads serialise.)
+template <typename HT, int G, int ABL = 0>
+__device__ __forceinline__ void wp_mainloop_merged(const WpTile& a, int M, const char* lds, uint32_t lds0, int wave, int lane,
+                                                   const int (&xoff)[4][2], const int (&yoff)[4][2], f32x4_t (&acc)[4][4],
+                                                   f32x4_t (&accb)[4], bool do_bias) {
+  const int nk = (M + WP_M - 1) / WP_M;
+  const bool partial = (M % WP_M) != 0;
+  const int lrow = lane >> 4, lc = lane & 15;
+  uint32_t off[6];
+  int prow[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int p = wave * 6 + i, sub = p >> 4, row = (p & 15) * 4 + lrow;
+    const int c = lc ^ swz<128>(row);
+    prow[i] = row;
+    if (sub == 0) off[i] = (uint32_t)(((size_t)row * a.ldy + min(a.n0 + c * 8, ((a.N + 7) & ~7) - 8)) * 2);
+    else off[i] = (uint32_t)(((size_t)row * a.ldx + min(a.k0 + (sub - 1) * 128 + c * 8, ((a.K + 7) & ~7) - 8)) * 2);
+  }
+  auto piece = [&](int kt, int slot, int i) {
+    const int p = wave * 6 + i;
+    const bool is_y = p < 16;
+    const char* g = (is_y ? a.dY : a.X) + (size_t)kt * WP_M * (is_y ? a.ldy : a.ldx) * 2;
+    const uint32_t dst = lds0 + slot * WP_STAGE + p * 1024;
+    if (partial && kt == nk - 1) {
+      const int over = max(kt * WP_M + prow[i] - (M - 1), 0);
+      glds16(g + off[i] - (size_t)over * (is_y ? a.ldy : a.ldx) * 2, dst);
+    } else {
+      glds16_s(uniform_ptr(g), off[i], dst);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 6; ++i) piece(0, 0, i);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) piece(1, 1, i);
+    glds_wait<6>();
+  } else {
+    glds_wait<0>();
+  }
+  wp_barrier();
+  if constexpr (G == 1) wp_barrier();
+
+  const int wk = wave & 3, gid = lane >> 4;
+  vec8<HT> xf[2][4], yf[2][4];
+  int slot = 0;
+  auto step = [&](int t, auto more_c) {
+    constexpr bool MORE = decltype(more_c)::value;
+    const char* sY = lds + slot * WP_STAGE;
+    const char* sX = sY + WP_SUB + (wk >> 1) * WP_SUB;
+    const int nslot = slot >= 1 ? slot - 1 : WP_NST - 1;
+    // ---- LOAD phase
+    if (!(ABL & 1) || t == 0) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int hb = half * (32 * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[half][i] = cat8<HT>(tr_read<HT>(sX + xoff[i][0] + hb), tr_read<HT>(sX + xoff[i][1] + hb));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yf[half][j] = cat8<HT>(tr_read<HT>(sY + yoff[j][0] + hb), tr_read<HT>(sY + yoff[j][1] + hb));
+      }
+    }
+    glds_wait<0>();   // this wave's pieces of stage t + 1 (issued in its previous MFMA phase) have landed
+    wp_wait_lds();
+    if (!MORE && partial && t == nk - 1) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int nvalid = M - (t * WP_M + half * 32 + 8 * gid);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (u >= nvalid) yf[half][j][u] = (HT)0.f;
+      }
+    }
+    wp_barrier();
+    // ---- MFMA phase
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!(ABL & 2)) acc[i][j] = mfma16x16<HT>(xf[half][i], yf[half][j], acc[i][j]);
+          else if (i == 0 && j == 0) acc[0][0][0] += (float)xf[half][0][0] * (float)yf[half][0][0];
+          const int q = half * 16 + i * 4 + j;
+          if (MORE && !(ABL & 4) && q % 5 == 2) {   // after MFMAs 2, 7, 12, 17, 22, 27
+            __builtin_amdgcn_sched_barrier(0);
+            piece(t + 2, nslot, q / 5);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    if (do_bias) {
+      vec8<HT> ones;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ones[u] = (HT)1.f;
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accb[j] = mfma16x16<HT>(ones, yf[half][j], accb[j]);
+    }
+    wp_barrier();
+    slot = slot + 1 == WP_NST ? 0 : slot + 1;
+  };
+  int t = 0;
+  for (; t + 2 < nk; ++t) step(t, std::true_type{});
+  for (; t < nk; ++t) step(t, std::false_type{});
+  if constexpr (G == 0) wp_barrier();
+}
+
 // Free-running form (MODE 1): no phase barriers.  The ring alone needs ONE barrier per 64-row step (3 slots: the barrier of
 // step t says "everybody's pieces of stage t have landed" and, by program order, "everybody is done reading stage t-1", whose
 // slot is refilled right after it); the two waves of a SIMD interleave through the hardware scheduler - a wave stalled on
@@ -261,7 +379,239 @@ __device__ __forceinline__ void wp_mainloop_free(const WpTile& a, int M, const c
   }
 }
 
-template <typename HT, int ABL = 0, int MODE = 1>
+// ---- loader-wave form (wgrad_ld_kernel, 12 waves) -----------------------------------------------------------------------
+// The same tile, ring and merged LOAD / MFMA phases, but the LDS-DMA pieces are issued by four extra waves (one per SIMD)
+// that do nothing else: a global_load_lds stalls its wave for 60-180 cycles at issue, and between a consumer's MFMAs that
+// stall is matrix-pipe time (tools/wgpp_abl.py: the merged loop runs 187 us with its pieces, 133 without).  The loaders also
+// take the bias gradient (column sums of dY by the ones-MFMA) off the consumers - 16 accumulator VGPRs less, which together
+// with XOR-derived fragment offsets brings the consumers under the 168 VGPRs three waves per SIMD may use.
+// Barriers b0, b1, ...: G0's LOAD(t) runs in window A_t = (b_2t, b_2t+1), its MFMA(t) in B_t = (b_2t+1, b_2t+2); G1 one
+// barrier later.  Loaders: pieces 0-7 of stage t+2 in A_t, 8-11 in B_t, into slot (t-1) % 3 - free since G1's reads of
+// stage t-1 were waited for before b_2t; "stage t+1 has landed" (vmcnt) before b_2t+1, two barriers before its first reader.
+template <typename HT, int G, int ABL>
+__device__ __forceinline__ void wl_consume(const char* lds, int M, int wave, int lane, f32x4_t (&acc)[4][4]) {
+  const int nk = (M + WP_M - 1) / WP_M;
+  const bool partial = (M % WP_M) != 0;
+  const int wk = wave & 3, gid = lane >> 4, p = lane & 15;
+  // fragment offsets of MFMA tile 0 (rows r = 0, 1 of a fragment); tile i is at (offset ^ (i << 5)): the tile index sits in
+  // bits 1-2 of the 16-byte chunk number, which the swizzle only XORs
+  int xo[2], yo[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = 8 * gid + 4 * r + (p >> 2);
+    xo[r] = tile_off<128>(row, (wk & 1) * 8 + ((p & 3) >> 1)) + (p & 1) * 8;
+    yo[r] = tile_off<128>(row, G * 8 + ((p & 3) >> 1)) + (p & 1) * 8;
+  }
+  wp_barrier();                          // b0: stage 0 has landed
+  if constexpr (G == 1) wp_barrier();
+  vec8<HT> xf[2][4], yf[2][4];
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    const char* sY = lds + slot * WP_STAGE;
+    const char* sX = sY + WP_SUB + (wk >> 1) * WP_SUB;
+    if (!(ABL & 1) || t == 0) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int hb = half * (32 * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          xf[half][i] = cat8<HT>(tr_read<HT>(sX + (xo[0] ^ (i << 5)) + hb), tr_read<HT>(sX + (xo[1] ^ (i << 5)) + hb));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          yf[half][j] = cat8<HT>(tr_read<HT>(sY + (yo[0] ^ (j << 5)) + hb), tr_read<HT>(sY + (yo[1] ^ (j << 5)) + hb));
+      }
+    }
+    wp_wait_lds();
+    if (partial && t == nk - 1) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int nvalid = M - (t * WP_M + half * 32 + 8 * gid);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (u >= nvalid) yf[half][j][u] = (HT)0.f;
+      }
+    }
+    wp_barrier();
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!(ABL & 2)) acc[i][j] = mfma16x16<HT>(xf[half][i], yf[half][j], acc[i][j]);
+          else if (i == 0 && j == 0) acc[0][0][0] += (float)xf[half][0][0] * (float)yf[half][0][0];
+        }
+    wp_barrier();
+    slot = slot + 1 == WP_NST ? 0 : slot + 1;
+  }
+  if constexpr (G == 0) wp_barrier();
+}
+
+template <typename HT, int ABL>
+__device__ __forceinline__ void wl_load(const WpTile& a, int M, const char* lds, uint32_t lds0, int lw, int lane, bool do_bias,
+                                        f32x4_t (&accb)[2]) {
+  const int nk = (M + WP_M - 1) / WP_M;
+  const bool partial = (M % WP_M) != 0;
+  const int lrow = lane >> 4, lc = lane & 15;
+  // this wave's 12 DMA pieces (1 KiB = 4 rows x 256 B) of a stage: pieces 12 lw .. 12 lw + 11 of its 48 (16 per sub-tile);
+  // groups of four never straddle a sub-tile
+  uint32_t off[12];
+  int prow[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int pc = lw * 12 + i, sub = pc >> 4, row = (pc & 15) * 4 + lrow;
+    const int c = lc ^ swz<128>(row);
+    prow[i] = row;
+    if (sub == 0) off[i] = (uint32_t)(((size_t)row * a.ldy + min(a.n0 + c * 8, ((a.N + 7) & ~7) - 8)) * 2);
+    else off[i] = (uint32_t)(((size_t)row * a.ldx + min(a.k0 + (sub - 1) * 128 + c * 8, ((a.K + 7) & ~7) - 8)) * 2);
+  }
+  auto group = [&](int kt, int slot, int q) {   // pieces 4q .. 4q+3 of stage kt
+    const int p0 = lw * 12 + 4 * q;
+    const bool is_y = p0 < 16;
+    const char* g = (is_y ? a.dY : a.X) + (size_t)kt * WP_M * (is_y ? a.ldy : a.ldx) * 2;
+    const uint32_t dst = lds0 + slot * WP_STAGE + p0 * 1024;
+    if (partial && kt == nk - 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int over = max(kt * WP_M + prow[4 * q + u] - (M - 1), 0);
+        glds16(g + off[4 * q + u] - (size_t)over * (is_y ? a.ldy : a.ldx) * 2, dst + u * 1024);
+      }
+    } else {
+      glds16_x4(uniform_ptr(g), off[4 * q], off[4 * q + 1], off[4 * q + 2], off[4 * q + 3], dst);
+    }
+  };
+  group(0, 0, 0); group(0, 0, 1); group(0, 0, 2);
+  if (nk > 1) {
+    group(1, 1, 0); group(1, 1, 1); group(1, 1, 2);
+    glds_wait<12>();
+  } else {
+    glds_wait<0>();
+  }
+  wp_barrier();   // b0
+
+  const int gid = lane >> 4, p = lane & 15;
+  int yo[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) yo[r] = tile_off<128>(8 * gid + 4 * r + (p >> 2), lw * 4 + ((p & 3) >> 1)) + (p & 1) * 8;
+  vec8<HT> ones;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) ones[u] = (HT)1.f;
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    const int nslot = slot >= 1 ? slot - 1 : WP_NST - 1;
+    const bool more = t + 2 < nk && !(ABL & 4);
+    // ---- window A_t
+    if (more) {
+      group(t + 2, nslot, 0); group(t + 2, nslot, 1);
+      glds_wait<8>();
+    } else {
+      glds_wait<0>();
+    }
+    wp_barrier();   // b_2t+1
+    // ---- window B_t
+    if (more) group(t + 2, nslot, 2);
+    if (do_bias) {   // column sums of this wave's two 16-column tiles of dY, stage t: all-ones A fragment (every row of D)
+      const char* sY = lds + slot * WP_STAGE;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int hb = half * (32 * 256);
+        vec8<HT> yf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          yf[j] = cat8<HT>(tr_read<HT>(sY + (yo[0] ^ (j << 5)) + hb), tr_read<HT>(sY + (yo[1] ^ (j << 5)) + hb));
+        if (partial && t == nk - 1) {
+          const int nvalid = M - (t * WP_M + half * 32 + 8 * gid);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (u >= nvalid) yf[j][u] = (HT)0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accb[j] = mfma16x16<HT>(ones, yf[j], accb[j]);
+      }
+      wp_wait_lds();
+    }
+    wp_barrier();   // b_2t+2
+    slot = slot + 1 == WP_NST ? 0 : slot + 1;
+  }
+  wp_barrier();     // b_2nk+1
+}
+
+template <typename HT, int ABL = 0>
+__global__ __launch_bounds__(768) void wgrad_ld_kernel(const WpGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = xcd_remap_wp(blockIdx.x, gridDim.x);
+  WpTile a;
+  int tl = t, tiles_k = 1;
+  float* dW = nullptr;
+  float* db = nullptr;
+#pragma unroll
+  for (int i = 0; i < WP_MAX; ++i) {
+    if (i < g.n && t >= g.tile0[i]) {
+      a.dY = (const char*)g.dY[i]; a.X = (const char*)g.X[i]; a.ldy = g.ldy[i]; a.ldx = g.ldx[i]; a.N = g.N[i]; a.K = g.K[i];
+      tl = t - g.tile0[i]; tiles_k = (g.K[i] + WP_TK - 1) / WP_TK;
+      dW = g.dW[i]; db = g.db[i];
+    }
+  }
+  a.n0 = (tl / tiles_k) * WP_TN; a.k0 = (tl % tiles_k) * WP_TK;
+  const float alpha = g.out_scale ? *g.out_scale : 1.f;
+  const int gid = lane >> 4, p = lane & 15;
+
+  if (wave >= 8) {   // ---- loader waves
+    const int lw = wave - 8;
+    const bool do_bias = db != nullptr && a.k0 == 0;
+    f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    wl_load<HT, ABL>(a, g.M, lds, lds0, lw, lane, do_bias, accb);
+    if (do_bias && gid == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = a.n0 + (lw * 2 + j) * 16 + p;
+        if (n < a.N) { const float s = accb[j][0] * alpha; db[n] = g.accumulate ? db[n] + s : s; }
+      }
+    }
+    return;
+  }
+
+  const int wn = wave >> 2, wk = wave & 3;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (wn == 0) wl_consume<HT, 0, ABL>(lds, g.M, wave, lane, acc);
+  else wl_consume<HT, 1, ABL>(lds, g.M, wave, lane, acc);
+
+  const int N = a.N, K = a.K;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = a.n0 + wn * 64 + j * 16 + p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = a.k0 + wk * 64 + i * 16 + 4 * gid;
+      if (n < N && k < K) {
+        float v[4] = {acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha};
+        float* dst = dW + (size_t)n * K + k;
+        if (k + 3 < K && ((((size_t)n * K + k) & 3) == 0)) {
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (g.accumulate) { const float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+          *reinterpret_cast<float4*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k + u < K) dst[u] = g.accumulate ? dst[u] + v[u] : v[u];
+        }
+      }
+    }
+  }
+}
+
+template <typename HT, int ABL = 0, int MODE = 2>
 __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpGroup g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -307,6 +657,9 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpGroup g) {
 
   if constexpr (MODE == 1) {
     wp_mainloop_free<HT, ABL>(a, g.M, lds, lds0, wave, lane, xoff, yoff, acc, accb, do_bias);
+  } else if constexpr (MODE == 2) {
+    if (wn == 0) wp_mainloop_merged<HT, 0, ABL>(a, g.M, lds, lds0, wave, lane, xoff, yoff, acc, accb, do_bias);
+    else wp_mainloop_merged<HT, 1, ABL>(a, g.M, lds, lds0, wave, lane, xoff, yoff, acc, accb, do_bias);
   } else {
     if (wn == 0) wp_mainloop<HT, 0, ABL>(a, g.M, lds, lds0, wave, lane, xoff, yoff, acc, accb, do_bias);
     else wp_mainloop<HT, 1, ABL>(a, g.M, lds, lds0, wave, lane, xoff, yoff, acc, accb, do_bias);
@@ -379,18 +732,29 @@ int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int 
   const int hi = precision == TIMHIP_PREC_F16 ? 1 : 0;
   if (!attr_set[hi]) {
     DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_pp_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_ld_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     attr_set[hi] = true;
   }
+  // the 12-wave loader form is the default; TIMHIP_WGRAD_LD=0 selects the 8-wave merged-phase kernel (A/B switch)
+  const char* ldv = getenv("TIMHIP_WGRAD_LD");   // (read per call: tests switch it inside one process)
+  const bool ld_on = !(ldv && ldv[0] == '0');
 #ifdef TIMHIP_TUNING
   if (const char* v = getenv("TIMHIP_WGPP_ABL")) {
     const int abl = atoi(v);
-    const int mode = getenv("TIMHIP_WGPP_MODE") ? atoi(getenv("TIMHIP_WGPP_MODE")) : 1;
+    const int mode = getenv("TIMHIP_WGPP_MODE") ? atoi(getenv("TIMHIP_WGPP_MODE")) : 4;
 #define WABL(X, MD) case X + 8 * MD: (void)hipFuncSetAttribute((const void*)wgrad_pp_kernel<f16_t, X, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
     hipLaunchKernelGGL((wgrad_pp_kernel<f16_t, X, MD>), dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g); return TIMHIP_OK;
-    switch (abl + 8 * mode) { WABL(0, 0) WABL(1, 0) WABL(2, 0) WABL(4, 0) WABL(6, 0) WABL(7, 0) WABL(0, 1) WABL(2, 1) WABL(4, 1) WABL(6, 1) default: break; }
+#define WLD(X) case X + 8 * 4: (void)hipFuncSetAttribute((const void*)wgrad_ld_kernel<f16_t, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((wgrad_ld_kernel<f16_t, X>), dim3((unsigned)g.tile0[n]), dim3(768), shmem, s, g); return TIMHIP_OK;
+    switch (abl + 8 * mode) { WLD(0) WLD(1) WLD(2) WLD(4) WLD(6) WABL(0, 0) WABL(1, 0) WABL(2, 0) WABL(4, 0) WABL(6, 0) WABL(7, 0) WABL(0, 1) WABL(2, 1) WABL(4, 1) WABL(6, 1) WABL(0, 2) WABL(1, 2) WABL(2, 2) WABL(4, 2) WABL(6, 2) default: break; }
 #undef WABL
+#undef WLD
   }
 #endif
-  DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_pp_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
+  if (ld_on) {
+    DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_ld_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(768), shmem, s, g));
+  } else {
+    DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_pp_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
+  }
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }

@@ -67,9 +67,12 @@ class Runtime:
         # fp32 value as hi + lo fp16 column blocks, one fp16 GEMM over the tripled contraction length (timhip_split3_many).
         self.split = precision == "fp16"
         self._wsplit = {}
+        self._wsparams = {}  # id(param) -> weakref: every weight this runtime has split
         # fp16 backward: gradient operands are stored times a power of two chosen per backward pass from the incoming
-        # cotangents (timhip_grad_scale): S * max|cotangent| ~ grad_scale_target
-        self.grad_scale_target = 64.0
+        # cotangents (timhip_grad_scale): S * max|cotangent| ~ grad_scale_target.  16 leaves a factor 4096 of headroom below
+        # the fp16 maximum for gradients that grow along the backward chain (LayerNorm's 1/std) and 2^-18 of the largest
+        # cotangent before values go subnormal
+        self.grad_scale_target = 16.0
         self._wcache = {}
         self._wparams = {}  # id(param) -> weakref: every weight this runtime has cast
         # dropout stream: seeded from torch's generator (torch.manual_seed / args.seed select the run's masks, as they do in the
@@ -161,18 +164,39 @@ class Runtime:
             self._wcache.update(fresh)
 
     def weight_split(self, p):
-        """[N, 3 ru(K)] split copy [hi | hi | lo] of an fp32 weight [N, K] (split-operand sites of the fp16 mode)"""
+        """[N, 3 ru(K)] split copy [hi | hi | lo] of an fp32 weight [N, K] (split-operand sites of the fp16 mode).  As in
+        `weight`, one stale copy refreshes every stale split copy this runtime holds in the same grouped launch."""
         ent = self._wsplit.get(id(p))
         ver = (p.data_ptr(), p._version)
         if ent is None or ent[0] != ver or ent[1].device != p.device:
-            N, K = p.shape
-            src = _f32c(p)
-            buf = ent[1] if ent is not None and ent[1].device == p.device else \
-                torch.empty((N, 3 * _ru(K)), dtype=self.op_dtype, device=p.device)
-            self.split3([(src, N, K, K, buf)], mode=1)
-            ent = (ver, buf, src)
-            self._wsplit[id(p)] = ent
+            self._wsparams[id(p)] = weakref.ref(p)
+            self._refresh_split(p.device)
+            ent = self._wsplit[id(p)]
         return ent[1]
+
+    def _refresh_split(self, dev):
+        items, fresh = [], {}
+        for key, ref in list(self._wsparams.items()):
+            q = ref()
+            if q is None:
+                self._wsparams.pop(key, None)
+                self._wsplit.pop(key, None)
+                continue
+            if q.device != dev:
+                continue
+            ent = self._wsplit.get(key)
+            ver = (q.data_ptr(), q._version)
+            if ent is not None and ent[0] == ver and ent[1].device == dev:
+                continue
+            N, K = q.shape
+            src = _f32c(q)
+            buf = ent[1] if ent is not None and ent[1].device == dev and ent[1].shape == (N, 3 * _ru(K)) else \
+                torch.empty((N, 3 * _ru(K)), dtype=self.op_dtype, device=dev)
+            items.append((src, N, K, K, buf))
+            fresh[key] = (ver, buf, src)
+        if items:
+            self.split3(items, mode=1)
+            self._wsplit.update(fresh)
 
     def split3(self, items, mode, relu=False):
         """items: [(src fp32 [rows, cols] with row stride lds, rows, cols, lds, dst [rows, 3 ru(cols)])]"""
