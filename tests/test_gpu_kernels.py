@@ -450,9 +450,12 @@ def test_fp16_scaled_gradient_operands():
 
 @pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("M,N,K", [(9920, 1024, 1024), (9920, 3072, 1024), (9920, 1024, 2048), (9925, 1000, 192), (3000, 2056, 64)])
-def test_gemm_pingpong_kernel(prec, M, N, K):
-    """gemm_pp.hip (one 8-wave block per CU, 160 x 256 tiles, three-stage LDS ring): every epilogue it carries, on the encoder
-    layer's shapes and on ragged edges (rows past M, columns past N, one / two / three contraction steps), against fp64"""
+@pytest.mark.parametrize("loaders", [False, True])
+def test_gemm_pingpong_kernel(prec, M, N, K, loaders, monkeypatch):
+    """gemm_pp.hip (one block per CU, 160 x 256 tiles, three-stage LDS ring; 8 waves, or 8 + 4 DMA loader waves): every epilogue
+    it carries, on the encoder layer's shapes and on ragged edges (rows past M, columns past N, one / two / three contraction
+    steps), against fp64"""
+    monkeypatch.setenv("TIMHIP_GEMM_LD", "1" if loaders else "0")
     rt = Runtime(prec)
     A, Ar = to_op(rt, rnd(M, K, seed=1))
     B, Br = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))

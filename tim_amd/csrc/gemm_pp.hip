@@ -41,7 +41,9 @@ __device__ __forceinline__ void pp_barrier() {
 __device__ __forceinline__ void pp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---- epilogue: one wave's TMW x 4 accumulator tiles (16 x 16 each, D[n][m] orientation) ------------------------------------
-template <typename HT, int EPI, int TMW>
+// PFD: how many row blocks ahead the fp32 residual (+ LayerNorm statistics) is fetched.  TMW = everything before the first
+// store (8-wave kernel, 256 VGPRs per wave); 2 = a two-deep ring refilled after each block's stores (12-wave kernel, 168 VGPRs).
+template <typename HT, int EPI, int TMW, int PFD = TMW>
 __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc)[PP_TNW][TMW], int mw0, int nw0, int M, int N,
                                             float* ep, int lane) {
   constexpr int EP_COLS = 64, EP_LD = EP_COLS + 4, CPR = EP_COLS / 4, OPR = EP_COLS / 8, RBS = 16;
@@ -65,13 +67,13 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
   // a load placed after a store cannot be hoisted above it (possible aliasing) and would cost a memory latency per chunk
   constexpr bool PRE_RES = (EPI == TIMHIP_EPI_DROP_RES_F32 || EPI == TIMHIP_EPI_ADD_F32);
   constexpr bool PRE_AUX = (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_MULAUX_T);
-  float4 rbuf[TMW][PRE_RES ? NITQ : 1];
-  float2 sbuf[TMW][PRE_RES ? NITQ : 1];
+  float4 rbuf[PFD][PRE_RES ? NITQ : 1];
+  float2 sbuf[PFD][PRE_RES ? NITQ : 1];
   vec8<HT> abuf[TMW][PRE_AUX ? NITO : 1];
   const bool pre_res = PRE_RES && e.vec && e.res != nullptr;
   const bool pre_ln = pre_res && EPI == TIMHIP_EPI_DROP_RES_F32 && e.ln_stats != nullptr;
   const bool pre_aux = PRE_AUX && e.vec8;
-  static_for<TMW>([&](auto jc) {
+  auto fetch_res = [&](auto jc) {   // row block j -> ring entry j % PFD
     constexpr int j = decltype(jc)::value;
     if constexpr (PRE_RES) {
       if (pre_res) {
@@ -79,12 +81,16 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
         for (int it = 0; it < NITQ; ++it) {
           const int idx = it * 64 + lane;
           const int m = mw0 + j * RBS + idx / CPR, n = nw0 + (idx % CPR) * 4;
-          rbuf[j][it] = (m < M && n + 3 < N) ? *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-          if (pre_ln) sbuf[j][it] = m < M ? *reinterpret_cast<const float2*>(e.ln_stats + 2 * (size_t)m) : make_float2(0.f, 1.f);
+          rbuf[j % PFD][it] = (m < M && n + 3 < N) ? *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pre_ln) sbuf[j % PFD][it] = m < M ? *reinterpret_cast<const float2*>(e.ln_stats + 2 * (size_t)m) : make_float2(0.f, 1.f);
         }
       }
     }
+  };
+  static_for<TMW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < PFD) fetch_res(jc);
     if constexpr (PRE_AUX) {
       if (pre_aux) {
 #pragma unroll
@@ -150,10 +156,11 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
         const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
         const int m = mw0 + j * RBS + row, n = nw0 + ch * 4;
         if (m < M && n < N)
-          epi_quad<EPI, HT>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j][PRE_RES ? it : 0], pre_b4 && n + 3 < N,
-                            bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j][PRE_RES ? it : 0], lng, lnb);
+          epi_quad<EPI, HT>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PFD][PRE_RES ? it : 0], pre_b4 && n + 3 < N,
+                            bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j % PFD][PRE_RES ? it : 0], lng, lnb);
       }
     }
+    if constexpr (j + PFD < TMW) fetch_res(std::integral_constant<int, j + PFD>{});   // refill this block's ring entry
     pp_wait_lds();   // reads done before the next row block overwrites the region
   });
 }
@@ -318,6 +325,127 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const HT* __restrict__ 
   }
 }
 
+// ---- loader-wave form (gemm_nt_ld_kernel, 12 waves): see wgrad_pp.hip (wl_consume / wl_load) for the barrier windows --------
+// Waves 0-7 keep the merged LOAD / MFMA phases without a single DMA instruction; waves 8-11 issue the stage's 52 pieces as 13
+// groups of four (A: groups 0-4, B: groups 5-12; loaders take 4 / 3 / 3 / 3 groups), two groups per wave in window A_t, the rest
+// in window B_t.
+template <typename HT, int TMW, int G>
+__device__ __forceinline__ void pl_consume(int nk, const char* lds, int a_frag, int b_frag, int c0, int c1, f32x4_t (&acc)[PP_TNW][TMW]) {
+  constexpr int BM = 32 * TMW;
+  constexpr int ST_BYTES = (BM + PP_BN) * PP_ROWB;
+  pp_barrier();                        // b0
+  if constexpr (G == 1) pp_barrier();
+  vec8<HT> xa[TMW], wb[PP_TNW], xb[TMW], wc[PP_TNW];
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    const char* base = lds + slot * ST_BYTES;
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c0);
+#pragma unroll
+    for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c0);
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) xb[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c1);
+#pragma unroll
+    for (int i = 0; i < PP_TNW; ++i) wc[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c1);
+    pp_wait_lds();
+    pp_barrier();
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int j = 0; j < TMW; ++j)
+#pragma unroll
+        for (int i = 0; i < PP_TNW; ++i)
+          acc[i][j] = half == 0 ? mfma16x16<HT>(wb[i], xa[j], acc[i][j]) : mfma16x16<HT>(wc[i], xb[j], acc[i][j]);
+    pp_barrier();
+    slot = slot + 1 == PP_NST ? 0 : slot + 1;
+  }
+  if constexpr (G == 0) pp_barrier();
+}
+
+template <typename HT, int TMW>
+__device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb, int M, int N, int m0, int n0,
+                                        int nk, uint32_t lds0, int lw, int lane) {
+  constexpr int BM = 32 * TMW, A_GROUPS = BM / 32;
+  constexpr int ST_BYTES = (BM + PP_BN) * PP_ROWB;
+  static_assert(A_GROUPS == 5, "group table written for the 160 x 256 tile");
+  const int g0 = lw == 0 ? 0 : 1 + 3 * lw, ng = lw == 0 ? 4 : 3;   // groups 0-3 | 4-6 | 7-9 | 10-12
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  uint32_t off[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = g0 * 4 + i;
+    const bool is_a = p < BM / 8;
+    const int row = (is_a ? p : p - BM / 8) * 8 + lrow;
+    const int c = (lchunk ^ kswz<64>(row)) * 8;
+    off[i] = is_a ? (uint32_t)(((size_t)min(m0 + row, M - 1) * lda + c) * 2) : (uint32_t)(((size_t)min(n0 + min(row, PP_BN - 1), N - 1) * ldb + c) * 2);
+  }
+  auto group = [&](int kt, int slot, int q) {   // this wave's q-th group of stage kt
+    if (q >= ng) return;
+    const int gq = g0 + q;
+    const char* g = reinterpret_cast<const char*>(gq < A_GROUPS ? (const void*)A : (const void*)B) + (size_t)kt * PP_ROWB;
+    glds16_x4(uniform_ptr(g), off[4 * q], off[4 * q + 1], off[4 * q + 2], off[4 * q + 3], lds0 + slot * ST_BYTES + gq * 4096);
+  };
+  group(0, 0, 0); group(0, 0, 1); group(0, 0, 2); group(0, 0, 3);
+  if (nk > 1) {
+    group(1, 1, 0); group(1, 1, 1); group(1, 1, 2); group(1, 1, 3);
+    if (lw == 0) glds_wait<16>(); else glds_wait<12>();
+  } else {
+    glds_wait<0>();
+  }
+  pp_barrier();   // b0
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    const int nslot = slot >= 1 ? slot - 1 : PP_NST - 1;
+    const bool more = t + 2 < nk;
+    if (more) {            // window A_t
+      group(t + 2, nslot, 0); group(t + 2, nslot, 1);
+      glds_wait<8>();      // stage t + 1 (issued one step earlier) has landed
+    } else {
+      glds_wait<0>();
+    }
+    pp_barrier();          // b_2t+1
+    if (more) { group(t + 2, nslot, 2); group(t + 2, nslot, 3); }   // window B_t
+    pp_barrier();          // b_2t+2
+    slot = slot + 1 == PP_NST ? 0 : slot + 1;
+  }
+  pp_barrier();            // b_2nk+1
+}
+
+template <typename HT, int EPI, int TMW>
+__global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                         int M, int N, int K, EpiDev e) {
+  constexpr int BM = 32 * TMW;
+  constexpr int A_BYTES = BM * PP_ROWB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (N + PP_BN - 1) / PP_BN, tiles_m = (M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * PP_BN;
+  const int nk = K / 64;
+  if (wave >= 8) {
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    pl_load<HT, TMW>(A, lda, B, ldb, M, N, m0, n0, nk, lds0, wave - 8, lane);
+    __syncthreads();
+    return;
+  }
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+  const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
+  const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
+  f32x4_t acc[PP_TNW][TMW];
+#pragma unroll
+  for (int i = 0; i < PP_TNW; ++i)
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (wm == 0) pl_consume<HT, TMW, 0>(nk, lds, a_frag, b_frag, c0, c1, acc);
+  else pl_consume<HT, TMW, 1>(nk, lds, a_frag, b_frag, c0, c1, acc);
+  __syncthreads();   // every wave is done with the stage ring: it becomes the epilogue's transposition space
+  float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
+  pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
+}
+
 template <typename HT, int EPI>
 void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, hipStream_t s) {
   constexpr int TMW = 5, BM = 32 * TMW;
@@ -335,9 +463,15 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
   static bool attr_set = false;   // idempotent; a benign race sets it twice at worst
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
   const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
+  const char* ldv = getenv("TIMHIP_GEMM_LD");
+  if (ldv && ldv[0] == '1') {
+    hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+    return;
+  }
   hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
 }
 

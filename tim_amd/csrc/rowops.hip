@@ -741,20 +741,39 @@ struct Split3Many {
   int mode, relu;
 };
 template <typename T>
-__global__ void split3_kernel(Split3Many sm) {
-  const int i = blockIdx.z, r = blockIdx.y;
-  if (r >= sm.rows[i]) return;
-  const int cols = sm.cols[i], cp = sm.ldd[i] / 3;
-  const float* src = sm.src[i] + (size_t)r * sm.lds[i];
-  T* dst = (T*)sm.dst[i] + (size_t)r * sm.ldd[i];
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cp; c += gridDim.x * blockDim.x) {
-    float v = c < cols ? src[c] : 0.f;
-    if (sm.relu) v = fmaxf(v, 0.f);
-    const T hi = OpT<T>::from_f(v);
-    const T lo = OpT<T>::from_f(v - OpT<T>::to_f(hi));
-    dst[c] = hi;
-    dst[cp + c] = sm.mode == 0 ? lo : hi;
-    dst[2 * cp + c] = sm.mode == 0 ? hi : lo;
+__global__ __launch_bounds__(256) void split3_kernel(Split3Many sm) {
+  // one thread per 4 consecutive columns of a row (block width is a multiple of 64): a 16-byte load, three 8-byte stores
+  const int i = blockIdx.z;
+  const int cols = sm.cols[i], cp = sm.ldd[i] / 3, qpr = cp >> 2;
+  const long long nq = (long long)sm.rows[i] * qpr;
+  const bool vec = (sm.lds[i] & 3) == 0 && (((uintptr_t)sm.src[i]) & 15) == 0;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(q / qpr), c = (int)(q % qpr) * 4;
+    const float* src = sm.src[i] + (size_t)r * sm.lds[i] + c;
+    float v[4];
+    if (vec && c + 3 < cols) {
+      const float4 f = *reinterpret_cast<const float4*>(src);
+      v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = c + u < cols ? src[u] : 0.f;
+    }
+    float lo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (sm.relu) v[u] = fmaxf(v[u], 0.f);
+      const float h = OpT<T>::to_f(OpT<T>::from_f(v[u]));
+      lo[u] = v[u] - h;
+    }
+    T* dst = (T*)sm.dst[i] + (size_t)r * sm.ldd[i] + c;
+    store4<T>(dst, v[0], v[1], v[2], v[3]);
+    if (sm.mode == 0) {
+      store4<T>(dst + cp, lo[0], lo[1], lo[2], lo[3]);
+      store4<T>(dst + 2 * cp, v[0], v[1], v[2], v[3]);
+    } else {
+      store4<T>(dst + cp, v[0], v[1], v[2], v[3]);
+      store4<T>(dst + 2 * cp, lo[0], lo[1], lo[2], lo[3]);
+    }
   }
 }
 
@@ -787,18 +806,32 @@ struct GsList { const float* p[GS_MAX]; long long n[GS_MAX]; int count; };
 __global__ __launch_bounds__(256) void grad_scale_kernel(GsList gl, float target, float* __restrict__ out) {
   __shared__ float red[4];
   float m = 0.f;
-  for (int i = 0; i < gl.count; ++i) {
+  const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < GS_MAX; ++i) {   // (static indexing of the kernel-argument arrays)
+    if (i >= gl.count) break;
     const float* __restrict__ p = gl.p[i];
     const long long n = gl.n[i], n4 = n >> 2;
     const bool al = (((uintptr_t)p) & 15) == 0;
     if (al) {
-      for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long long)gridDim.x * blockDim.x) {
+      long long q = t0;
+      for (; q + 3 * stride < n4; q += 4 * stride) {   // four independent 16-byte loads in flight per lane
+        const float4 a = *reinterpret_cast<const float4*>(p + 4 * q);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4 * (q + stride));
+        const float4 c = *reinterpret_cast<const float4*>(p + 4 * (q + 2 * stride));
+        const float4 d = *reinterpret_cast<const float4*>(p + 4 * (q + 3 * stride));
+        const float ma = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+        const float mb = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)));
+        const float mc = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
+        const float md = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
+      }
+      for (; q < n4; q += stride) {
         const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
       }
     }
-    for (long long j = (al ? 4 * n4 : 0) + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long long)gridDim.x * blockDim.x)
-      m = fmaxf(m, fabsf(p[j]));
+    for (long long j = (al ? 4 * n4 : 0) + t0; j < n; j += stride) m = fmaxf(m, fabsf(p[j]));
   }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -1182,7 +1215,11 @@ int timhip_split3_many(int precision, int count, const float* const* src, const 
     if (on && rows[i] > maxr) maxr = rows[i];
     if (on && ldd[i] / 3 > maxc) maxc = ldd[i] / 3;
   }
-  dim3 grid((maxc + 255) / 256 > 8 ? 8 : (maxc + 255) / 256, maxr, count);
+  long long blocks = ((long long)maxr * (maxc / 4) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+  for (int i = 0; i < count; ++i)
+    if ((ldd[i] & 3) || (((uintptr_t)dst[i]) & 7)) return TIMHIP_EALIGN;
+  dim3 grid((unsigned)blocks, 1, count);
   DISPATCH_H16(precision, hipLaunchKernelGGL(split3_kernel<HT>, grid, dim3(256), 0, (hipStream_t)stream, sm));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
@@ -1213,7 +1250,7 @@ int timhip_grad_scale(const float* const* cot, const long long* counts, int n, f
     if (i < n && (!cot[i] || counts[i] < 0)) return TIMHIP_EINVAL;
     total += gl.n[i];
   }
-  long long blocks = (total / 4 + 255) / 256 / 4;   // ~4 float4 per thread: enough loads in flight to run at HBM rate
+  long long blocks = (total / 4 + 255) / 256 / 8;   // ~8 float4 per thread, four in flight at a time
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gl, target, out);
   TIM_CHECK_LAUNCH();
