@@ -20,7 +20,9 @@
 //     wgrad_ld_kernel  MODE 2's phases on 8 consumer waves + 4 loader waves that issue every DMA piece      156-159
 //   The last one is the default (1.05 PFLOP/s on the layer).  What it removes: a global_load_lds stalls the issuing wave
 //   for 60-180 cycles, and between a consumer's MFMAs that is matrix-pipe time - MODE 2 runs 134 us with its DMA pieces
-//   ablated, 187+ with them.  (Round-2 note, superseded: MODE 1 was measured ahead of MODE 0 on one box, 217 vs 232; with
+//   ablated, 187+ with them.  A further variant - FOUR consumer waves with 64 x 128 tiles (0.75 reads per MFMA, each wave
+//   overlapping its own reads with its own MFMAs) + four loaders, one barrier per step - measured 192-207 us: one wave per
+//   SIMD cannot keep the LDS busy (its reads + DMA alone, MFMAs ablated: 181 us against 129); not kept.  (Round-2 note, superseded: MODE 1 was measured ahead of MODE 0 on one box, 217 vs 232; with
 //   the modes interleaved in one process MODE 0 is ahead on every box tried.)
 // Hazard bookkeeping of MODES 0 / 2: see gemm_pp.hip (identical phase structure); of the loader form: at wl_consume below.
 #include <stdlib.h>
