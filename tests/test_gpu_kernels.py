@@ -274,6 +274,7 @@ def test_gemm_dropout_keep_bits(epi, M, N, prec):
     (155 * 8, [(256, 512), (512, 256), (256, 256), (768, 256)]),      # an encoder layer (E 256, FF 512): 48 tiles, split
     (9920, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # C2a: 512 tiles, no split, direct writes
     (4100, [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)]),  # same, ragged last step of 64 rows
+    (2100, [(2000, 1000), (1000, 2000), (3000, 1000)]),                # one-block-per-CU kernels with ragged n / k tiles and rows
 ])
 @pytest.mark.parametrize("loaders", [True, False])
 def test_wgrad_group(M, shapes, accumulate, prec, loaders, monkeypatch):

@@ -814,19 +814,18 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(GsList gl, float target
     const long long n = gl.n[i], n4 = n >> 2;
     const bool al = (((uintptr_t)p) & 15) == 0;
     if (al) {
-      long long q = t0;
-      for (; q + 3 * stride < n4; q += 4 * stride) {   // four independent 16-byte loads in flight per lane
-        const float4 a = *reinterpret_cast<const float4*>(p + 4 * q);
-        const float4 b = *reinterpret_cast<const float4*>(p + 4 * (q + stride));
-        const float4 c = *reinterpret_cast<const float4*>(p + 4 * (q + 2 * stride));
-        const float4 d = *reinterpret_cast<const float4*>(p + 4 * (q + 3 * stride));
+      // a block takes chunks of 1024 float4 (16 KiB): every lane has four 16-byte loads in flight whatever the tensor's size
+      const long long nchunk = n4 >> 10;
+      for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+        const float4* q = reinterpret_cast<const float4*>(p) + (ch << 10) + threadIdx.x;
+        const float4 a = q[0], b = q[256], c = q[512], d = q[768];
         const float ma = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
         const float mb = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)));
         const float mc = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
         const float md = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
         m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
       }
-      for (; q < n4; q += stride) {
+      for (long long q = (nchunk << 10) + t0; q < n4; q += stride) {
         const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
       }
@@ -1250,7 +1249,7 @@ int timhip_grad_scale(const float* const* cot, const long long* counts, int n, f
     if (i < n && (!cot[i] || counts[i] < 0)) return TIMHIP_EINVAL;
     total += gl.n[i];
   }
-  long long blocks = (total / 4 + 255) / 256 / 8;   // ~8 float4 per thread, four in flight at a time
+  long long blocks = (total / 4 + 1023) / 1024 / 2;   // ~two 16-KiB chunks per block
   blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
   hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gl, target, out);
   TIM_CHECK_LAUNCH();
