@@ -451,7 +451,7 @@ __device__ __forceinline__ void wl_consume(const char* lds, int M, int wave, int
   if constexpr (G == 0) wp_barrier();
 }
 
-template <typename HT, int ABL>
+template <typename HT, int ABL, int NA = 2>   // NA: how many of a wave's three piece groups go out in window A_t (0 / 1 / 3: within noise of 2 or slower)
 __device__ __forceinline__ void wl_load(const WpTile& a, int M, const char* lds, uint32_t lds0, int lw, int lane, bool do_bias,
                                         f32x4_t (&accb)[2]) {
   const int nk = (M + WP_M - 1) / WP_M;
@@ -506,14 +506,18 @@ __device__ __forceinline__ void wl_load(const WpTile& a, int M, const char* lds,
     const bool more = t + 2 < nk && !(ABL & 4);
     // ---- window A_t
     if (more) {
-      group(t + 2, nslot, 0); group(t + 2, nslot, 1);
-      glds_wait<8>();
+#pragma unroll
+      for (int q = 0; q < NA; ++q) group(t + 2, nslot, q);
+      glds_wait<4 * NA>();
     } else {
       glds_wait<0>();
     }
     wp_barrier();   // b_2t+1
     // ---- window B_t
-    if (more) group(t + 2, nslot, 2);
+    if (more) {
+#pragma unroll
+      for (int q = NA; q < 3; ++q) group(t + 2, nslot, q);
+    }
     if (do_bias) {   // column sums of this wave's two 16-column tiles of dY, stage t: all-ones A fragment (every row of D)
       const char* sY = lds + slot * WP_STAGE;
 #pragma unroll
@@ -542,7 +546,7 @@ __device__ __forceinline__ void wl_load(const WpTile& a, int M, const char* lds,
   wp_barrier();     // b_2nk+1
 }
 
-template <typename HT, int ABL = 0>
+template <typename HT, int ABL = 0, int NA = 2>
 __global__ __launch_bounds__(768) void wgrad_ld_kernel(const WpGroup g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(768) void wgrad_ld_kernel(const WpGroup g) {
     const bool do_bias = db != nullptr && a.k0 == 0;
     f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-    wl_load<HT, ABL>(a, g.M, lds, lds0, lw, lane, do_bias, accb);
+    wl_load<HT, ABL, NA>(a, g.M, lds, lds0, lw, lane, do_bias, accb);
     if (do_bias && gid == 0) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
