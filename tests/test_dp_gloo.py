@@ -83,6 +83,12 @@ def _worker(rank, world, port, q):
         dist.broadcast(both, 0)
         assert torch.equal(both, got)          # every rank ends with the SAME gradients (all-gather of the reduced shards)
         assert dp.bytes_on_wire > 0
+        # TIM_AMD_DP_COLLECTIVE=allreduce: the plain fp32 all-reduce path gives the exact mean
+        os.environ["TIM_AMD_DP_COLLECTIVE"] = "allreduce"
+        z = x.clone()
+        dp._exchange(z)
+        assert torch.allclose(z, exact, rtol=1e-6, atol=1e-9)
+        del os.environ["TIM_AMD_DP_COLLECTIVE"]
         # no_sync(): gradients stay local
         with dp.no_sync():
             y = torch.full((64,), float(rank + 1))

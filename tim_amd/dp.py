@@ -27,6 +27,7 @@ Like DistributedDataParallel, construction broadcasts rank 0's parameters and bu
 that were seeded or loaded differently start from the same weights.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -119,6 +120,12 @@ class DataParallel(nn.Module):
     def _exchange(self, flat):
         """flat (fp32, 1-D) <- mean over ranks, via all-to-all + fp32 sum + all-gather on `wire_dtype`"""
         W, n = self.world, flat.numel()
+        if os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") == "allreduce":
+            # plain fp32 ring all-reduce (A/B switch and a way out should a runtime mishandle the all-to-all)
+            dist.all_reduce(flat, group=self.pg)
+            flat.mul_(1.0 / W)
+            self.bytes_on_wire += 2 * 2 * (n // W) * (W - 1) * 4
+            return
         st = self._staging(n, flat.device)
         per = st["per"]
         st["send"][:n].copy_(flat)                                             # 1. narrow
