@@ -384,6 +384,17 @@ def test_attention_dropout(prec):
     _attn_case(prec, 2, 40, 24, 2, 64, p=0.25)
 
 
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("B,S,F,H,Dh,p", [(3, 155, 100, 2, 128, 0.1), (2, 125, 100, 1, 128, 0.0), (1, 160, 128, 2, 128, 0.1),
+                                          (2, 192, 97, 1, 128, 0.0)])
+def test_attention_backward_fused_and_two_kernel(prec, fused, B, S, F, H, Dh, p, monkeypatch):
+    """the production-shape backward in both forms: rows + keys kernels with the dS / P~ scratch (TIMHIP_ATTN_FUSED=0) and the
+    one-kernel form that keeps dS / P~ in LDS (128-wide heads, 97..128 feature keys, S <= 192); with attention dropout"""
+    monkeypatch.setenv("TIMHIP_ATTN_FUSED", fused)
+    _attn_case(prec, B, S, F, H, Dh, p=p)
+
+
 def test_dropout_mask_statistics_and_determinism():
     for p in (0.1, 0.5):
         m1 = torch.empty((257, 1024), dtype=torch.uint8, device=DEV)

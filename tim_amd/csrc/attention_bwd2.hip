@@ -8,6 +8,8 @@
 //                    transposed by ds_read_b64_tr_b16 (same scheme as wgrad.hip).
 // Compared with the single-kernel version (attn_bwd_mfma) nothing is recomputed in the transposed orientation:
 // no second exp / Philox pass, and the row kernel runs one wave per row block.
+#include <stdlib.h>
+
 #include "common.h"
 #include "mfma_tiles.h"
 
@@ -36,15 +38,24 @@ __device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int
   return c == 0 ? k[0] : (c == 1 ? k[1] : (c == 2 ? k[2] : k[3]));
 }
 
-template <typename HT, int DH, int NJB>
+// FUSED (DH = 128, FP = 128, S <= 192): dS and P~ of the (window, head) stay in LDS ([S rounded up to 32][128 keys] each,
+// 80 KB at S = 155) and the block computes dK / dV of its feature keys itself after its row blocks are done (phase 2: the
+// key-side TN product of attn_bwd_keys on the block's own tiles, Q and dO staged over the K / V space) - no scratch round
+// trip through HBM (41 MB written and read back per layer at C2a), no second launch.  (Measured alternative: the three waves
+// without a row block prefetching Q / dO into registers during phase 1 - slower, 81 vs 74 us: their loads compete with the
+// K / V staging and the row blocks' own operand loads at the start of the block.)
+template <typename HT, int DH, int NJB, bool FUSED = false>
 __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv, const HT* __restrict__ o,
                                                      const float* __restrict__ lse, const HT* __restrict__ d_o,
                                                      HT* __restrict__ dqkv, HT* __restrict__ dS_scr,
                                                      HT* __restrict__ Pt_scr, AttnArgsM a) {
   constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
+  static_assert(!FUSED || (DH == 128 && FP == 128), "the fused form is written for 128 x 128 tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = sK + FP * DH * 2;
+  char* sS = sV + FP * DH * 2;                          // FUSED: dS  [SP][FP]
+  char* sP = sS + ((a.S + 31) & ~31) * FP * 2;          // FUSED: P~  [SP][FP]
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int S = a.S, F = a.F, E = a.E;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -147,7 +158,15 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
                       sc[8 * p2 + 6], sc[8 * p2 + 7], g);
         pair_exchange(vp, dp[8 * p2], dp[8 * p2 + 1], dp[8 * p2 + 2], dp[8 * p2 + 3], dp[8 * p2 + 4], dp[8 * p2 + 5],
                       dp[8 * p2 + 6], dp[8 * p2 + 7], g);
-        if (valid && !ATT_ABL(a, 1)) {
+        if constexpr (FUSED) {
+          if (!valid) {   // padded rows of the last row block contribute nothing to dK / dV
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { vs[u] = 0.f; vp[u] = 0.f; }
+          }
+          const int to = tile_off<128>(row, jb * 4 + 2 * p2 + g);
+          store8_h<HT>(reinterpret_cast<HT*>(sS + to), vs);
+          store8_h<HT>(reinterpret_cast<HT*>(sP + to), vp);
+        } else if (valid && !ATT_ABL(a, 1)) {
           const size_t so = (size_t)row * FP + jb * 32 + 16 * p2 + 8 * g;
           store8_h<HT>(dSs + so, vs);
           store8_h<HT>(Pts + so, vp);
@@ -196,6 +215,95 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
     }
   }
 
+  if constexpr (FUSED) {
+    // ---------------- phase 2: dK = dS^T Q, dV = P~^T dO for the F feature keys ----------------
+    // out[key][dh] = sum_row Y[row][key] X[row][dh]; wave w: dh block w & 3 (32 columns), key half w >> 2 (two 32-key blocks)
+    const int SP = (S + 31) & ~31;
+    const int gid = lane >> 4, p = lane & 15, g2 = gid >> 1;
+    const int row0 = 4 * g2 + (p >> 2);
+    const int wi = wave & 3, wj = wave >> 2;
+    int xtr[2], ytr[2][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      xtr[hh] = tile_off<128>(row0 + 8 * hh, 4 * wi + 2 * (gid & 1) + ((p & 3) >> 1)) + (p & 1) * 8;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        ytr[j][hh] = tile_off<128>(row0 + 8 * hh, 4 * (2 * wj + j) + 2 * (gid & 1) + ((p & 3) >> 1)) + (p & 1) * 8;
+    }
+    char* sX = smem;   // [SP][128] over the K / V tiles (SP * 256 B <= 64 KB for SP <= 256)
+    // X rows travel global -> registers -> LDS in two steps so that a tile's load latency sits under something else: Q's under
+    // the wait for the block's slowest row-block wave, dO's under the dK product
+    constexpr int XU = 6;   // 16-byte chunks per thread: SP * 16 / 512 <= 6 for SP <= 192
+    vec8<HT> xr[XU];
+    auto x_load = [&](const HT* src, size_t lds_) {
+#pragma unroll
+      for (int u = 0; u < XU; ++u) {
+        const int idx = tid + u * 512, row = idx >> 4, c = idx & 15;
+        if (idx < SP * 16 && row < S) xr[u] = *reinterpret_cast<const vec8<HT>*>(src + (size_t)row * lds_ + c * 8);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xr[u][e] = (HT)0.f;
+        }
+      }
+    };
+    auto x_store = [&]() {
+#pragma unroll
+      for (int u = 0; u < XU; ++u) {
+        const int idx = tid + u * 512;
+        if (idx < SP * 16) *reinterpret_cast<vec8<HT>*>(sX + tile_off<128>(idx >> 4, idx & 15)) = xr[u];
+      }
+    };
+    x_load(base, ld);
+#pragma unroll
+    for (int prod = 0; prod < 2; ++prod) {
+      __syncthreads();   // phase 1 (prod 0) / the previous product's fragment reads (prod 1) are done with this space
+      x_store();
+      if (prod == 0) x_load(dobase, (size_t)E);
+      __syncthreads();
+      const char* sY = prod ? sP : sS;
+      // two accumulator sets (even / odd 16-row steps: SP / 16 is even) - four independent MFMA chains per wave, and the
+      // fragments of both steps of a pair are requested before the first MFMA
+      f32x16_t acc[2], acc2[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc2[j][r] = 0.f; }
+      {
+        for (int ms = 0; ms < SP / 16; ms += 2) {
+          const vec8<HT> xf = cat8<HT>(tr_read<HT>(sX + xtr[0] + ms * 4096), tr_read<HT>(sX + xtr[1] + ms * 4096));
+          const vec8<HT> xg = cat8<HT>(tr_read<HT>(sX + xtr[0] + ms * 4096 + 4096), tr_read<HT>(sX + xtr[1] + ms * 4096 + 4096));
+          vec8<HT> yf[2], yg[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            yf[j] = cat8<HT>(tr_read<HT>(sY + ytr[j][0] + ms * 4096), tr_read<HT>(sY + ytr[j][1] + ms * 4096));
+            yg[j] = cat8<HT>(tr_read<HT>(sY + ytr[j][0] + ms * 4096 + 4096), tr_read<HT>(sY + ytr[j][1] + ms * 4096 + 4096));
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[j] = mfma16<HT>(xf, yf[j], acc[j]);
+            acc2[j] = mfma16<HT>(xg, yg[j], acc2[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] += acc2[j][r];
+        HT* out = dbase + (prod ? 2 * E : E);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = (2 * wj + j) * 32 + li;
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            float v[8];
+            pair_exchange(v, acc[j][8 * p2], acc[j][8 * p2 + 1], acc[j][8 * p2 + 2], acc[j][8 * p2 + 3], acc[j][8 * p2 + 4],
+                          acc[j][8 * p2 + 5], acc[j][8 * p2 + 6], acc[j][8 * p2 + 7], g);
+            const int k = wi * 32 + 16 * p2 + 8 * g;
+            if (n < F) store8_h<HT>(out + (size_t)n * ld + k, v);
+          }
+        }
+      }
+    }
+  }
 }
 
 // dK / dV of the feature keys: out[key][dh] = sum_row Y[row][key] X[row][dh]
@@ -336,6 +444,24 @@ AttnArgsM make_args2(const TimDesc& d) {
 
 static inline int rows_waves(int S) { const int n = (S + 31) / 32; return n < 1 ? 1 : (n > 8 ? 8 : n); }
 
+// fused form: DH = 128, 97..128 feature keys, K / V / dS / P~ within the 160 KB of LDS (S <= 192)
+static inline bool fused_fits(const TimDesc& d) {
+  const char* v = getenv("TIMHIP_ATTN_FUSED");
+  if (v && v[0] == '0') return false;
+  const int SP = (d.S + 31) & ~31;
+  return d.E / d.H == 128 && (d.F + 31) / 32 == 4 && (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 <= 160 * 1024;
+}
+
+template <typename HT>
+int launch_bwd_fused(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, hipStream_t s) {
+  const int SP = (d.S + 31) & ~31;
+  const size_t lds = (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2;
+  (void)hipFuncSetAttribute((const void*)attn_bwd_rows<HT, 128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_rows<HT, 128, 4, true>), dim3(d.B * d.H), dim3(512), lds, s, (const HT*)qkv, (const HT*)o, lse,
+                     (const HT*)d_o, (HT*)dqkv, (HT*)nullptr, (HT*)nullptr, make_args2(d));
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
+
 template <typename HT, int DH, int NJB>
 int launch_bwd2(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
                 void* ws, hipStream_t s) {
@@ -362,6 +488,7 @@ size_t tim_attention_bwd2_ws(const TimDesc& d) {
 int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                             void* dqkv, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!h16_storage(d.precision) || (d.E % 8) != 0 || d.B * d.H > 65535) return TIMHIP_EUNSUPPORTED;
+  if (fused_fits(d)) DISPATCH_H16(d.precision, return (launch_bwd_fused<HT>(d, qkv, o, lse, d_o, dqkv, s)));
   if (!ws || ws_bytes < tim_attention_bwd2_ws(d)) return TIMHIP_EUNSUPPORTED;
   const int DHv = d.E / d.H, NJBv = (d.F + 31) / 32;
 #define B2(DHc, NJBc) DISPATCH_H16(d.precision, return (launch_bwd2<HT, DHc, NJBc>(d, qkv, o, lse, d_o, dqkv, ws, s)))
