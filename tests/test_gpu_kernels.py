@@ -347,7 +347,7 @@ def _attn_case(prec, B, S, F, H, Dh, p=0.0, seed=11):
     torch.cuda.synchronize()
     mask = None
     if p > 0:
-        LP = (F + 1 + 3) // 4 * 4
+        LP = (F + 1 + 7) // 8 * 8     # row pitch of the probability dropout stream
         mk = torch.empty((B * H * S, LP), dtype=torch.uint8, device=DEV)
         L.call("timhip_dropout_mask", 99, 16 + 8 * 1 + 0, p, B * H * S, LP, L.ptr(mk), st())
         torch.cuda.synchronize()

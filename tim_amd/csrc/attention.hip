@@ -12,7 +12,7 @@
 namespace {
 
 struct AttnArgs {
-  int S, F, E, H, Dh, LP;  // LP = round_up(F + 1, 4): row pitch of the probability dropout stream
+  int S, F, E, H, Dh, LP;  // LP = round_up(F + 1, 8): row pitch of the probability dropout stream
   float scale;
   uint32_t thr; float dscale; TimSeed seed; uint32_t site;
 };
@@ -20,9 +20,7 @@ struct AttnArgs {
 __device__ __forceinline__ float attn_keep(const AttnArgs& a, int b, int h, int row, int j) {
   if (a.thr == 0u) return 1.f;
   const uint64_t base = (((uint64_t)b * a.H + h) * a.S + row) * (uint64_t)a.LP + (uint64_t)j;
-  Philox4 r = philox4x32_7(a.seed, a.site, base >> 2);
-  const uint32_t v = (base & 3) == 0 ? r.x : ((base & 3) == 1 ? r.y : ((base & 3) == 2 ? r.z : r.w));
-  return v >= a.thr ? a.dscale : 0.f;
+  return drop_mask1(a.seed, a.site, base, a.thr, a.dscale);
 }
 
 constexpr int KPL = 3;  // keys per lane: F <= 192
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_bwd_simple(const T* __restrict__ qkv
 
 AttnArgs make_args(const TimDesc& d) {
   AttnArgs a;
-  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.Dh = d.E / d.H; a.LP = round_up(d.F + 1, 4);
+  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.Dh = d.E / d.H; a.LP = round_up(d.F + 1, 8);
   a.scale = 1.f / sqrtf((float)a.Dh);
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;

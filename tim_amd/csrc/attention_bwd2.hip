@@ -44,6 +44,20 @@ __device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int
 // trip through HBM (41 MB written and read back per layer at C2a), no second launch.  (Measured alternative: the three waves
 // without a row block prefetching Q / dO into registers during phase 1 - slower, 81 vs 74 us: their loads compete with the
 // K / V staging and the row blocks' own operand loads at the start of the block.)
+// keep factors of one lane pair's 16 keys kb .. kb+15 (kb a multiple of 16, rowbase of 8): lane g owns keys kb + 8t + 4g .. +3
+// for t = 0, 1.  Counter t covers keys kb + 8t .. +7: lane g draws counter t = g and passes its partner (lane ^ 32) the half
+// that lane owns - one Philox call and two exchanges per lane instead of two calls (common.h: 16-bit draws)
+__device__ __forceinline__ void keep_pair(const AttnArgsM& a, uint64_t rowbase, int kb, int g, float (&k0)[4], float (&k1)[4]) {
+  const Philox4 r = philox4x32_7(a.seed, a.site, ((rowbase + (uint64_t)kb) >> 3) + (uint64_t)g);
+  const uint32_t s0 = g ? r.x : r.z, s1 = g ? r.y : r.w;
+  const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 32, 64), r1 = (uint32_t)__shfl_xor((int)s1, 32, 64);
+  float own[4], oth[4];
+  drop_mask4_words(g ? r.z : r.x, g ? r.w : r.y, a.thr, a.dscale, own[0], own[1], own[2], own[3]);
+  drop_mask4_words(r0, r1, a.thr, a.dscale, oth[0], oth[1], oth[2], oth[3]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { k0[u] = g ? oth[u] : own[u]; k1[u] = g ? own[u] : oth[u]; }
+}
+
 template <typename HT, int DH, int NJB, bool FUSED = false>
 __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv, const HT* __restrict__ o,
                                                      const float* __restrict__ lse, const HT* __restrict__ d_o,
@@ -138,17 +152,19 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
         dp = mfma16<HT>(vf, df[kk], dp);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float k[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.thr != 0u) keep4(a, rowbase, jb * 32 + 8 * q + 4 * g, k[0], k[1], k[2], k[3]);
+      for (int qp = 0; qp < 2; ++qp) {
+        float kk[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+        if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp, g, kk[0], kk[1]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int r = 4 * q + t;
-          const int key = jb * 32 + 8 * q + 4 * g + t;
-          const float p = key < F ? __expf(sc[r] * a.scale - l) : 0.f;
-          sc[r] = p * (dp[r] * k[t] - delta) * a.scale;
-          dp[r] = p * k[t];
-        }
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int q = 2 * qp + h2, r = 4 * q + t;
+            const int key = jb * 32 + 8 * q + 4 * g + t;
+            const float p = key < F ? __expf(sc[r] * a.scale - l) : 0.f;
+            sc[r] = p * (dp[r] * kk[h2][t] - delta) * a.scale;
+            dp[r] = p * kk[h2][t];
+          }
       }
       // hand dS and the dropped probabilities P~ to the key-side kernel (16-byte stores: pair_exchange)
 #pragma unroll
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys(const HT* __restrict__ dS_s
 
 AttnArgsM make_args2(const TimDesc& d) {
   AttnArgsM a;
-  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 4);
+  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 8);
   a.scale = 1.f / sqrtf((float)(d.E / d.H));
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;

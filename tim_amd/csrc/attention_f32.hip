@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_bwd_keys_f32(const float* __restrict
 
 AttnArgsF make_args_f(const TimDesc& d) {
   AttnArgsF a;
-  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 4);
+  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 8);
   a.scale = 1.f / sqrtf((float)(d.E / d.H));
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;

@@ -37,6 +37,20 @@ __device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int
   return c == 0 ? k[0] : (c == 1 ? k[1] : (c == 2 ? k[2] : k[3]));
 }
 
+// keep factors of one lane pair's 16 keys kb .. kb+15 (kb a multiple of 16, rowbase of 8): lane g owns keys kb + 8t + 4g .. +3
+// for t = 0, 1.  Counter t covers keys kb + 8t .. +7: lane g draws counter t = g and passes its partner (lane ^ 32) the half
+// that lane owns - one Philox call and two exchanges per lane instead of two calls (common.h: 16-bit draws)
+__device__ __forceinline__ void keep_pair(const AttnArgsM& a, uint64_t rowbase, int kb, int g, float (&k0)[4], float (&k1)[4]) {
+  const Philox4 r = philox4x32_7(a.seed, a.site, ((rowbase + (uint64_t)kb) >> 3) + (uint64_t)g);
+  const uint32_t s0 = g ? r.x : r.z, s1 = g ? r.y : r.w;
+  const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 32, 64), r1 = (uint32_t)__shfl_xor((int)s1, 32, 64);
+  float own[4], oth[4];
+  drop_mask4_words(g ? r.z : r.x, g ? r.w : r.y, a.thr, a.dscale, own[0], own[1], own[2], own[3]);
+  drop_mask4_words(r0, r1, a.thr, a.dscale, oth[0], oth[1], oth[2], oth[3]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { k0[u] = g ? oth[u] : own[u]; k1[u] = g ? own[u] : oth[u]; }
+}
+
 template <int C>
 __device__ __forceinline__ float quad_bcast(float v) {  // value of lane (lane & ~3) + C within each quad
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), C * 0x55, 0xF, 0xF, true));
@@ -142,14 +156,13 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
 #pragma unroll
     for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (a.thr != 0u) {
-          float k0, k1, k2, k3;
-          keep4(a, rowbase, jb * 32 + 8 * q + 4 * g, k0, k1, k2, k3);
-          sc[jb][4 * q] *= inv * k0; sc[jb][4 * q + 1] *= inv * k1;
-          sc[jb][4 * q + 2] *= inv * k2; sc[jb][4 * q + 3] *= inv * k3;
-        } else {
-          sc[jb][4 * q] *= inv; sc[jb][4 * q + 1] *= inv; sc[jb][4 * q + 2] *= inv; sc[jb][4 * q + 3] *= inv;
+      for (int qp = 0; qp < 2; ++qp) {
+        float ka[4] = {1.f, 1.f, 1.f, 1.f}, kb[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp, g, ka, kb);   // (both lanes of a pair take this branch)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          sc[jb][8 * qp + t] *= inv * ka[t];
+          sc[jb][8 * qp + 4 + t] *= inv * kb[t];
         }
       }
     float pself = pself_un * inv;
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const HT* __restrict__ qkv,
 
 AttnArgsM make_args(const TimDesc& d) {
   AttnArgsM a;
-  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 4);
+  a.S = d.S; a.F = d.F; a.E = d.E; a.H = d.H; a.LP = round_up(d.F + 1, 8);
   a.scale = 1.f / sqrtf((float)(d.E / d.H));
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;

@@ -150,26 +150,54 @@ __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
   return (uint32_t)t;
 }
 
-// masks of the 4 consecutive elements whose linear index is 4*q .. 4*q+3
+// Dropout decisions are 16-bit draws: ONE Philox call serves the 8 consecutive elements 8*c .. 8*c+7 (element e of the group
+// = bits 16*(e&1) .. +15 of word e>>1; kept iff that halfword >= thr >> 16).  Half the Philox work of 32-bit draws - it was
+// ~70 % of the attention kernels' VALU instructions and 8 us of LayerNorm-1 - at a drop probability quantised to 1/65536
+// (0.1 -> 0.09999).  Every kernel and timhip_dropout_mask derive their masks from these helpers, so forward, backward and the
+// tests' oracle agree by construction.
+//
+// masks of the 4 consecutive elements whose linear index is 4*q .. 4*q+3 (one half of counter q >> 1)
 __device__ __forceinline__ void drop_mask4(uint64_t seed, uint32_t site, uint64_t q, uint32_t thr,
                                            float scale, float& m0, float& m1, float& m2, float& m3) {
-  Philox4 r = philox4x32_7(seed, site, q);
-  m0 = r.x >= thr ? scale : 0.f;
-  m1 = r.y >= thr ? scale : 0.f;
-  m2 = r.z >= thr ? scale : 0.f;
-  m3 = r.w >= thr ? scale : 0.f;
+  const Philox4 r = philox4x32_7(seed, site, q >> 1);
+  const uint32_t a = (q & 1) ? r.z : r.x, b = (q & 1) ? r.w : r.y, t = thr >> 16;
+  m0 = (a & 0xffffu) >= t ? scale : 0.f;
+  m1 = (a >> 16) >= t ? scale : 0.f;
+  m2 = (b & 0xffffu) >= t ? scale : 0.f;
+  m3 = (b >> 16) >= t ? scale : 0.f;
+}
+// the same four factors from two words of a counter somebody else drew (lane pairs of the attention kernels share calls)
+__device__ __forceinline__ void drop_mask4_words(uint32_t a, uint32_t b, uint32_t thr, float scale, float& m0, float& m1,
+                                                 float& m2, float& m3) {
+  const uint32_t t = thr >> 16;
+  m0 = (a & 0xffffu) >= t ? scale : 0.f;
+  m1 = (a >> 16) >= t ? scale : 0.f;
+  m2 = (b & 0xffffu) >= t ? scale : 0.f;
+  m3 = (b >> 16) >= t ? scale : 0.f;
+}
+// factor of the single element with linear index idx
+__device__ __forceinline__ float drop_mask1(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thr, float scale) {
+  const Philox4 r = philox4x32_7(seed, site, idx >> 3);
+  const int e = (int)(idx & 7), wsel = e >> 1;
+  const uint32_t w = wsel == 0 ? r.x : (wsel == 1 ? r.y : (wsel == 2 ? r.z : r.w));
+  return ((w >> (16 * (e & 1))) & 0xffffu) >= (thr >> 16) ? scale : 0.f;
+}
+// keep-bits of the 8 consecutive elements 8*c .. 8*c+7 (bit e = element 8*c + e kept)
+__device__ __forceinline__ uint32_t drop_bits8(uint64_t seed, uint32_t site, uint64_t c, uint32_t thr) {
+  const Philox4 r = philox4x32_7(seed, site, c);
+  const uint32_t t = thr >> 16;
+  return ((r.x & 0xffffu) >= t ? 1u : 0u) | ((r.x >> 16) >= t ? 2u : 0u) | ((r.y & 0xffffu) >= t ? 4u : 0u) |
+         ((r.y >> 16) >= t ? 8u : 0u) | ((r.z & 0xffffu) >= t ? 16u : 0u) | ((r.z >> 16) >= t ? 32u : 0u) |
+         ((r.w & 0xffffu) >= t ? 64u : 0u) | ((r.w >> 16) >= t ? 128u : 0u);
 }
 
-// keep-bits of the 32 consecutive elements 4*q0 .. 4*q0+31 (bit i = element 4*q0 + i kept): the packed form of drop_mask4,
-// produced ahead of time by a memory-bound kernel with idle VALU (LayerNorm forward) for a GEMM epilogue that would
-// otherwise spend 15-18 us per launch drawing the same numbers while the matrix pipes wait
+// keep-bits of the 32 consecutive elements 4*q0 .. 4*q0+31 (q0 a multiple of 2; bit i = element 4*q0 + i kept): the packed
+// form of drop_mask4, produced ahead of time by a memory-bound kernel with idle VALU (LayerNorm forward) for a GEMM epilogue
+// that would otherwise spend 15-18 us per launch drawing the same numbers while the matrix pipes wait
 __device__ __forceinline__ uint32_t drop_bits32(uint64_t seed, uint32_t site, uint64_t q0, uint32_t thr) {
   uint32_t bits = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const Philox4 r = philox4x32_7(seed, site, q0 + j);
-    bits |= ((r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u)) << (4 * j);
-  }
+  for (int j = 0; j < 4; ++j) bits |= drop_bits8(seed, site, (q0 >> 1) + j, thr) << (8 * j);
   return bits;
 }
 // factors of 4 consecutive elements from their keep-bits (low 4 bits of `nib`)

@@ -232,14 +232,12 @@ __global__ void colsum_kernel(const T* __restrict__ src, int rows, int cols, int
 }
 
 __global__ void dropout_mask_kernel(TimSeed seed, uint32_t site, uint32_t thr, int rows, int cols, uint8_t* out) {
-  const int colsq = (cols + 3) >> 2;
-  const size_t total = (size_t)rows * colsq;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / colsq), q = (int)(i % colsq);
-    Philox4 p = philox4x32_7(seed, site, (uint64_t)r * colsq + q);
-    const uint32_t v[4] = {p.x, p.y, p.z, p.w};
-    for (int j = 0; j < 4; ++j)
-      if (q * 4 + j < cols) out[(size_t)r * cols + q * 4 + j] = v[j] >= thr ? 1 : 0;
+  // element (r, c) has linear index r * cols + c; one thread per 8 consecutive elements = one Philox call (common.h)
+  const size_t total = (size_t)rows * cols, groups = (total + 7) >> 3;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < groups; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t bits = drop_bits8(seed, site, i, thr);
+    for (int e = 0; e < 8; ++e)
+      if (8 * i + e < total) out[8 * i + e] = (bits >> e) & 1u;
   }
 }
 
