@@ -293,7 +293,9 @@ int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const
 int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const float* w,
                        const void* dh, int ld, float* dw, float* db, float* dt, const float* out_scale, void* stream);
 
-/* keep-mask (1/0 bytes) of a dropout site, as the kernels generate it: test hook */
+/* keep-mask (1/0 bytes) of a dropout site, as the kernels generate it: test hook.  Element (r, c) has linear index
+ * r * cols + c; one Philox-4x32-7 call (key = seed, stream = site, counter = index / 8) decides 8 consecutive elements by its
+ * eight 16-bit halves: kept iff halfword >= floor(p * 65536). */
 int timhip_dropout_mask(uint64_t seed, uint32_t site, float p, int rows, int cols, uint8_t* out,
                         void* stream);
 
