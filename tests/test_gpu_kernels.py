@@ -551,3 +551,15 @@ def test_split_operand_gemm(prec):
     assert torch.equal(hi, x.clamp(min=0).to(rt.op_dtype).float())
     assert torch.equal(A3[:, 2 * Kp:2 * Kp + K].float().cpu(), hi)
     assert (A3[:, K:Kp] == 0).all() and (A3[:, Kp + K:2 * Kp] == 0).all()
+    # unaligned source (row stride and width not multiples of 4): the element-wise path of the kernel, two items in one launch
+    wide = (rnd(37, 1010, seed=5) * 0.7).to(DEV)
+    src = wide[:, 3:1005]                       # 1002 columns, row stride 1010, base address 12 bytes off
+    A4 = torch.empty((37, 3 * Kp), dtype=rt.op_dtype, device=DEV)
+    A5 = torch.empty((M, 3 * Kp), dtype=rt.op_dtype, device=DEV)
+    rt.split3([(src, 37, 1002, 1010, A4), (xd, M, K, K, A5)], mode=0)
+    torch.cuda.synchronize()
+    hi4 = src.to(rt.op_dtype)
+    assert torch.equal(A4[:, :1002], hi4) and torch.equal(A4[:, 2 * Kp:2 * Kp + 1002], hi4)
+    assert torch.equal(A4[:, Kp:Kp + 1002], (src - hi4.float()).to(rt.op_dtype))
+    assert (A4[:, 1002:Kp] == 0).all()
+    assert torch.equal(A5[:, :K].float().cpu(), x.to(rt.op_dtype).float())
