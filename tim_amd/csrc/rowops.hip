@@ -393,7 +393,8 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
 // Backward.  A block owns ROWS_PB consecutive rows (one wave walks rows wave, wave+4, ...) and
 // reduces dgamma/dbeta over its rows in registers, then LDS across its 4 waves, then one atomic
 // per column per block.
-template <typename T, int LN_MAXV>
+// ACT0: the LayerNorm input is not an activation (act == 0, the encoder layers): no gelu' / relu' factors and their registers
+template <typename T, int LN_MAXV, bool ACT0 = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dx, int lddx,
                                                      const float* __restrict__ y, int ldy,
                                                      const float* __restrict__ stats, int rows, int cols, int act,
@@ -445,11 +446,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       const int c = (i * 64 + lane) * 4;
       if (i < nv && c < cols) {
         const float4 t = xh[i];
-        if (act != 0) ga[i] = make_float4(act_grad_f(act, t.x), act_grad_f(act, t.y), act_grad_f(act, t.z),
+        if (!ACT0 && act != 0) ga[i] = make_float4(act_grad_f(act, t.x), act_grad_f(act, t.y), act_grad_f(act, t.z),
                                           act_grad_f(act, t.w));
         float4 h;
-        h.x = (act_f(act, t.x) - mean) * rstd; h.y = (act_f(act, t.y) - mean) * rstd;
-        h.z = (act_f(act, t.z) - mean) * rstd; h.w = (act_f(act, t.w) - mean) * rstd;
+        if (ACT0) {
+          h.x = (t.x - mean) * rstd; h.y = (t.y - mean) * rstd; h.z = (t.z - mean) * rstd; h.w = (t.w - mean) * rstd;
+        } else {
+          h.x = (act_f(act, t.x) - mean) * rstd; h.y = (act_f(act, t.y) - mean) * rstd;
+          h.z = (act_f(act, t.z) - mean) * rstd; h.w = (act_f(act, t.w) - mean) * rstd;
+        }
         xh[i] = h;
         ag[i].x += d[i].x * h.x; ag[i].y += d[i].y * h.y; ag[i].z += d[i].z * h.z; ag[i].w += d[i].w * h.w;
         ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       if (i < nv && c < cols) {
         float o0 = rstd * (d[i].x - s1 - xh[i].x * s2), o1 = rstd * (d[i].y - s1 - xh[i].y * s2);
         float o2 = rstd * (d[i].z - s1 - xh[i].z * s2), o3 = rstd * (d[i].w - s1 - xh[i].w * s2);
-        if (act != 0) { o0 *= ga[i].x; o1 *= ga[i].y; o2 *= ga[i].z; o3 *= ga[i].w; }
+        if (!ACT0 && act != 0) { o0 *= ga[i].x; o1 *= ga[i].y; o2 *= ga[i].z; o3 *= ga[i].w; }
         if (dyf) store4<float>(dyf + (size_t)row * lddy + c, o0, o1, o2, o3);
         if (dyt) {
           float k0 = ts, k1 = ts, k2 = ts, k3 = ts;
@@ -1002,10 +1007,11 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
   return TIMHIP_OK;
 }
 
-// 16 rows per block, more when that would exceed the 512 co-resident blocks (2 per CU): one balanced round
+// 16 rows per block, more when that would exceed the 768 co-resident blocks (3 per CU at the 154 VGPRs of the encoder's
+// act == 0 kernel): one balanced round
 static int ln_bwd_rows_per_block(int rows) {
   int rpb = 16;
-  if (rows > 16 * 512) rpb = (((rows + 511) / 512) + 3) / 4 * 4;
+  if (rows > 16 * 768) rpb = (((rows + 767) / 768) + 3) / 4 * 4;
   return rpb;
 }
 
@@ -1026,7 +1032,14 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale)
   const int nv = (cols + 255) / 256;
-  DISPATCH_T(precision, if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4); else LN_BWD(8));
+#define LN_BWD0(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, true>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
+                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale)
+  if (act == 0 && nv == 4) {
+    DISPATCH_T(precision, LN_BWD0(4));
+  } else {
+    DISPATCH_T(precision, if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4); else LN_BWD(8));
+  }
+#undef LN_BWD0
 #undef LN_BWD
   TIM_CHECK_LAUNCH();
   if (partial_ws && (dgamma || dbeta) && !defer_colsum) {

@@ -43,3 +43,10 @@ t(fwd(0.0))
 print("reference points: fp32 -> fp16 cast of the same matrix (40 MB in, 20 MB out) %.1f us | torch fp32 copy (40 + 40 MB) %.1f us" % (t(cast), t(copy)))
 print("ln_fwd (operand copy + statistics, no keep-bits) %.1f us" % t(fwd(0.0)))
 print("ln_bwd  no mask %.1f us | with dropout mask %.1f us" % (t(bwd(0.0)), t(bwd(0.1))))
+def bwd_part(which):
+    def f(i):
+        y, dx, of, ot, st, mk = sets[i % 6]
+        call("timhip_layernorm_bwd", rt.prec, ptr(dx), E, ptr(y), E, ptr(st), M, E, 0, ptr(w), ptr(of) if which != "t" else None, E,
+             ptr(ot) if which != "f" else None, E, 0.0, 7, 17, ptr(dg), ptr(db), None, _stream())
+    return f
+print("ln_bwd  fp32 output only (80 MB in, 40 out) %.1f us | operand copy only (80 in, 20 out) %.1f us" % (t(bwd_part("f")), t(bwd_part("t"))))
