@@ -192,9 +192,15 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int co
   const int r = blockIdx.y;
   const float vs = vscale ? *vscale : 1.f;   // factor on the values (gradient scale of the fp16 mode)
   const int colsq = (cols + 3) >> 2;
+  const bool vec = (lds_ & 3) == 0 && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)dst) & 15) == 0);   // (ld % 4 == 0 always)
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < ld; q += gridDim.x * blockDim.x) {
     float k[4] = {1.f, 1.f, 1.f, 1.f};
     if (thr != 0u && q < colsq) drop_mask4(seed, site, (uint64_t)r * colsq + q, thr, scale, k[0], k[1], k[2], k[3]);
+    if (vec && q * 4 + 3 < cols) {   // 16-byte load, one 8- / 16-byte store
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * lds_ + q * 4);
+      store4<T>(dst + (size_t)r * ld + q * 4, v.x * k[0] * vs, v.y * k[1] * vs, v.z * k[2] * vs, v.w * k[3] * vs);
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = q * 4 + j;
