@@ -698,17 +698,27 @@ __global__ __launch_bounds__(128) void assemble_bwd_te_kernel(const TimSeqRow* _
                                                               float scale, TimSeed seed, uint32_t site,
                                                               float* __restrict__ d_te) {
   // block (t, y): time row t for the y-th share of the windows.  The token rows that read time row t (1 for features and audio
-  // queries, 3 for visual queries) are found ONCE per block - the table scan is 155 dependent scalar loads, which a block per
-  // (window, time row) repeated 8000 times.
+  // queries, 3 for visual queries) are found ONCE per block, by a ballot scan of the table (one thread walking its 155 entries
+  // took ~5 us of dependent loads per block).
   const int t = blockIdx.x;
   const int E = 2 * d;
   __shared__ int readers[8];
   __shared__ int nread;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {   // wave 0 scans the table 64 rows at a time (ballot; the readers stay in ascending order)
     int n = 0;
-    for (int s = 0; s < S; ++s)
-      if (rows[s].te_row == t) { if (n < 8) readers[n] = s; ++n; }
-    nread = n;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + (int)threadIdx.x;
+      unsigned long long m = __ballot(s < S && rows[s].te_row == t);
+      if (threadIdx.x == 0) {
+        while (m) {
+          const int bit = __ffsll((long long)m) - 1;
+          if (n < 8) readers[n] = s0 + bit;
+          ++n;
+          m &= m - 1;
+        }
+      }
+    }
+    if (threadIdx.x == 0) nread = n;
   }
   __syncthreads();
   const int nr = nread;   // > 8 (no TIM layout does this): the list is not used, every row is tested again
