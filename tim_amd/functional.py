@@ -719,9 +719,16 @@ class EncoderFn(torch.autograd.Function):
         grads = model._alloc_grad_buckets(names, params, dev, layer_overwrite=overwrite)
         G = grads.views
 
-        dx = torch.zeros((M, E), dtype=torch.float32, device=dev)
+        # gradient stream of the last layer's output: the feature rows start as the incoming `feats` cotangent (a copy, not a
+        # zero fill + add: 66 instead of 118 MB at C2a), the query rows as zeros for the heads' row scatters to add into
+        dx = torch.empty((M, E), dtype=torch.float32, device=dev)
+        dx3 = dx.view(B, S, E)
         if g["feats"] is not None:
-            dx.view(B, S, E)[:, :F] += g["feats"]  # tiny add of an incoming cotangent (plumbing)
+            dx3[:, :F].copy_(g["feats"])
+        else:
+            dx3[:, :F].zero_()
+        if S > F:
+            dx3[:, F:].zero_()
         xL_t = ctx.xs_t[Lyr]
         # fp16: scale of the gradient operands for this pass, from the cotangents that enter it (device side, no sync).  The
         # fp32 stream dx and every parameter gradient stay true-scale; only fp16 tensors carry the factor.
