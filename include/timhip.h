@@ -139,6 +139,14 @@ const char* timhip_strerror(int code);
 /* bytes of the per-layer saved-for-backward block and of the scratch workspace */
 size_t timhip_layer_saved_bytes(const TimDesc* d);
 size_t timhip_layer_workspace_bytes(const TimDesc* d);
+/* Test hook: byte offset and size of one field of the saved block (opaque to the product's host code).  Fields: the packed
+ * in-projection output qkv [M,3E] (T), the attention output o [M,E] (T), the pre-norm sums y1 / y2 [M,E] fp32, the operand copy
+ * of norm1's output x1 [M,E] (T), the FFN hidden activations h [M,FF] (T: dropmask * gelu(linear1)), and the FFN dropout
+ * keep-bits [M, FF/8] bytes that LayerNorm-1 draws (bit c%8 of byte [r*FF/8 + c/8] = element (r,c) kept; only written when
+ * p_drop > 0). */
+enum { TIMHIP_SAVED_QKV = 0, TIMHIP_SAVED_O = 1, TIMHIP_SAVED_Y1 = 2, TIMHIP_SAVED_X1T = 3, TIMHIP_SAVED_H = 4,
+       TIMHIP_SAVED_Y2 = 5, TIMHIP_SAVED_FFN_KEEP_BITS = 6 };
+int timhip_layer_saved_field(const TimDesc* d, int field, size_t* offset, size_t* bytes);
 
 /* ---------------------------------------------------------------- weights ---- */
 /* dst[rows, ld] (T) = cast(src[rows, cols] fp32), zero padded to ld columns.

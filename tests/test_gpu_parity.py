@@ -486,7 +486,7 @@ def _c2a_b64_oracle():
             o32 = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
         R = H.cotangents(cfg, B, nv, na, o32, seed=2, dtype=torch.float32)
         _, _, g32, _ = oracle_run(cfg, sd, inp, nv, na, R, torch.float32)
-        _B64.update(cfg=cfg, sd=sd, inp=inp, o32=o32, R=R, gnorm={k: v.double().norm().item() for k, v in g32.items()})
+        _B64.update(cfg=cfg, sd=sd, inp=inp, o32=o32, R=R, g32=g32, gnorm={k: v.double().norm().item() for k, v in g32.items()})
     return _B64
 
 
@@ -513,5 +513,16 @@ def test_c2a_production_batch_end_to_end(prec):
         n = res["grads"][k].double().norm().item()
         wg = max(wg, abs(n - n32) / max(1.0, n32))
         assert abs(n - n32) <= tol_g * max(1.0, n32), (prec, k, n, n32)
-    print("C2a B=64 %s: worst |dlogit| %.3g over %d logits, worst gradient-norm deviation %.3g"
-          % (prec, worst, sum(v.numel() for k, v in res["outs"].items() if k != "feats"), wg))
+    # ELEMENTWISE gradient agreement at the production batch (not only norms): cosine and largest error relative to the
+    # tensor's largest element, every parameter
+    wc, wr = 1.0, 0.0
+    cos_min, rel_max = {"fp32": (0.999999, 1e-3), "fp16": (0.9995, 6e-2), "bf16": (0.995, 0.3)}[prec]
+    for k, v in c["g32"].items():
+        a, b = res["grads"][k].double().flatten(), v.double().flatten()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-300)).item()
+        rel = relerr(res["grads"][k], v)
+        wc, wr = min(wc, cos), max(wr, rel)
+        assert cos >= cos_min, (prec, k, cos)
+        assert rel <= rel_max, (prec, k, rel)
+    print("C2a B=64 %s: worst |dlogit| %.3g over %d logits, worst gradient-norm deviation %.3g, elementwise min cos %.6f max rel err %.3g"
+          % (prec, worst, sum(v.numel() for k, v in res["outs"].items() if k != "feats"), wg, wc, wr))

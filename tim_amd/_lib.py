@@ -18,6 +18,14 @@ H16 = (PREC_BF16, PREC_F16)   # 16-bit operand storage (the MFMA GEMM / attentio
 
 # dropout site ids (csrc/common.h)
 SITE_FEAT_V, SITE_FEAT_A, SITE_SEQ = 1, 2, 3
+SITE_L_ATTN, SITE_L_DROP1, SITE_L_FFN, SITE_L_DROP2 = 0, 1, 2, 3
+
+
+def layer_site(layer, which):
+    return 16 + 8 * layer + which
+
+
+SAVED_QKV, SAVED_O, SAVED_Y1, SAVED_X1T, SAVED_H, SAVED_Y2, SAVED_FFN_KEEP_BITS = range(7)   # timhip_layer_saved_field
 
 vp, i32, u32, u64, f32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
 
@@ -69,6 +77,7 @@ _SIGS = {
     "timhip_strerror": (C.c_char_p, [C.c_int]),
     "timhip_layer_saved_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_layer_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
+    "timhip_layer_saved_field": (C.c_int, [C.POINTER(TimDesc), i32, C.POINTER(sz), C.POINTER(sz)]),
     "timhip_cast_weight": (C.c_int, [i32, vp, i32, i32, vp, i32, i32, vp]),
     "timhip_cast_weight_both": (C.c_int, [i32, vp, i32, i32, vp, i32, vp, i32, vp]),
     "timhip_cast_weights": (C.c_int, [i32, vp, i32, vp]),

@@ -170,6 +170,24 @@ const char* timhip_strerror(int code) {
 }
 
 size_t timhip_layer_saved_bytes(const TimDesc* d) { return d ? saved_layout(*d).total : 0; }
+
+// test hook: where a field of the (otherwise opaque) saved block lives
+int timhip_layer_saved_field(const TimDesc* d, int field, size_t* offset, size_t* bytes) {
+  if (!d || !offset || !bytes) return TIMHIP_EINVAL;
+  const SavedLayout L = saved_layout(*d);
+  const size_t M = (size_t)d->B * d->S, ts = opsize(d->precision);
+  switch (field) {
+    case TIMHIP_SAVED_QKV: *offset = L.qkv; *bytes = M * 3 * d->E * ts; break;
+    case TIMHIP_SAVED_O: *offset = L.o; *bytes = M * d->E * ts; break;
+    case TIMHIP_SAVED_Y1: *offset = L.y1; *bytes = M * d->E * 4; break;
+    case TIMHIP_SAVED_X1T: *offset = L.x1t; *bytes = M * d->E * ts; break;
+    case TIMHIP_SAVED_H: *offset = L.h; *bytes = M * d->FF * ts; break;
+    case TIMHIP_SAVED_Y2: *offset = L.y2; *bytes = M * d->E * 4; break;
+    case TIMHIP_SAVED_FFN_KEEP_BITS: *offset = L.ffn_mask; *bytes = M * d->FF / 8; break;
+    default: return TIMHIP_EINVAL;
+  }
+  return TIMHIP_OK;
+}
 size_t timhip_layer_workspace_bytes(const TimDesc* d);
 
 int timhip_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,

@@ -85,6 +85,7 @@ class Runtime:
             rank = 0
         self.seed = ((torch.initial_seed() & 0xFFFFFFFFFFFF) * 0x9E3779B1 + rank * 0x85EBCA6B + 0x5EED) & 0x7FFFFFFFFFFFFFFF
         self.step = 0
+        self.last_seed = 0   # the Philox key of the most recent training forward (what timhip_dropout_mask reproduces)
         self.bucket_hook = None  # callable(bucket_name, flat_grad_tensor) -> None
         self.finish_hook = None  # callable() -> None, called at the end of the encoder backward
         # TIM_AMD_OVERLAP_WGRAD=1: the weight-gradient launch of layer l runs on a side stream, overlapping the data chain of
@@ -221,6 +222,10 @@ class Runtime:
 
     def next_seed(self):
         self.step += 1
+        self.last_seed = self._next_seed()
+        return self.last_seed
+
+    def _next_seed(self):
         if _SALT["word"] is not None:
             # graph-safe mode: the launch-time seed stays fixed, the per-step part lives in device memory and is advanced
             # by a (capturable) device-side add, so a replayed graph draws fresh masks every time
