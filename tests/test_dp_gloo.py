@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bpe=3):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -35,7 +35,8 @@ def _worker(rank, world, port, q):
         cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
         m = TIM(cfg.num_class, visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2, num_feats=6)
         before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
-        dp = DataParallel(m, wire_dtype=torch.float32, buckets_per_exchange=3)
+        dp = DataParallel(m, buckets_per_exchange=bpe)
+        assert dp.wire_dtype == torch.float32          # the default is the reference's exact fp32 mean
         assert dp.world == world and dp.active and m.rt.bucket_hook is not None
         names = m._encoder_param_names
         params = m._encoder_param_list()
@@ -52,7 +53,7 @@ def _worker(rank, world, port, q):
             gb.views[n].fill_(float(i + 1) * (rank + 1))  # what the kernels would have accumulated
         for b in ("heads", "layer1", "layer0", "front"):  # order in which the backward completes them
             gb.done(b)
-        assert len(dp._pending) == 1                      # three buckets travelled as one contiguous range, one is waiting
+        assert len(dp._pending) == 4 % bpe                # bpe buckets travel as one contiguous range, the rest is waiting
         m.rt.finish_hook()                                # end of the encoder backward: the rest is exchanged
         assert not dp._pending
         mean = (1 + world) / 2.0
@@ -89,11 +90,65 @@ def _worker(rank, world, port, q):
         dp._exchange(z)
         assert torch.allclose(z, exact, rtol=1e-6, atol=1e-9)
         del os.environ["TIM_AMD_DP_COLLECTIVE"]
+        # odd lengths that W does not divide, both wire formats, against the exact mean (staging path with padded chunks)
+        for n_odd in (1, 7, 100003, 64 * 5):
+            for wd in (torch.float32, torch.bfloat16):
+                dp.wire_dtype = wd
+                dp._stage.clear()
+                xo = torch.randn(n_odd, generator=g) * 1e-3
+                ex = xo.clone()
+                allreduce_buckets_reference([ex], world)
+                go = xo.clone()
+                dp._exchange(go)
+                mx = xo.abs().max().clone()
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)          # the largest contribution of any rank sets the rounding step
+                lim = 1e-9 + (2.0 ** -8 * 1.01 if wd == torch.bfloat16 else 1e-6) * mx.item()
+                assert (go - ex).abs().max().item() <= lim, (n_odd, wd)
+        dp.wire_dtype = torch.float32
+        dp._stage.clear()
         # no_sync(): gradients stay local
         with dp.no_sync():
             y = torch.full((64,), float(rank + 1))
             dp._on_bucket("layer0", y)
             assert torch.equal(y, torch.full((64,), float(rank + 1)))
+        dp._accumulating = False
+        # gradient accumulation: microbatch 1 under no_sync(), microbatch 2 synchronised -> p.grad = mean over ranks of (g1 + g2)
+        # for EVERY parameter.  The kernels cannot run here; the test plays autograd's part (AccumulateGrad assigns the returned
+        # view when p.grad is None, adds to it otherwise) around the real bucket objects and hooks.
+        pd = dict(zip(names, params))
+        for p in m.parameters():
+            p.grad = None
+
+        def one_pass(scale):
+            gbk = _GradBuckets(m.rt, names, params, torch.device("cpu"), m._bucket_of)
+            for i, n in enumerate(names):
+                gbk.views[n].fill_(scale * float(i + 1) * (rank + 1))
+            for b in ("heads", "layer1", "layer0", "front"):
+                gbk.done(b)
+            m.rt.finish_hook()
+            for n in names:                                   # AccumulateGrad
+                if pd[n].grad is None:
+                    pd[n].grad = gbk.views[n]
+                else:
+                    pd[n].grad += gbk.views[n]
+            for j, p in enumerate(dp._small):
+                gs = torch.full_like(p, scale * float(j + 1) * (rank + 1))
+                p.grad = gs if p.grad is None else p.grad + gs
+            dp._reduce_small()
+
+        with dp.no_sync():
+            one_pass(1.0)
+        for i, n in enumerate(names):
+            assert torch.allclose(pd[n].grad, torch.full_like(pd[n], float(i + 1) * (rank + 1)))   # still local
+        one_pass(10.0)
+        for i, n in enumerate(names):
+            assert torch.allclose(pd[n].grad, torch.full_like(pd[n], 11.0 * (i + 1) * mean)), n
+        for j, p in enumerate(dp._small):
+            assert torch.allclose(p.grad, torch.full_like(p, 11.0 * (j + 1) * mean))
+        assert not dp._accumulating
+        one_pass(100.0)   # a further synchronised pass without zero_grad: plain accumulation of averaged gradients
+        for i, n in enumerate(names):
+            assert torch.allclose(pd[n].grad, torch.full_like(pd[n], 111.0 * (i + 1) * mean)), n
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -102,12 +157,13 @@ def _worker(rank, world, port, q):
         q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
 
 
-def test_two_rank_gradient_buckets_gloo():
-    world = 2
+@pytest.mark.parametrize("world,bpe", [(2, 3), (3, 1), (4, 4)])
+def test_gradient_buckets_gloo(world, bpe):
+    """world sizes 2, 3 (divides no bucket: padded chunks) and 4; one bucket per exchange, three, and all four as one range"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, bpe)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

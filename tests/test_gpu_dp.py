@@ -30,3 +30,5 @@ def test_two_ranks_sharing_one_gpu_average_their_gradients():
                          capture_output=True, text=True, timeout=600)
     assert "RESULT params 102 mismatches 0 ranks_agree True" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert "RANK1 ranks_agree True" in out.stdout
+    # gradient accumulation (first microbatch under no_sync) gives the one-pass averaged gradients on both ranks
+    assert "ACCUM rank 0 mismatches 0" in out.stdout and "ACCUM rank 1 mismatches 0" in out.stdout, out.stdout[-2000:]

@@ -167,3 +167,24 @@ def test_workspaces_captured_by_a_graph_are_retired_not_freed():
     m.rt.step = 17
     m.set_dropout_rng_state(st)
     assert m.rt.step == st["dropout_step"]
+
+
+def test_build_model_takes_the_reference_parsers_namespaces():
+    """`build_model(args)` with exactly the attributes the reference's two argument parsers produce
+    (recognition/time_interval_machine/utils/parser.py:48-70, detection/.../utils/parser.py:28-50): no `variant` attribute -
+    the detection namespace is recognised by its own fields (--iou_threshold, the `feedfoward_scale` spelling)"""
+    import argparse
+    from tim_amd.build import build_model
+    from tim_amd.detection import TIM as DetTIM
+    from tim_amd.tim import TIM as RecTIM
+    common = dict(num_gpus=0, workers=4, visual_input_dim=24, audio_input_dim=40, feat_dropout=0.5, seq_dropout=0.5, d_model=32,
+                  nhead=2, num_layers=2, enc_dropout=0.1, model_modality="audio_visual", data_modality="audio_visual",
+                  num_feats=6, include_verb_noun=True)
+    rec = argparse.Namespace(num_class=[[7, 11, 13], 5], feedforward_scale=4, apply_feature_pooling=False, **common)
+    m, _ = build_model(rec)
+    assert type(m) is RecTIM and m.dim_feedforward == 128
+    det = argparse.Namespace(num_class=[[7, 11, 13], 5], feedfoward_scale=4, iou_threshold=0.6, label_smoothing=0.9, **common)
+    m, _ = build_model(det)
+    assert type(m) is DetTIM and hasattr(m, "reg_head")
+    rec.variant = "recognition"      # an explicit attribute still wins
+    assert type(build_model(rec)[0]) is RecTIM

@@ -19,7 +19,14 @@ def build_model(args, gpu_id=None):
     else:
         assert args.num_gpus == 0, "Cuda is not available. Please set `NUM_GPUS: 0 for running on CPUs."
     precision = getattr(args, "precision", "fp16")   # the fastest mode within 1e-3 of the fp32 logits
-    if getattr(args, "variant", "recognition") == "detection":
+    # which of the reference's two `time_interval_machine` packages this is: the detection parser (detection/
+    # time_interval_machine/utils/parser.py:37,43) is the one that defines --iou_threshold and spells the FFN argument
+    # `feedfoward_scale` (det build.py:21-38);
+    # an explicit args.variant, if somebody sets one, wins
+    variant = getattr(args, "variant", None)
+    if variant is None:
+        variant = "detection" if hasattr(args, "iou_threshold") and hasattr(args, "feedfoward_scale") else "recognition"
+    if variant == "detection":
         from .detection import TIM as DetTIM
         model = DetTIM(args.num_class, visual_input_dim=args.visual_input_dim,
                        audio_input_dim=args.audio_input_dim, feat_drop=args.feat_dropout,

@@ -208,6 +208,20 @@ __device__ __forceinline__ void drop_mask4_bits(uint32_t nib, float scale, float
   m3 = (nib & 8u) ? scale : 0.f;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute: the "already done" flag of a launcher is kept per
+// device (a process that drives a second GPU would otherwise skip the call there and fail its launches)
+struct PerDeviceOnce {
+  bool done[32] = {};
+  bool first() {   // true the first time it is asked on the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 ? 0 : (dev > 31 ? 31 : dev);
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
+
 // dropout site ids (stream id = site; per-layer sites add 16*layer)
 enum {
   SITE_FEAT_V = 1, SITE_FEAT_A = 2, SITE_SEQ = 3,

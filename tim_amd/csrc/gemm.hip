@@ -593,11 +593,10 @@ void launch_h16(const void* A, int lda, const void* B, int ldb, int M, int N, in
   const int per = (nk + splitk - 1) / splitk;
   dim3 grid(((M + BM - 1) / BM) * ((N + BN - 1) / BN), 1, splitk);
   const size_t shmem = (size_t)NST * (BM + BN) * BKT * 2;
-  static bool attr_set = false;  // idempotent; a benign race sets it twice at worst
-  if (!attr_set && shmem > 64 * 1024) {
+  static PerDeviceOnce attr_set;  // idempotent; a benign race sets it twice at worst
+  if (shmem > 64 * 1024 && attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_h16_kernel<HT, EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_set = true;
   }
   hipLaunchKernelGGL((gemm_nt_h16_kernel<HT, EPI, BM, BN, WM, WN, BKT, NST, GM, ABL>), grid, dim3(WM * WN * 64), shmem, s,
                      (const HT*)A, lda, (const HT*)B, ldb, M, N, K, per, e);

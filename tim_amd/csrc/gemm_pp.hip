@@ -460,11 +460,10 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     }
   }
 #endif
-  static bool attr_set = false;   // idempotent; a benign race sets it twice at worst
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;   // idempotent; a benign race sets it twice at worst
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_set = true;
   }
   const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
   const char* ldv = getenv("TIMHIP_GEMM_LD");

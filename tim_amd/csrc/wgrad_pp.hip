@@ -734,12 +734,11 @@ int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int 
     g.tile0[i + 1] = g.tile0[i] + ((t.Nout + WP_TN - 1) / WP_TN) * ((t.Kout + WP_TK - 1) / WP_TK);
   }
   const size_t shmem = (size_t)WP_NST * WP_STAGE;
-  static bool attr_set[2] = {false, false};
+  static PerDeviceOnce attr_set[2];
   const int hi = precision == TIMHIP_PREC_F16 ? 1 : 0;
-  if (!attr_set[hi]) {
+  if (attr_set[hi].first()) {
     DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_pp_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_ld_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set[hi] = true;
   }
   // the 12-wave loader form is the default; TIMHIP_WGRAD_LD=0 selects the 8-wave merged-phase kernel (A/B switch)
   const char* ldv = getenv("TIMHIP_WGRAD_LD");   // (read per call: tests switch it inside one process)

@@ -19,9 +19,19 @@ at once.  So a bucket of N gradients travels as
 
 i.e. bf16 on the wire with fp32 accumulation (an all-reduce on bf16 tensors would accumulate in
 bf16 inside the collective).  117 MB per step per direction for the 58.3 M parameters of C2a
-instead of 233 MB.  `wire_dtype=torch.float32` keeps fp32 on the wire (exact mean; the gloo tests
-use both).  The few parameters outside the encoder Function (time MLP, DRLoc MLP: ~1.6 M) go
-through the same exchange as one more bucket when the backward finishes.
+instead of 233 MB.  THE DEFAULT IS `wire_dtype=torch.float32`: the exact fp32 mean, what the
+reference's DistributedDataParallel computes; then steps 1 and 5 do not exist and the collectives
+run on the gradient bucket itself (all-to-all out of it, all-gather into it: one local memory
+pass, the fp32 sum).  `wire_dtype=torch.bfloat16` is the opt-in bandwidth optimisation: each
+rank's contribution and the mean are rounded to 8 mantissa bits (2^-9 relative) before the
+optimizer sees them - a change in training numerics the caller has to want.  The few parameters
+outside the encoder Function (time MLP, DRLoc MLP: ~1.6 M) go through the same exchange as one
+more bucket when the backward finishes.
+
+Gradient accumulation (`no_sync()`): passes inside the context leave their gradients in `p.grad`,
+un-exchanged.  The next synchronised pass folds those local sums into its buckets before the
+exchange and hands autograd the averaged total, so after it `p.grad = mean over ranks of
+(g_1 + ... + g_k)` for every parameter - the DistributedDataParallel result.
 
 Like DistributedDataParallel, construction broadcasts rank 0's parameters and buffers, so ranks
 that were seeded or loaded differently start from the same weights.
@@ -35,7 +45,7 @@ from torch import nn
 
 
 class DataParallel(nn.Module):
-    def __init__(self, module, process_group=None, wire_dtype=torch.bfloat16, broadcast_parameters=True, force=False,
+    def __init__(self, module, process_group=None, wire_dtype=torch.float32, broadcast_parameters=True, force=False,
                  buckets_per_exchange=4):
         """force: run the exchange even in a one-rank group (every collective is then a copy) - the single-GPU
         test of how the side-stream work interferes with the backward uses it.
@@ -63,6 +73,7 @@ class DataParallel(nn.Module):
         self.bytes_on_wire = 0     # per rank and step: bytes sent + received by the last step's exchanges
         self.buckets_per_exchange = max(1, int(buckets_per_exchange))
         self._pending = []         # buckets completed but not yet exchanged: (flat, ready)
+        self._accumulating = False  # a backward pass ran under no_sync() since the last exchange
         rt = module.rt
         rt.bucket_hook = self._on_bucket
         rt.finish_hook = self._on_encoder_done
@@ -102,20 +113,31 @@ class DataParallel(nn.Module):
             self.sync = old
 
     # ---- the exchange of one flat fp32 bucket -------------------------------------------------------
-    def _staging(self, n, dev):
-        key = (n, dev)
+    def _staging(self, n, dev, recv_only=False):
+        key = (n, dev, recv_only)
         st = self._stage.get(key)
         if st is None:
             W = self.world
             per = (n + W - 1) // W
             per = (per + 7) // 8 * 8                       # 16-byte chunks on the wire
             st = {"per": per,
-                  "send": torch.zeros(per * W, dtype=self.wire_dtype, device=dev),   # padding stays zero
+                  "send": None if recv_only else torch.zeros(per * W, dtype=self.wire_dtype, device=dev),   # padding stays zero
                   "recv": torch.empty(per * W, dtype=self.wire_dtype, device=dev),
                   "shard": torch.empty(per, dtype=self.wire_dtype, device=dev),
                   "acc": torch.empty(per, dtype=torch.float32, device=dev)}
             self._stage[key] = st
         return st
+
+    def _reduce_chunks(self, st, W, per, on_gpu):
+        """shard[per] = (1/W) * sum over the W received chunks, accumulated in fp32"""
+        if on_gpu and self.wire_dtype in (torch.bfloat16, torch.float32):            # one launch
+            from ._lib import call, ptr
+            call("timhip_dp_reduce", 1 if self.wire_dtype == torch.bfloat16 else 0, ptr(st["recv"]), W, per, 1.0 / W,
+                 ptr(st["shard"]), torch.cuda.current_stream().cuda_stream)
+        else:                                                                        # (gloo / CPU tests of the logic)
+            torch.sum(st["recv"].view(W, per), dim=0, dtype=torch.float32, out=st["acc"])
+            st["acc"].mul_(1.0 / W)
+            st["shard"].copy_(st["acc"])
 
     def _exchange(self, flat):
         """flat (fp32, 1-D) <- mean over ranks, via all-to-all + fp32 sum + all-gather on `wire_dtype`"""
@@ -126,18 +148,22 @@ class DataParallel(nn.Module):
             flat.mul_(1.0 / W)
             self.bytes_on_wire += 2 * 2 * (n // W) * (W - 1) * 4
             return
+        if self.wire_dtype == torch.float32 and n % (8 * W) == 0 and flat.is_contiguous():
+            # fp32 on the wire and a range that splits into W 32-byte-aligned chunks (bucket starts and sizes are multiples of
+            # 64 elements, so this is every range when W divides 8): no staging copies - all-to-all out of the bucket,
+            # all-gather into it; the only local memory pass is the fp32 sum
+            per = n // W
+            st = self._staging(n, flat.device, recv_only=True)
+            dist.all_to_all_single(st["recv"], flat, group=self.pg)
+            self._reduce_chunks(st, W, per, flat.is_cuda)
+            dist.all_gather_into_tensor(flat, st["shard"], group=self.pg)
+            self.bytes_on_wire += 2 * 2 * per * (W - 1) * 4
+            return
         st = self._staging(n, flat.device)
         per = st["per"]
         st["send"][:n].copy_(flat)                                             # 1. narrow
         dist.all_to_all_single(st["recv"], st["send"], group=self.pg)          # 2. chunk r of every rank -> rank r
-        if flat.is_cuda and self.wire_dtype in (torch.bfloat16, torch.float32):        # 3. fp32 accumulation: one launch
-            from ._lib import call, ptr
-            call("timhip_dp_reduce", 1 if self.wire_dtype == torch.bfloat16 else 0, ptr(st["recv"]), W, per, 1.0 / W,
-                 ptr(st["shard"]), torch.cuda.current_stream().cuda_stream)
-        else:                                                                          # (gloo / CPU tests of the logic)
-            torch.sum(st["recv"].view(W, per), dim=0, dtype=torch.float32, out=st["acc"])
-            st["acc"].mul_(1.0 / W)
-            st["shard"].copy_(st["acc"])
+        self._reduce_chunks(st, W, per, flat.is_cuda)                          # 3. fp32 accumulation
         dist.all_gather_into_tensor(st["send"], st["shard"], group=self.pg)    # 4. (send is free again: reuse it)
         flat.copy_(st["send"][:n])                                             # 5. widen
         esz = st["send"].element_size()
@@ -148,9 +174,24 @@ class DataParallel(nn.Module):
             self._comm = torch.cuda.Stream(device=dev)
         return self._comm
 
-    def _on_bucket(self, name, flat, ready=None):
-        if not (self.active and self.sync):
+    def _on_bucket(self, name, flat, ready=None, members=None):
+        if not self.active:
             return
+        if not self.sync:
+            self._accumulating = True     # this pass's gradients go into p.grad through autograd, un-exchanged
+            return
+        if self._accumulating and members:
+            # earlier passes under no_sync() left local sums in p.grad: fold them into this bucket before the exchange and
+            # clear p.grad, so that autograd ASSIGNS the averaged total (mean over ranks of g_1 + ... + g_k) instead of adding the
+            # average of the last microbatch to a local sum
+            ps = [(p, v) for p, v in members if p.grad is not None]
+            if ps:
+                if ready is not None and flat.is_cuda:
+                    torch.cuda.current_stream().wait_event(ready)   # the side-stream weight gradients of this bucket
+                with torch.no_grad():
+                    torch._foreach_add_([v for _, v in ps], [p.grad for p, _ in ps])
+                for p, _ in ps:
+                    p.grad = None
         # consecutive buckets are contiguous in memory (same storage, ascending addresses): collect them into one range
         if self._pending and self._pending[-1][0].data_ptr() + self._pending[-1][0].numel() * 4 != flat.data_ptr():
             self._flush()      # (a bucket from elsewhere: exchange what is pending on its own)
@@ -189,6 +230,7 @@ class DataParallel(nn.Module):
     def _on_encoder_done(self):
         if self.active and self.sync:
             self._flush()
+            self._accumulating = False
         if self.active and self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
 

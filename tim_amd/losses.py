@@ -117,17 +117,22 @@ def _mlp_bwd(rt, gy, xT, h1, h2, w0, w2, w4, need_dx):
     z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
     dw0, db0, dw2, db2, dw4, db4 = z(d, K0), z(d), z(d, d), z(d), z(1, d), z(1)
     g = _f32c(gy).reshape(R, 1)
+    # fp16: the cotangent of a mean-reduced L1 loss is ~1e-4 / 1e-5 and the chain multiplies it with weights of ~0.04 - fp16
+    # subnormals.  As in the encoder, the 16-bit gradient operands carry a power-of-two factor chosen on the device from the
+    # incoming cotangent; parameter gradients and the fp32 input gradient are true-scale (timhip_grad_scale, include/timhip.h)
+    gs = rt.grad_scale([g], dev)
+    gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
     gT = torch.empty((R, 64), dtype=rt.op_dtype, device=dev)
-    call("timhip_cast_rows", rt.prec, ptr(g), R, 1, 1, ptr(gT), 64, 0.0, 0, 0, None, st)
+    call("timhip_cast_rows", rt.prec, ptr(g), R, 1, 1, ptr(gT), 64, 0.0, 0, 0, gs_in, st)
     dh2 = torch.zeros_like(h2)
     rt.gemm(L.EPI_DRELU_T, gT, rt.weight(w4, True), R, d, 1, dh2, dh2.shape[1], aux=h2, ldaux=h2.shape[1])
     dh1 = torch.zeros_like(h1)
     rt.gemm(L.EPI_DRELU_T, dh2, rt.weight(w2, True), R, d, d, dh1, dh1.shape[1], aux=h1, ldaux=h1.shape[1])
-    rt.wgrad_many([(gT, 1, h2, d, R, dw4, db4), (dh2, d, h1, d, R, dw2, db2), (dh1, d, xT, K0, R, dw0, db0)])
+    rt.wgrad_many([(gT, 1, h2, d, R, dw4, db4), (dh2, d, h1, d, R, dw2, db2), (dh1, d, xT, K0, R, dw0, db0)], out_scale=gs_out)
     dpts = None
     if need_dx:
         dpts = torch.empty((R, K0), dtype=torch.float32, device=dev)
-        rt.gemm(L.EPI_STORE_F32, dh1, rt.weight(w0, True), R, K0, d, dpts, K0)
+        rt.gemm(L.EPI_ADD_F32, dh1, rt.weight(w0, True), R, K0, d, dpts, K0, acc_scale=gs_out)   # (no residual: out0 = acc / S)
     return dpts, (dw0, db0, dw2, db2, dw4, db4)
 
 

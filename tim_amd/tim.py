@@ -182,6 +182,8 @@ class _GradBuckets:
         self.rt = rt
         self.views = {}
         self.flat = {}
+        self.members = {}   # bucket -> [(parameter, its gradient view)]: what a data-parallel hook needs to fold in earlier,
+        #                     locally accumulated .grad values (tim_amd/dp.py: gradient accumulation under no_sync)
         sizes = {}
         for n, p in zip(names, params):
             b = bucket_of(n)
@@ -207,6 +209,7 @@ class _GradBuckets:
         for n, p in zip(names, params):
             b = bucket_of(n)
             self.views[n] = self.flat[b][off[b]:off[b] + p.numel()].view(p.shape)
+            self.members.setdefault(b, []).append((p, self.views[n]))
             if layer_overwrite and b.startswith("layer"):
                 if ".norm" in n:
                     accumulated.append(self.views[n])
@@ -220,7 +223,7 @@ class _GradBuckets:
     def done(self, bucket, ready=None):
         """`ready`: event after which the side-stream part of the bucket is complete (None: current stream)"""
         if self.rt.bucket_hook is not None and bucket in self.flat:
-            self.rt.bucket_hook(bucket, self.flat[bucket], ready)
+            self.rt.bucket_hook(bucket, self.flat[bucket], ready, self.members.get(bucket))
 
     def range_of(self, first, last):
         """the contiguous fp32 range covering buckets first..last (in completion order)"""

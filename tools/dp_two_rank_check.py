@@ -46,6 +46,31 @@ Rs = [r[rank * B * q:(rank + 1) * B * q] for r, q in zip(Rfull, nq)]
 dp = DataParallel(model)
 assert dp.world == 2
 g_dp = run(dp, shard, Rs)
+# gradient accumulation: this rank's windows as two microbatches, the first under no_sync(): must equal the one-pass result
+for p in model.parameters():
+    p.grad = None
+h = B // 2
+for i, ctx in enumerate((dp.no_sync(), None)):
+    mb = {k: v[i * h:(i + 1) * h] for k, v in shard.items()}
+    Rm = [r[i * h * q:(i + 1) * h * q] for r, q in zip(Rs, nq)]
+    def fb():
+        te_ = dp(mb["times"], "time_mlp")
+        hd, ft = dp([mb["visual"], mb["audio"]], "encoder", te_, nv, na)
+        torch.autograd.backward([t for t in hd if t is not None] + [ft], Rm)
+    if ctx is not None:
+        with ctx:
+            fb()
+    else:
+        fb()
+torch.cuda.synchronize()
+acc_bad = 0
+for n, p in model.named_parameters():
+    if n in g_dp:
+        tol = (3e-3 + 2.0 ** -7) * g_dp[n].abs().max().item() + 1e-12
+        if (p.grad - g_dp[n]).abs().max().item() > tol:
+            acc_bad += 1
+            print("ACCUM MISMATCH rank", rank, n, (p.grad - g_dp[n]).abs().max().item(), g_dp[n].abs().max().item())
+print("ACCUM rank", rank, "mismatches", acc_bad, flush=True)
 # every rank must hold the same averaged gradients
 flat = torch.cat([v.reshape(-1) for v in g_dp.values()]).cpu()
 other = flat.clone()
