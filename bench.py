@@ -57,12 +57,62 @@ def make_batch(cfg, B, nv, na, seed, dev):
     return {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
 
 
-def step_fn(model, batch, nv, na, R):
+def make_det_targets(cfg, B, ngt, seed, dev):
+    """synthetic ground truth of the detection windows in the wire format of det sliding_window.py:383-390: `ngt` sorted
+    segments per window inside [0, 1] and their verb / noun / action (class_id: audio) labels"""
+    rs = np.random.RandomState(seed)
+    seg = lambda: torch.from_numpy(np.sort(rs.rand(B, ngt, 2), axis=-1).astype(np.float32)).to(dev)
+    nc = cfg.num_class
+    vc = nc[0] if isinstance(nc[0], (list, tuple)) else (nc[0], nc[0], nc[0])
+    ri = lambda hi: torch.from_numpy(rs.randint(0, hi, (B, ngt))).to(dev)
+    return {"v_gt_segments": seg(), "a_gt_segments": seg(), "verb": ri(vc[0]), "noun": ri(vc[1]), "action": ri(vc[2]),
+            "class_id": ri(nc[1])}
+
+
+def det_train_step(model, batch, target, state):
+    """One TRUE detection training step (det scripts/train.py:212-349): model.train(), the query set drawn from the training
+    pyramid, IoU labelling of every query on the device (timhip_label_queries), encoder forward, focal classification loss
+    with IoU row weights + 1-D DIoU regression loss over the positive queries, full backward.  No optimizer (as the
+    recognition step: the operand-copy refresh of the weights stands for it)."""
+    from tim_amd import losses
     inner = model.module if hasattr(model, "module") else model
     for p in inner.parameters():
         p.grad = None
+    inner.rt.invalidate_weights()
+    output, offsets, labels, _, ious = model([batch["visual"], batch["audio"]], "encoder", batch["times"], target, label_queries=True)
+    loss = 0.0
+    sides = []
+    if "visual" in inner.data_modality:
+        ids = (0, 1, 2) if inner.include_verb_noun else (2,)
+        sides.append((ids, 0, [labels[0][i] for i in ids]))
+    if "audio" in inner.data_modality:
+        sides.append(((3,), 1, [labels[1]]))
+    for mi, (cls_ids, reg_id, lab) in enumerate(sides):
+        iou, off = ious[reg_id], offsets[reg_id]
+        valid_reg = off[:, 0] != float("inf")                       # det train.py:223
+        valid_cls = iou >= 0.0
+        w = torch.where(iou < inner.iou_threshold, torch.ones_like(iou), iou)   # :228
+        # EMA of the positive count (:230): kept as a DEVICE scalar - the reference's `max(num_pos, 1)` compares a device tensor
+        # with a Python int, i.e. synchronises the host every step; clamp() is the same value without the read-back
+        num_pos = valid_reg.sum()
+        normaliser = 0.9 * state.get("norm", 250.0) + 0.1 * torch.clamp(num_pos, min=1).to(torch.float32)   # parser.py:113-121
+        state["norm"] = normaliser.detach()
+        cls = sum(losses.focal_loss_sum(output[0][c], lab[j], row_weights=w, row_valid=valid_cls)
+                  for j, c in enumerate(cls_ids)) / (len(cls_ids) * normaliser)
+        reg = losses.diou_loss_sum(output[1][reg_id], torch.where(valid_reg[:, None], off, torch.zeros_like(off)),
+                                   row_valid=valid_reg) * 0.5 / normaliser   # :277-285, lambda_reg = 0.5 (parser.py:78)
+        loss = loss + cls + reg
+    loss.backward()
+
+
+def step_fn(model, batch, nv, na, R):
+    inner = model.module if hasattr(model, "module") else model
+    if isinstance(R, dict):          # detection as true training: R carries {"target": ..., state}
+        return det_train_step(model, batch, R["target"], R)
+    for p in inner.parameters():
+        p.grad = None
     inner.rt.invalidate_weights()  # weights changed (optimizer step): redo the operand copies
-    if hasattr(inner, "reg_head"):   # detection (secondary workload C4): dense query pyramid generated by the model
+    if hasattr(inner, "reg_head"):   # detection in inference form with gradients: dense query pyramid generated by the model
         (cls, reg, feats), _, _, _, _ = model([batch["visual"], batch["audio"]], "encoder", batch["times"], None,
                                               label_queries=False)
         outs = [t for t in list(cls) + list(reg) + [feats] if t is not None]
@@ -177,47 +227,67 @@ def gemm_roofline(model, cfg, B, nv, na, precision, reps=20):
     return out, tot_flop, tot_ms
 
 
-def _oracle_rate(cfg, sd_np, nv, na, threads, budget_s, B=4):
+def _oracle_masks(cfg, B, S, seed=0):
+    """Bernoulli keep-masks for every dropout site of one training forward, in the layout oracle/tim_oracle.py takes them
+    (which bits are kept does not change the cost of the step)"""
+    g = torch.Generator().manual_seed(seed)
+    keep = lambda p, *shape: (torch.rand(*shape, generator=g) >= p).to(torch.uint8)
+    nf, E, FF, H, F = cfg.num_feats, cfg.E, cfg.FF, cfg.nhead, cfg.F
+    m = {"feat_visual": keep(cfg.feat_drop, B, nf, cfg.visual_input_dim), "feat_audio": keep(cfg.feat_drop, B, nf, cfg.audio_input_dim),
+         "seq": keep(cfg.seq_drop, B, S, E)}
+    for l in range(cfg.num_layers):
+        m["l%d_attn" % l] = keep(cfg.enc_dropout, B, H, S, F + 1)
+        m["l%d_drop1" % l] = keep(cfg.enc_dropout, B, S, E)
+        m["l%d_ffn" % l] = keep(cfg.enc_dropout, B, S, FF)
+        m["l%d_drop2" % l] = keep(cfg.enc_dropout, B, S, E)
+    return m
+
+
+def _oracle_rate(cfg, sd_np, nv, na, threads, B, runs=3):
+    """interval-queries/s of the CPU oracle on THE STEP THE GPU LEG TIMES: training-mode forward (all five dropout sites, masks
+    supplied) + backward to every parameter gradient of B windows; one untimed step, then `runs` timed ones -> median"""
     from oracle import tim_oracle as O
     torch.set_num_threads(threads)
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in sd_np.items()}
     inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(cfg, B, nv, na, seed=11).items()}
+    masks = _oracle_masks(cfg, B, cfg.F + cfg.num_queries(nv, na))
 
     def one():
-        cls, feats = O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na)
+        for v in sd.values():
+            v.grad = None
+        cls, feats = O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na, masks=masks)
         loss = sum(c.sum() for c in cls if c is not None) + feats.sum()
         loss.backward()
 
     one()
-    t0 = time.time()
-    n = 0
-    while True:
+    times = []
+    for _ in range(runs):
+        t0 = time.time()
         one()
-        n += 1
-        if time.time() - t0 > budget_s or n >= 64:
-            break
-    dt = time.time() - t0
-    return B * (nv + na) * n / dt, n, dt
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return B * (nv + na) / med, times
 
 
-def cpu_baseline(cfg, sd_np, nv, na, workload, budget_s=10.0):
-    """The oracle (torch CPU fp32 restatement of the reference path, kind "port") timed on this box's host cores on a bounded
-    sample of the same workload: forward+backward of B=4 windows of the same shapes, at the thread count where torch's CPU
-    GEMMs of this size stop scaling (<= 32) and at 8 threads.  The oracle evaluates the eval-mode math (no dropout
-    draws); the GPU leg runs train-mode dropout - the CPU figure is therefore slightly favoured."""
+def cpu_baseline(cfg, sd_np, nv, na, workload, B=64):
+    """The oracle (torch CPU fp32 restatement of the reference path, kind "port") timed on this box's host cores on the same
+    step the GPU leg times - train-mode forward + backward of B = 64 windows of the same shapes - at the thread count where
+    torch's CPU GEMMs of this size stop scaling (<= 32): one untimed step, median of three timed ones."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 32))
-    v, n, dt = _oracle_rate(cfg, sd_np, nv, na, cores, budget_s)
-    v8, n8, dt8 = _oracle_rate(cfg, sd_np, nv, na, min(8, avail), budget_s * 0.6)
+    if avail < 16:
+        B = min(B, 4)     # (a small host, e.g. the build container: keep the leg bounded)
+    v, times = _oracle_rate(cfg, sd_np, nv, na, cores, B)
     return {"value": round(v, 2), "unit": "interval-queries/s", "cores": cores, "kind": "port",
             "host_threads_total": os.cpu_count(), "host_threads_available": avail,
-            "value_8_threads": round(v8, 2),
-            "math": "eval-mode (no dropout draws) forward+backward; the GPU leg is train-mode",
-            "sample": "oracle/tim_oracle.py fwd+bwd, %d steps of B=4 windows of the %s shapes, torch CPU fp32, %d threads, %.1f s "
-                      "(and %d steps at %d threads, %.1f s)" % (n, workload, cores, dt, n8, min(8, avail), dt8)}
+            "math": "train-mode forward (feature / sequence / attention / residual / FFN dropout, masks supplied) + backward to every "
+                    "parameter gradient: the step the GPU leg times",
+            "sample": "oracle/tim_oracle.py fwd+bwd of B=%d windows of the %s shapes (%d interval queries per step), torch CPU fp32, %d "
+                      "threads: 1 untimed step, median of %d timed steps (%s s)"
+                      % (B, workload, B * (nv + na), cores, len(times), ", ".join("%.2f" % t for t in times))}
 
 
 def logit_parity(model, cfg, sd_np, nv, na, dev, B=4):
@@ -241,6 +311,75 @@ def logit_parity(model, cfg, sd_np, nv, na, dev, B=4):
             worst = max(worst, (a.float().cpu() - b).abs().max().item())
             n += a.numel()
     return worst, n
+
+
+def det_logit_parity(model, cfg, sd_np, dev, B=2):
+    """detection model (eval: the 399 inference queries, det tim.py:348) against the fp32 CPU oracle on B synthetic windows"""
+    from oracle import tim_oracle as O
+    inp_np = synth.make_inputs(cfg, B, 0, 0, seed=12)
+    was = model.training
+    model.eval()
+    with torch.no_grad():
+        d = {k: torch.from_numpy(v).to(dev) for k, v in inp_np.items()}
+        (cls, reg, _), _, _, _, _ = model([d["visual"], d["audio"]], "encoder", d["times"], None, label_queries=False)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+        q = O.generate_queries(0.01)
+        times = torch.cat([torch.from_numpy(inp_np["times"]), q.expand(B, -1, -1)], 1)
+        nq = q.shape[1]
+        has_v = "visual" in cfg.data_modality
+        rc, _, rr = O.forward(sd, cfg, torch.from_numpy(inp_np["visual"]), torch.from_numpy(inp_np["audio"]), times,
+                              nq if has_v else 0, 0 if cfg.data_modality == "visual" else nq)
+    model.train(was)
+    worst, n = 0.0, 0
+    for a, b in list(zip(cls, rc)) + list(zip(reg, rr)):
+        if a is not None and b is not None:
+            worst = max(worst, (a.float().cpu() - b).abs().max().item())
+            n += a.numel()
+    return worst, n
+
+
+def secondary_block(workload, B, precision, dev, steps, warmup, det_train=False, graph=False):
+    """one more BASELINE.json configuration, same build and mode, measured like the headline (eager steps of the full
+    forward + backward on HBM-resident synthetic inputs) plus its logit error against the fp32 oracle"""
+    cfg = named_config(workload)
+    det = getattr(cfg, "variant", "recognition") == "detection"
+    nv, na = (10, 0) if workload == "C1" else (15, 10)
+    if det:
+        nv, na = 399, 0
+    m, sd_np = build_model(cfg, precision, dev, seed=0)
+    m.train(det_train or not det)
+    batch = make_batch(cfg, B, 0 if det else nv, na, seed=100, dev=dev)
+    R = {"target": make_det_targets(cfg, B, 6, 5, dev)} if det_train else [None]
+    for _ in range(warmup):
+        step_fn(m, batch, nv, na, R)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn(m, batch, nv, na, R)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    err, nlog = (det_logit_parity(m, cfg, sd_np, dev) if det else logit_parity(m, cfg, sd_np, nv, na, dev, B=2))
+    qps = B * (nv + na) / ms * 1e3
+    out = {"windows_per_gpu": B, "tokens_per_window": cfg.F + cfg.num_queries(nv, na), "ms_per_step": round(ms, 3),
+           "interval_queries_per_s": round(qps, 1),
+           "frac_of_mfma_peak": round(qps * GFLOP_PER_QUERY[workload] / 1e3 / PEAK_BF16_TFLOPS, 4),
+           "max_abs_logit_err": float("%.3g" % err), "parity_sample": "%d outputs of 2 windows, eval mode, vs the fp32 CPU oracle" % nlog}
+    if graph:   # the same step as one HIP-graph replay (child process, as for the headline): the host-bound small model's fast path
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--workload", workload, "--batch", str(B),
+               "--precision", precision, "--steps", str(max(steps, 20)), "--warmup", str(warmup)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out["graph_replay"] = json.loads(line[-1]) if line else {"error": "child exited with %d" % r.returncode}
+            g = out["graph_replay"].get("ms_per_step")
+            if g:
+                out["graph_replay"]["frac_of_mfma_peak"] = round(B * (nv + na) / g * GFLOP_PER_QUERY[workload] / PEAK_BF16_TFLOPS, 4)
+        except Exception as e:  # noqa: BLE001
+            out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    del m, batch
+    return out
 
 
 def timed_steps(model, batch, nv, na, steps, warmup):
@@ -310,7 +449,10 @@ def main():
     run_model = model
     if world > 1:
         from tim_amd.dp import DataParallel
-        run_model = DataParallel(model)
+        # fp32 on the wire = the exact mean the reference's DistributedDataParallel computes (the default of tim_amd.dp);
+        # TIM_AMD_DP_WIRE=bf16 selects the half-traffic exchange (bf16 payload, fp32 accumulation)
+        wire = torch.bfloat16 if os.environ.get("TIM_AMD_DP_WIRE", "fp32") == "bf16" else torch.float32
+        run_model = DataParallel(model, wire_dtype=wire)
     batch = make_batch(cfg, B, 0 if detection else nv, na, seed=100 + rank, dev=dev)  # each rank its own shard of windows
     R = [None]
 
@@ -395,8 +537,9 @@ def main():
                 "bytes_sent_plus_received_per_rank": wire_bytes,
                 "bus_GBps_per_rank": None if not comm_ms else round(wire_bytes / comm_ms / 1e6, 1),
                 "wire_dtype": str(run_model.wire_dtype).replace("torch.", ""),
-                "note": "bf16 on the wire, fp32 accumulation: all-to-all + local sum + all-gather per gradient bucket on a side "
-                        "stream (tim_amd/dp.py); xGMI peak 7 links x ~153 GB/s per GPU"}
+                "note": "all-to-all + local fp32 sum + all-gather per range of gradient buckets on a side stream (tim_amd/dp.py): "
+                        "fp32 payload by default (exact mean, collectives run on the bucket itself), TIM_AMD_DP_WIRE=bf16 halves "
+                        "the traffic; xGMI peak 7 links x ~153 GB/s per GPU"}
     live_serial = None
     if live and world == 1 and not args.no_extra_step:
         # the same measurement on one extra (untimed) step in the other stream configuration (weight gradients on a side
@@ -531,23 +674,26 @@ def main():
                 del m2
             except Exception as e:  # noqa: BLE001
                 out["bf16_mode"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-        # (3) C2b: the window BASELINE.json words (75 + 75 feature tokens, S = 205), same model, same mode
+        # (3) one block per further BASELINE.json configuration (c2b: the window BASELINE.json words, 75 + 75 feature tokens;
+        #     c1: the small visual-only model, eager and as a HIP-graph replay - its eager step is host-bound; c3: Perception
+        #     Test; c4_train: detection as TRUE training - .train(), 399 drawn queries, on-device IoU labelling, focal + DIoU)
         if args.workload == "C2a":
-            try:
-                cfg_b = named_config("C2b")
-                m3, sd_b = build_model(cfg_b, args.precision, dev, seed=0)
-                m3.train()
-                batch_b = make_batch(cfg_b, B, nv, na, seed=100, dev=dev)
-                ms3 = timed_steps(m3, batch_b, nv, na, max(5, args.steps // 2), 3)
-                err3, _ = logit_parity(m3, cfg_b, sd_b, nv, na, dev, B=2)
-                out["c2b"] = {"workload": "C2b: 75+75 feature tokens, 15+10 queries (S = 205), B = %d" % B, "ms_per_step": round(ms3, 3),
-                              "interval_queries_per_s": round(B * (nv + na) / ms3 * 1e3, 1),
-                              "frac_of_mfma_peak": round(B * (nv + na) / ms3 * GFLOP_PER_QUERY["C2b"] / PEAK_BF16_TFLOPS, 4),
-                              "max_abs_logit_err": float("%.3g" % err3)}
-                del m3, batch_b
-            except Exception as e:  # noqa: BLE001
-                out["c2b"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            sec_steps = max(5, args.steps // 2)
+            for key, wl, b_, kw, desc in (
+                    ("c2b", "C2b", B, {}, "C2b: 75+75 feature tokens, 15+10 queries (S = 205), train-mode dropout"),
+                    ("c1", "C1", B, {"graph": True}, "C1: visual-only, d_model 256, 2 layers, 4 heads, 50 tokens + 3 x 10 queries (S = 80), train-mode dropout"),
+                    ("c3", "C3", B, {}, "C3: Perception Test A+V recognition, 50+50 tokens, 15+10 queries, dropouts 0.1"),
+                    ("c4_train", "C4", 16, {"det_train": True},
+                     "C4: EPIC-100 detection TRAINING step (det scripts/train.py:212-349): model.train(), 399 queries drawn from the "
+                     "training pyramid, IoU labelling on the device, encoder forward, sigmoid focal loss with IoU row weights + 1-D "
+                     "DIoU over the positives, full backward (S = 499)")):
+                try:
+                    blk = secondary_block(wl, b_, args.precision, dev, sec_steps, 3, **kw)
+                    blk["workload"] = desc
+                    out[key] = blk
+                except Exception as e:  # noqa: BLE001
+                    out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not detection:
         out["cpu_baseline"] = cpu_baseline(cfg, sd_np, nv, na, args.workload)
     if rank == 0:
         print(json.dumps(out))

@@ -361,8 +361,10 @@ HARSH = dict(row_scale=(2.0, 4.0), gain=(0.5, 3.0), shift=0.2, sigma=0.5)
 @pytest.mark.parametrize("train", [False, True])
 def test_c2a_fp16_trained_like_weights(train):
     """fp16 mode, C2a B = 2, on a trained-like distribution (in_proj / linear1 rows x1.5-3, LayerNorm gains 0.5-2 with shifts,
-    log-normal feature magnitudes; logits up to ~3): every logit within 1e-3 of max(1, largest |logit|) of the fp32 oracle, in
-    evaluation mode and in training mode (same masks); gradients cos >= 0.9995"""
+    log-normal feature magnitudes; logits up to ~3).  Evaluation mode: every logit within 1e-3 of max(1, largest |logit|) of the
+    fp32 oracle.  Training mode (same masks; dropout 0.5 / 0.5 doubles twice what survives): within 2.5e-3, and in both modes
+    below the error of the reference's own GPU arithmetic on the same inputs (fp16 autocast: EVERY Linear on fp16 operands,
+    scripts/train.py:197 - the oracle with rd = fp16).  Gradients: cos >= 0.9995."""
     cfg = named_config("C2a")
     B, nv, na = 2, 15, 10
     sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
@@ -371,6 +373,7 @@ def test_c2a_fp16_trained_like_weights(train):
         o_eval = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
     R = H.cotangents(cfg, B, nv, na, o_eval, seed=2, dtype=torch.float32)
     m = build(cfg, "fp16", sd)
+    masks = None
     if train:
         res = run_train(m, inp, nv, na, R)
         masks = site_masks(cfg, res["seed"], B, res["S"], inp)
@@ -379,16 +382,17 @@ def test_c2a_fp16_trained_like_weights(train):
         from tests.test_gpu_parity import run_model, oracle_run
         res = run_model(m, inp, nv, na, True, R)
         o, _, g, _ = oracle_run(cfg, sd, inp, nv, na, R, torch.float32)
-    worst, scale = 0.0, 0.0
-    for k, v in res["outs"].items():
-        if k == "feats":
-            continue
-        worst = max(worst, maxerr(v, o[k]))
-        scale = max(scale, amax(o[k]))
+    with torch.no_grad():
+        rec = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na, masks=masks, rd=torch.float16))
+    heads = [k for k in res["outs"] if k != "feats"]
+    worst = max(maxerr(res["outs"][k], o[k]) for k in heads)
+    recipe = max(maxerr(rec[k], o[k]) for k in heads)
+    scale = max(amax(o[k]) for k in heads)
     wc = min(grad_agreement(res["grads"][k], v)[0] for k, v in g.items() if not k.startswith("drloc_mlp"))
-    print("C2a fp16 trained-like weights (train=%s): worst |dlogit| %.3g at |logit|max %.2f -> %.3g relative; min gradient cos %.6f"
-          % (train, worst, scale, worst / max(1.0, scale), wc))
-    assert worst / max(1.0, scale) <= 1e-3, worst
+    print("C2a fp16 trained-like weights (train=%s): worst |dlogit| %.3g at |logit|max %.2f -> %.3g relative (reference fp16-autocast "
+          "arithmetic: %.3g); min gradient cos %.6f" % (train, worst, scale, worst / max(1.0, scale), recipe, wc))
+    assert worst / max(1.0, scale) <= (2.5e-3 if train else 1e-3), worst
+    assert worst <= recipe
     assert wc >= 0.9995, wc
 
 
