@@ -143,8 +143,9 @@ def gemm_roofline(model, cfg, B, nv, na, precision, reps=20):
     shapes = [  # name, M, N, K, epi, launches per layer (fwd + bwd)
         ("in_proj fwd", M, 3 * E, E, L.EPI_STORE_T, 1), ("out_proj fwd", M, E, E, L.EPI_DROP_RES_F32, 1),
         ("ffn1 fwd", M, FF, E, L.EPI_GELU_DROP_G2, 1), ("ffn2 fwd", M, E, FF, L.EPI_DROP_RES_F32, 1),
-        ("ffn2 dgrad", M, FF, E, L.EPI_MULAUX_T, 1), ("ffn1 dgrad", M, E, FF, L.EPI_ADD_F32, 1),
-        ("out_proj dgrad", M, E, E, L.EPI_STORE_T, 1), ("in_proj dgrad", M, E, 3 * E, L.EPI_ADD_F32, 1),
+        # (round 3: the two N = E input-gradient products are stored 16-bit; LayerNorm-backward adds them to the fp32 stream)
+        ("ffn2 dgrad", M, FF, E, L.EPI_MULAUX_T, 1), ("ffn1 dgrad", M, E, FF, L.EPI_STORE_T, 1),
+        ("out_proj dgrad", M, E, E, L.EPI_STORE_T, 1), ("in_proj dgrad", M, E, 3 * E, L.EPI_STORE_T, 1),
     ]
     if precision in ("bf16", "fp16"):
         shapes.append(("layer wgrad (ffn2 + ffn1 + out_proj + in_proj, one grouped launch)", 0, 0, Mp, "group", 1))
@@ -604,7 +605,7 @@ def main():
         S_ = cfg.F + cfg.num_queries(nv, na)
         M_, E_, FF_ = B * S_, cfg.E, cfg.FF
         nt = [(3 * E_, E_, 2 * 3 * E_), (E_, E_, 8 * E_), (FF_, E_, 2 * 2 * FF_ + FF_ // 8), (E_, FF_, 8 * E_),      # forward
-              (FF_, E_, 4 * FF_), (E_, FF_, 8 * E_), (E_, E_, 2 * E_), (E_, 3 * E_, 8 * E_)]                       # input gradients
+              (FF_, E_, 4 * FF_), (E_, FF_, 2 * E_), (E_, E_, 2 * E_), (E_, 3 * E_, 2 * E_)]                       # input gradients
         alg_nt = [M_ * k * 2 + n * k * 2 + M_ * ob for n, k, ob in nt]
         alg_tn = M_ * (E_ + FF_ + E_ + 3 * E_) * 2 + M_ * (FF_ + E_ + E_ + E_) * 2 + (2 * E_ * FF_ + 4 * E_ * E_) * 4
         alg_avg = (sum(alg_nt) + alg_tn) / 9.0

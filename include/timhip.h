@@ -352,6 +352,22 @@ int timhip_layer_bwd_weights(const TimDesc* d, const void* x_in_T, const void* s
                              const TimLayerGrads* g, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* Split gradient stream between layers (optional, what tim_amd/functional.py uses inside the stack).  The gradient of a layer
+ * boundary travels as an fp32 part plus an operand-dtype part: dx = dx_f32 + (1/S) * dx_add, S the fp16 gradient scale of
+ * TimDesc.grad_scale (1 in the other modes).  dx_out_add (may be NULL: the gradient entering the stack is plain fp32) is added
+ * by the layer's norm2 backward as it reads its input; with dx_in_add != NULL the layer leaves its input gradient in the same
+ * split form - dx_in receives norm1's fp32 output gradient, dx_in_add [M,E] (T) the in-projection's input-gradient product -
+ * for the next call's dx_out / dx_out_add; with dx_in_add == NULL dx_in is the complete fp32 gradient (as timhip_layer_bwd).
+ * Inside the layer the FFN branch's input gradient is handed to norm1's backward the same way.  The "+ residual" epilogues of
+ * the two N = E input-gradient GEMMs disappear: they store 2 bytes per element instead of reading 4 and writing 4.  dx_out is
+ * NOT clobbered by these forms. */
+int timhip_layer_bwd_split(const TimDesc* d, const TimLayerParams* w, const void* x_in_T, const void* saved, const float* dx_out,
+                           const void* dx_out_add, float* dx_in, void* dx_in_add, const TimLayerGrads* g, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int timhip_layer_bwd_data_split(const TimDesc* d, const TimLayerParams* w, const void* saved, const float* dx_out,
+                                const void* dx_out_add, float* dx_in, void* dx_in_add, void* dy, const TimLayerGrads* g,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- front end --------------------------------------------------------------
  * The time MLP (tim.py:66-74), the modality embedders and the sequence assembly
  * (encodings.py:41-75,102-121,181-251) are sequenced by the host mirror

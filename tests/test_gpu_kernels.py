@@ -468,6 +468,23 @@ def test_gemm_pingpong_kernel(prec, M, N, K, loaders, monkeypatch):
     it carries, on the encoder layer's shapes and on ragged edges (rows past M, columns past N, one / two / three contraction
     steps), against fp64"""
     monkeypatch.setenv("TIMHIP_GEMM_LD", "1" if loaders else "0")
+    monkeypatch.setenv("TIMHIP_GEMM_DG", "0")      # this test is about the one-tile-per-block kernel
+    _check_layer_gemm_epilogues(prec, M, N, K)
+
+
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("M,N,K,offset", [(9920, 1024, 1024, 9), (9920, 2048, 1024, 9), (9920, 3072, 1024, 9), (9920, 1024, 2048, 9),
+                                          (9920, 1024, 3072, 3), (8000, 1024, 128, 1), (13120, 1024, 192, 21)])
+def test_gemm_dual_group_kernel(prec, M, N, K, offset, monkeypatch):
+    """gemm_nt_dg_kernel (round 3: two wave groups on different 160 x 128 tiles a few steps apart, persistent over tile pairs,
+    2-slot rings): every epilogue the encoder layers use, 1 / 2 / 3 pairs per block, 2 .. 48 contraction steps, several group
+    offsets (the offset only changes WHEN things happen - results must not depend on it), against fp64"""
+    monkeypatch.setenv("TIMHIP_GEMM_DG", "1")
+    monkeypatch.setenv("TIMHIP_GEMM_DG_OFFSET", str(offset))
+    _check_layer_gemm_epilogues(prec, M, N, K)
+
+
+def _check_layer_gemm_epilogues(prec, M, N, K):
     rt = Runtime(prec)
     A, Ar = to_op(rt, rnd(M, K, seed=1))
     B, Br = to_op(rt, rnd(N, K, seed=2, scale=K ** -0.5))

@@ -106,6 +106,10 @@ _SIGS = {
                                            vp, vp, vp]),
     "timhip_layer_bwd": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp,
                                    C.POINTER(TimLayerGrads), vp, sz, vp]),
+    "timhip_layer_bwd_split": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp, vp, vp,
+                                         C.POINTER(TimLayerGrads), vp, sz, vp]),
+    "timhip_layer_bwd_data_split": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp, vp, vp,
+                                              C.POINTER(TimLayerGrads), vp, sz, vp]),
     "timhip_layer_dy_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_layer_data_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_layer_wgrad_workspace_bytes": (sz, [C.POINTER(TimDesc)]),

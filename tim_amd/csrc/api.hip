@@ -314,16 +314,19 @@ size_t timhip_layer_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d)
 size_t timhip_layer_data_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).total : 0; }
 size_t timhip_layer_wgrad_workspace_bytes(const TimDesc* d) { return d ? ws_layout(*d).wg_bytes : 0; }
 
-int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void* saved, float* dx_out, float* dx_in,
-                          void* dy, const TimLayerGrads* g, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!dp || !w || !saved || !dx_out || !dx_in || !dy || !g || !workspace) return TIMHIP_EINVAL;
-  const TimDesc& d = *dp;
+// The data chain.  dx_out_add / dx_in_add (both optional): the SPLIT form of the gradient stream between layers - the
+// gradient of a layer boundary travels as an fp32 part (what LayerNorm-backward wrote) plus a 16-bit part (the input-gradient
+// product of the GEMM in front of it, still carrying the fp16 gradient scale), and the next LayerNorm-backward adds the two
+// as it reads them.  The two "+ residual" input-gradient GEMMs of a layer then store 20 MB instead of reading 40 and writing
+// 40 (C2a), and the fp32 sum is never written: 360 instead of 440 MB of gradient-stream traffic per layer.
+static int layer_bwd_data_impl(const TimDesc& d, const TimLayerParams* w, const void* saved, const float* dx_out,
+                               const void* dx_out_add, float* dx_in, void* dx_in_add, void* dy, const TimLayerGrads* g,
+                               void* workspace, size_t workspace_bytes, hipStream_t s) {
   int rc = check_layer_desc(d);
   if (rc) return rc;
   const WsLayout W = ws_layout(d);
   if (workspace_bytes < W.total) return TIMHIP_EWORKSPACE;
   const int M = d.B * d.S, E = d.E, FF = d.FF, prec = d.precision;
-  hipStream_t s = (hipStream_t)stream;
   const SavedLayout L = saved_layout(d);
   const DyLayout Y = dy_layout(d);
   const char* sv = (const char*)saved;
@@ -333,41 +336,61 @@ int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void
   const float* y2 = (const float*)(sv + L.y2); const float* st2 = (const float*)(sv + L.st2);
   char* ws = (char*)workspace;
   float* f32a = (float*)(ws + W.f32a); float* f32b = (float*)(ws + W.f32b);
-  void* Tc = ws + W.Tc;
+  void* Tb = ws + W.Tb; void* Tc = ws + W.Tc;
   char* yb = (char*)dy;
   void* df = yb + Y.df; void* du = yb + Y.du; void* da = yb + Y.da; void* dqkv = yb + Y.dqkv;
-  // fp16: the gradient OPERANDS (df, du, da, Tc, dqkv and the attention scratch) carry the factor S = grad_scale[0]; it enters
-  // with the T copies LayerNorm-backward writes and leaves where an input-gradient product joins the fp32 stream
+  // fp16: the gradient OPERANDS (df, du, da, Tb, Tc, dqkv, the 16-bit parts of the stream and the attention scratch) carry the
+  // factor S = grad_scale[0]; it enters with the T copies LayerNorm-backward writes and leaves where a product joins fp32 values
   const float* gs_in = (prec == TIMHIP_PREC_F16 && d.grad_scale) ? d.grad_scale : nullptr;
   const float* gs_out = gs_in ? gs_in + 1 : nullptr;
 
   // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
   if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, df, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b,
-                              g->ln_partials ? g->ln_partials : (float*)(ws + W.lnp), s, g->ln_partials != nullptr, gs_in))) return rc;
+                              g->ln_partials ? g->ln_partials : (float*)(ws + W.lnp), s, g->ln_partials != nullptr, gs_in,
+                              dx_out_add, E, gs_out))) return rc;
   // du = (df W2) * [dropout-mask * gelu'(pre-activation)]
   TimEpi e = epi0();
   e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;   // u = dropmask * gelu'(pre-activation), written by the forward
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_MULAUX_T, df, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
-  // dx1 = du W1 + dy2   (residual branch)
+  // the FFN branch's input gradient du W1 as a 16-bit product; norm1 backward adds it to dy2 (the residual branch) as it reads
   e = epi0();
-  e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E; e.acc_scale = gs_out;
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
+  e.out0 = Tb; e.ld0 = E;
+  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
   // norm1 backward -> dy1 (fp32) and da = dropout1-mask * dy1 (T)
-  if ((rc = tim_layernorm_bwd(prec, f32b, E, y1, E, st1, M, E, 0, w->n1_w, f32a, E, da, E, d.p_drop, d.seed,
+  float* dy1 = dx_in_add ? dx_in : f32b;
+  if ((rc = tim_layernorm_bwd(prec, f32a, E, y1, E, st1, M, E, 0, w->n1_w, dy1, E, da, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b,
                               g->ln_partials ? g->ln_partials + tim_layernorm_bwd_ws(M, E) / sizeof(float) : (float*)(ws + W.lnp), s,
-                              g->ln_partials != nullptr, gs_in))) return rc;
+                              g->ln_partials != nullptr, gs_in, Tb, E, gs_out))) return rc;
   // do = da Wo
   e = epi0();
   e.out0 = Tc; e.ld0 = E;
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, da, E, w->out_wt, E, M, E, E, e, 1, s))) return rc;
   // attention backward -> dqkv
   if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, dqkv, ws + W.attn, W.lnp - W.attn, s))) return rc;
-  // dx_in = dqkv Win + dy1
   e = epi0();
-  e.out0 = dx_in; e.ld0 = E; e.res = f32a; e.ldres = E; e.acc_scale = gs_out;
+  if (dx_in_add) {   // split form: the product stays 16-bit (and scaled); dy1 is already in dx_in
+    e.out0 = dx_in_add; e.ld0 = E;
+    return tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, dqkv, 3 * E, w->in_wt, 3 * E, M, E, 3 * E, e, 1, s);
+  }
+  // dx_in = dqkv Win + dy1: the complete fp32 gradient (first layer of the stack, or a caller that wants one tensor)
+  e.out0 = dx_in; e.ld0 = E; e.res = dy1; e.ldres = E; e.acc_scale = gs_out;
   return tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, dqkv, 3 * E, w->in_wt, 3 * E, M, E, 3 * E, e, 1, s);
+}
+
+int timhip_layer_bwd_data(const TimDesc* dp, const TimLayerParams* w, const void* saved, float* dx_out, float* dx_in,
+                          void* dy, const TimLayerGrads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !w || !saved || !dx_out || !dx_in || !dy || !g || !workspace) return TIMHIP_EINVAL;
+  return layer_bwd_data_impl(*dp, w, saved, dx_out, nullptr, dx_in, nullptr, dy, g, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int timhip_layer_bwd_data_split(const TimDesc* dp, const TimLayerParams* w, const void* saved, const float* dx_out,
+                                const void* dx_out_add, float* dx_in, void* dx_in_add, void* dy, const TimLayerGrads* g,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !w || !saved || !dx_out || !dx_in || !dy || !g || !workspace) return TIMHIP_EINVAL;
+  return layer_bwd_data_impl(*dp, w, saved, dx_out, dx_out_add, dx_in, dx_in_add, dy, g, workspace, workspace_bytes,
+                             (hipStream_t)stream);
 }
 
 int timhip_layer_bwd_weights(const TimDesc* dp, const void* x_in_T, const void* saved, const void* dy,
@@ -411,6 +434,21 @@ int timhip_layer_bwd(const TimDesc* dp, const TimLayerParams* w, const void* x_i
   char* ws = (char*)workspace;
   void* dy = ws + W.total;
   int rc = timhip_layer_bwd_data(dp, w, saved, dx_out, dx_in, dy, g, ws, W.total, stream);
+  if (rc) return rc;
+  return timhip_layer_bwd_weights(dp, x_in_T, saved, dy, g, ws + W.tA, W.wg_bytes, stream);
+}
+
+
+int timhip_layer_bwd_split(const TimDesc* dp, const TimLayerParams* w, const void* x_in_T, const void* saved, const float* dx_out,
+                           const void* dx_out_add, float* dx_in, void* dx_in_add, const TimLayerGrads* g, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (!dp) return TIMHIP_EINVAL;
+  const WsLayout W = ws_layout(*dp);
+  const size_t need = W.total + dy_layout(*dp).total;
+  if (workspace_bytes < need) return TIMHIP_EWORKSPACE;
+  char* ws = (char*)workspace;
+  void* dy = ws + W.total;
+  int rc = timhip_layer_bwd_data_split(dp, w, saved, dx_out, dx_out_add, dx_in, dx_in_add, dy, g, ws, W.total, stream);
   if (rc) return rc;
   return timhip_layer_bwd_weights(dp, x_in_T, saved, dy, g, ws + W.tA, W.wg_bytes, stream);
 }

@@ -43,9 +43,11 @@ __device__ __forceinline__ void pp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(
 // ---- epilogue: one wave's TMW x 4 accumulator tiles (16 x 16 each, D[n][m] orientation) ------------------------------------
 // PFD: how many row blocks ahead the fp32 residual (+ LayerNorm statistics) is fetched.  TMW = everything before the first
 // store (8-wave kernel, 256 VGPRs per wave); 2 = a two-deep ring refilled after each block's stores (12-wave kernel, 168 VGPRs).
-template <typename HT, int EPI, int TMW, int PFD = TMW>
+struct PpNoSync { __device__ __forceinline__ void operator()() const {} };
+// AFTER: called after every 16-row block (the dual-group kernel keeps its barrier cadence there; default: nothing)
+template <typename HT, int EPI, int TMW, int PFD = TMW, typename AFTER = PpNoSync>
 __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc)[PP_TNW][TMW], int mw0, int nw0, int M, int N,
-                                            float* ep, int lane) {
+                                            float* ep, int lane, AFTER after = AFTER{}) {
   constexpr int EP_COLS = 64, EP_LD = EP_COLS + 4, CPR = EP_COLS / 4, OPR = EP_COLS / 8, RBS = 16;
   constexpr int NITQ = RBS * CPR / 64, NITO = RBS * OPR / 64;     // 4 quads / 2 octs per lane per row block
   const float asc = e.acc_scale ? *e.acc_scale : 1.f;
@@ -162,6 +164,7 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
     }
     if constexpr (j + PFD < TMW) fetch_res(std::integral_constant<int, j + PFD>{});   // refill this block's ring entry
     pp_wait_lds();   // reads done before the next row block overwrites the region
+    after();
   });
 }
 
@@ -446,6 +449,156 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
   pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
 }
 
+// ---- dual-group persistent form (gemm_nt_dg_kernel, round 3) -----------------------------------------------------------------
+// What the 160 x 256 kernel above cannot do: keep the matrix pipes busy while a tile's epilogue moves its bytes.  Every block of
+// a round finishes its main loop at the same moment, then all of them store (and, for the "+ residual" epilogues, read) at
+// the HBM rate with the matrix pipes idle - 20-50 % of a launch.  Here the two wave groups of a block
+// work on DIFFERENT tiles, a few contraction steps apart:
+//   * group tile 160 x 128 (4 waves, 2 x 2 of the same 80 x 64 wave tile as above: same fragment reads, same MFMA phase,
+//     same epilogue code), own 2-slot ring of 36-KiB stages (2 x 72 KiB per block); a block owns PAIRS of adjacent column
+//     tiles of one row panel - group 0 the even, group 1 the odd one - and walks its pairs in a persistent loop;
+//   * both groups run the LOAD / MFMA phase alternation of the kernel above behind the same workgroup barriers, group 1
+//     an ODD number of barriers behind: one group's MFMA phase coincides with the other's LOAD phase as before, but
+//     group 1 reaches the end of its tile DG_OFFSET / 2 steps after group 0 - while a group runs its epilogue (five 16-row
+//     blocks, one barrier each, to keep the cadence) the other one is still in its main loop, and its next tile's first
+//     stage is already in flight;
+//   * a 2-slot ring suffices because a LOAD phase reads a whole stage into registers: slot t % 2 is free from the
+//     barrier that ends LOAD phase t, stage t + 2 is issued into it during MFMA phase t and waited for at the end of MFMA
+//     phase t + 1 (one full step of flight time).  The epilogue transposes through the group's own slot 1 while the next
+//     tile's stage 0 lands in slot 0.
+// Hazards: as above per group; the barriers are workgroup-wide, i.e. stronger than a group needs.  A group that has
+// finished its tiles simply ends; the hardware barrier only counts live waves.
+// vmcnt: the DMA pieces are invisible to the compiler's own s_waitcnt bookkeeping; hidden older operations can only make
+// its waits for the epilogue's loads longer, never shorter, and the kernel's own counted waits (vmcnt(9): everything but the
+// newest stage) cover whatever the epilogue still has outstanding.
+constexpr int DG_BM = 160, DG_BN = 128, DG_CNT = 9, DG_TMW = 5;
+constexpr int DG_A_PIECES = DG_BM / 8, DG_A_BYTES = DG_BM * PP_ROWB, DG_ST_BYTES = (DG_BM + DG_BN) * PP_ROWB, DG_RING = 2 * DG_ST_BYTES;
+
+template <typename HT, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_dg_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                         int M, int N, int K, EpiDev e, int ppb, int offset_phases) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [group][2 slots][A tile 160 x 128 B | B tile 128 x 128 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w = wave & 3, wm = w >> 1, wn = w & 1;
+  const char* ring = lds + grp * DG_RING;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(ring));
+  const int pairs_n = N / (2 * DG_BN);
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int nk = K / 64;
+
+  // this wave's 9 pieces of a stage: tile-independent offsets (full tiles only: no clamping)
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  const int first_piece = DG_CNT * w;
+  uint32_t off[DG_CNT];
+#pragma unroll
+  for (int i = 0; i < DG_CNT; ++i) {
+    const int p = first_piece + i;
+    const bool is_a = p < DG_A_PIECES;
+    const int row = (is_a ? p : p - DG_A_PIECES) * 8 + lrow;
+    const int c = (lchunk ^ kswz<64>(row)) * 8;
+    off[i] = (uint32_t)(((size_t)row * (is_a ? lda : ldb) + c) * 2);
+  }
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+  const int a_frag = (wm * 16 * DG_TMW + frow) * PP_ROWB;
+  const int b_frag = DG_A_BYTES + (wn * 64 + frow) * PP_ROWB;
+
+  const char* Ab = nullptr; const char* Bb = nullptr;
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int pair) {
+    m0 = (pair / pairs_n) * DG_BM;
+    n0 = ((pair % pairs_n) * 2 + grp) * DG_BN;
+    Ab = reinterpret_cast<const char*>(A + (size_t)m0 * lda);
+    Bb = reinterpret_cast<const char*>(B + (size_t)n0 * ldb);
+  };
+  auto piece = [&](int kt, int slot, int i) {
+    const int p = first_piece + i;
+    const char* g = (p < DG_A_PIECES ? Ab : Bb) + (size_t)kt * PP_ROWB;
+    glds16_s(uniform_ptr(g), off[i], lds0 + slot * DG_ST_BYTES + p * 1024);
+  };
+  auto issue_stage = [&](int kt, int slot) {
+#pragma unroll
+    for (int i = 0; i < DG_CNT; ++i) piece(kt, slot, i);
+  };
+
+  if (grp == 1)
+    for (int i = 0; i < offset_phases; ++i) pp_barrier();
+
+  int pair = lb * ppb;
+  set_tile(pair);
+  issue_stage(0, 0);
+  issue_stage(1, 1);
+
+  f32x4_t acc[PP_TNW][DG_TMW];
+  vec8<HT> xa[DG_TMW], wb[PP_TNW], xb[DG_TMW], wc[PP_TNW];
+  for (int pi = 0; pi < ppb; ++pi) {
+#pragma unroll
+    for (int i = 0; i < PP_TNW; ++i)
+#pragma unroll
+      for (int j = 0; j < DG_TMW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    glds_wait<DG_CNT>();   // stage 0 (and whatever the previous epilogue still had in flight) has landed; stage 1 may fly
+    pp_barrier();
+    auto step = [&](int t, auto more_c) {
+      constexpr bool MORE = decltype(more_c)::value;
+      const int slot = t & 1;
+      const char* base = ring + slot * DG_ST_BYTES;
+#pragma unroll
+      for (int j = 0; j < DG_TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c0);
+#pragma unroll
+      for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c0);
+#pragma unroll
+      for (int j = 0; j < DG_TMW; ++j) xb[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c1);
+#pragma unroll
+      for (int i = 0; i < PP_TNW; ++i) wc[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c1);
+      pp_wait_lds();
+      pp_barrier();   // every wave of the group has read slot t % 2: it may be refilled
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int j = 0; j < DG_TMW; ++j)
+#pragma unroll
+          for (int i = 0; i < PP_TNW; ++i) {
+            acc[i][j] = half == 0 ? mfma16x16<HT>(wb[i], xa[j], acc[i][j]) : mfma16x16<HT>(wc[i], xb[j], acc[i][j]);
+            const int q = half * (DG_TMW * PP_TNW) + j * PP_TNW + i, k = q / 4;
+            if (MORE && q % 4 == 1 && k < DG_CNT) {
+              __builtin_amdgcn_sched_barrier(0);
+              piece(t + 2, slot, k);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      if (MORE) glds_wait<DG_CNT>(); else glds_wait<0>();   // stage t + 1 (issued one step ago) has landed
+      pp_barrier();
+    };
+    int t = 0;
+    for (; t + 2 < nk; ++t) step(t, std::true_type{});
+    for (; t < nk; ++t) step(t, std::false_type{});
+
+    // epilogue of this tile; the next tile's stage 0 flies meanwhile (slot 0), slot 1 is the transposition space
+    const int em0 = m0 + wm * 16 * DG_TMW, en0 = n0 + wn * 64;
+    const bool next = pi + 1 < ppb;
+    if (next) {
+      set_tile(pair + pi + 1);
+      issue_stage(0, 0);
+    }
+    float* ep = reinterpret_cast<float*>(const_cast<char*>(ring) + DG_ST_BYTES) + w * (16 * 68);
+    pp_epilogue<HT, EPI, DG_TMW>(e, acc, em0, en0, M, N, ep, lane, [] { pp_barrier(); });
+    if (next) issue_stage(1, 1);
+  }
+}
+
+template <typename HT, int EPI>
+void launch_dg(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int offset_phases, hipStream_t s) {
+  const size_t shmem = 2 * (size_t)DG_RING;
+  static PerDeviceOnce attr_set;
+  if (attr_set.first())
+    (void)hipFuncSetAttribute((const void*)gemm_nt_dg_kernel<HT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  const int npairs = (M / DG_BM) * (N / (2 * DG_BN));
+  const int ppb = (npairs + 255) / 256;         // pairs per block; tim_gemm_dg_ok() guarantees ppb divides npairs
+  hipLaunchKernelGGL((gemm_nt_dg_kernel<HT, EPI>), dim3(npairs / ppb), dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N,
+                     K, e, ppb, offset_phases);
+}
+
 template <typename HT, int EPI>
 void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, hipStream_t s) {
   constexpr int TMW = 5, BM = 32 * TMW;
@@ -485,10 +638,43 @@ bool tim_gemm_pp_wins(int M, int N, int K, int splitk) {
   return tiles >= 192 && tiles * 100 >= rounds * 256 * 75;   // the last round at least three quarters full on average
 }
 
+// Shapes for the dual-group persistent kernel: whole 160 x 256 tile pairs, at least two contraction steps, an even spread of the
+// pairs over the blocks, vectorised epilogue operands.
+static bool tim_gemm_dg_ok(int M, int N, int K, const EpiDev& e) {
+  if (M % DG_BM || N % (2 * DG_BN) || K % 64 || K < 128 || !e.vec || !e.vec8) return false;
+  const int npairs = (M / DG_BM) * (N / (2 * DG_BN));
+  const int ppb = (npairs + 255) / 256;
+  return npairs >= 192 && npairs % ppb == 0;
+}
+
 int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
                    hipStream_t s) {
   const EpiDev& e = *reinterpret_cast<const EpiDev*>(epi_dev);
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
+  // TIMHIP_GEMM_DG=1: the dual-group persistent kernel where the shape allows (an A/B switch and a tested alternative, NOT the
+  // default: measured 13 % slower over the layer's eight shapes than the one-tile-per-block kernel - its 160 x 128 group tiles
+  // stage 72 KiB per step pair where the 160 x 256 tile stages 52, and the global -> LDS path (~30 B/clk/CU), not the matrix
+  // pipe, is what bounds these loops; the hidden epilogues do not pay for that - DESIGN.md section 5c);
+  // TIMHIP_GEMM_DG_OFFSET: barriers group 1 runs behind group 0 (odd)
+  const char* dgv = getenv("TIMHIP_GEMM_DG");
+  if (dgv && dgv[0] == '1' && tim_gemm_dg_ok(M, N, K, e)) {
+    const char* ov = getenv("TIMHIP_GEMM_DG_OFFSET");
+    int off = ov ? atoi(ov) : 9;
+    if (off < 1) off = 1;
+    off |= 1;
+    switch (epi) {
+#define CASE(X) case X: DISPATCH_H16(precision, (launch_dg<HT, X>(A, lda, B, ldb, M, N, K, e, off, s))); break;
+      CASE(TIMHIP_EPI_STORE_T)
+      CASE(TIMHIP_EPI_DROP_RES_F32)
+      CASE(TIMHIP_EPI_ADD_F32)
+      CASE(TIMHIP_EPI_GELU_DROP_G2)
+      CASE(TIMHIP_EPI_MULAUX_T)
+#undef CASE
+      default: goto plain;
+    }
+    return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+  }
+plain:
   switch (epi) {
 #define CASE(X) case X: DISPATCH_H16(precision, (launch_pp<HT, X>(A, lda, B, ldb, M, N, K, e, s))); break;
     CASE(TIMHIP_EPI_STORE_T)

@@ -410,9 +410,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      T* __restrict__ dyt, int ldt, uint32_t thr, float scale,
                                                      TimSeed seed, uint32_t site, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows_pb,
-                                                     float* __restrict__ partial, const float* __restrict__ t_scale) {
+                                                     float* __restrict__ partial, const float* __restrict__ t_scale,
+                                                     const T* __restrict__ addt, int ldadd, const float* __restrict__ add_scale) {
   extern __shared__ float red[];  // [4][2][cols]
   const float ts = t_scale ? *t_scale : 1.f;   // factor on the operand-dtype copy (gradient scale of the fp16 mode)
+  // optional second addend of the incoming gradient, in the operand dtype: dx_eff = dx + add_scale * addt.  The input-gradient
+  // GEMM in front of this LayerNorm then stores its (scaled) 16-bit product instead of reading the fp32 stream and writing
+  // the sum back (20 MB instead of 80 per launch at C2a)
+  const float as = (addt && add_scale) ? *add_scale : 1.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (cols + 255) >> 8;
   float4 ag[LN_MAXV], ab[LN_MAXV];
@@ -428,6 +433,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     ww[i] = (i < nv && c < cols) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
   }
   float4 tn[LN_MAXV], dn[LN_MAXV];
+  typedef T t4_t __attribute__((ext_vector_type(4)));
+  t4_t an[LN_MAXV];
   float2 stn = make_float2(0.f, 0.f);
   auto fetch = [&](int row) {
     stn = *reinterpret_cast<const float2*>(stats + 2 * row);
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       if (i < nv && c < cols) {
         tn[i] = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
         dn[i] = *reinterpret_cast<const float4*>(dx + (size_t)row * lddx + c);
+        if (addt) an[i] = *reinterpret_cast<const t4_t*>(addt + (size_t)row * ldadd + c);
       }
     }
   };
@@ -446,7 +454,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const float mean = stn.x, rstd = stn.y;
     float4 xh[LN_MAXV], d[LN_MAXV], ga[LN_MAXV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) { xh[i] = tn[i]; d[i] = dn[i]; }
+    for (int i = 0; i < LN_MAXV; ++i) {
+      xh[i] = tn[i]; d[i] = dn[i];
+      if (addt) {
+        d[i].x = fmaf(OpT<T>::to_f(an[i][0]), as, d[i].x); d[i].y = fmaf(OpT<T>::to_f(an[i][1]), as, d[i].y);
+        d[i].z = fmaf(OpT<T>::to_f(an[i][2]), as, d[i].z); d[i].w = fmaf(OpT<T>::to_f(an[i][3]), as, d[i].w);
+      }
+    }
     if (row + 4 < r1) fetch(row + 4);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1038,9 +1052,10 @@ size_t tim_layernorm_bwd_ws(int rows, int cols) { return (size_t)((rows + 15) / 
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
                       float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, float* partial_ws,
-                      hipStream_t s, bool defer_colsum, const float* t_scale) {
+                      hipStream_t s, bool defer_colsum, const float* t_scale, const void* addt, int ldadd,
+                      const float* add_scale) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
-  if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4))
+  if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4) || (addt && ldadd % 4))
     return TIMHIP_EUNSUPPORTED;
   const int rpb = ln_bwd_rows_per_block(rows);
   dim3 grid((rows + rpb - 1) / rpb);
@@ -1048,10 +1063,12 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
-                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale)
+                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
+                                   (const T*)addt, ldadd, add_scale)
   const int nv = (cols + 255) / 256;
 #define LN_BWD0(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, true>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
-                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale)
+                                   cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
+                                   (const T*)addt, ldadd, add_scale)
   if (act == 0 && nv == 4) {
     DISPATCH_T(precision, LN_BWD0(4));
   } else {

@@ -819,6 +819,10 @@ class EncoderFn(torch.autograd.Function):
                          gs_in)
         lib = L.load()
         dx2 = torch.empty_like(dx)
+        # between layers the gradient travels split: fp32 part (what LayerNorm-backward wrote) + operand-dtype part (the
+        # in-projection's input-gradient product, added by the next LayerNorm-backward as it reads): timhip_layer_bwd_split
+        dxa = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(2)] if Lyr > 1 else [None, None]
+        add_in = None     # 16-bit part of the gradient entering the current layer (None at the top of the stack)
         stack = model._stack_prefix
         main = torch.cuda.current_stream()
         overlap = rt.overlap_wgrad
@@ -851,8 +855,10 @@ class EncoderFn(torch.autograd.Function):
                 dyb = dys[l & 1]
                 if l + 2 in done:
                     main.wait_event(done[l + 2])  # the weight gradients of layer l+2 no longer read this dy
-                call("timhip_layer_bwd_data", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.layer_saved[l]),
-                     ptr(dx), ptr(dx2), ptr(dyb), C.byref(lg), ptr(ws), dws_bytes, main.cuda_stream)
+                add_out = dxa[l & 1] if l > 0 else None
+                call("timhip_layer_bwd_data_split", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.layer_saved[l]),
+                     ptr(dx), ptr(add_in), ptr(dx2), ptr(add_out), ptr(dyb), C.byref(lg), ptr(ws), dws_bytes, main.cuda_stream)
+                add_in = add_out
                 ev = torch.cuda.Event()
                 ev.record(main)
                 aux.wait_event(ev)
@@ -864,8 +870,10 @@ class EncoderFn(torch.autograd.Function):
                 keep_alive.append(ctx.layer_saved[l])
                 grads.done("layer%d" % l, ready=dn)
             else:
-                call("timhip_layer_bwd", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.xs_t[l]),
-                     ptr(ctx.layer_saved[l]), ptr(dx), ptr(dx2), C.byref(lg), ptr(ws), ws_bytes, st)
+                add_out = dxa[l & 1] if l > 0 else None
+                call("timhip_layer_bwd_split", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.xs_t[l]),
+                     ptr(ctx.layer_saved[l]), ptr(dx), ptr(add_in), ptr(dx2), ptr(add_out), C.byref(lg), ptr(ws), ws_bytes, st)
+                add_in = add_out
                 grads.done("layer%d" % l)
             dx, dx2 = dx2, dx
             ctx.layer_saved[l] = None
