@@ -458,7 +458,15 @@ AttnArgsM make_args2(const TimDesc& d) {
   return a;
 }
 
-static inline int rows_waves(int S) { const int n = (S + 31) / 32; return n < 1 ? 1 : (n > 8 ? 8 : n); }
+static inline int rows_waves(int S) {
+  int n = (S + 31) / 32;
+  n = n < 1 ? 1 : (n > 8 ? 8 : n);
+  if (const char* v = getenv("TIMHIP_ATTN_WAVES")) {   // (A/B knob, as in attention_mfma.hip)
+    const int w = atoi(v);
+    if (w >= 1 && w <= 8) n = w;
+  }
+  return n;
+}
 
 // fused form: DH = 128, 97..128 feature keys, K / V / dS / P~ within the 160 KB of LDS (S <= 192)
 static inline bool fused_fits(const TimDesc& d) {

@@ -15,6 +15,8 @@
 // with g chosen so that BOTH access patterns are bank-conflict free:
 //   ds_read_b128 fragment reads (16 different rows, same chunk)   -> rows map to 16 distinct slots
 //   ds_read_b64_tr_b16 reads (4 rows x 64 B)                      -> 16 distinct slots
+#include <stdlib.h>
+
 #include "common.h"
 #include "mfma_tiles.h"
 
@@ -465,7 +467,19 @@ AttnArgsM make_args(const TimDesc& d) {
 }
 
 // one wave per 32-row block of queries, at most 8 waves (2 per SIMD keeps the 256-VGPR budget)
-static inline int attn_waves(int S) { const int n = (S + 31) / 32; return n < 1 ? 1 : (n > 8 ? 8 : n); }
+// One wave per 32-row block of queries, but at most FOUR per block: the kernel needs 212 VGPRs (two waves per SIMD = eight wave
+// slots per CU) and 64-80 KiB of LDS, so two 4-wave blocks are co-resident on a CU where a 5-wave block (S = 155) runs alone -
+// one block's K / V staging and operand loads then overlap the other's arithmetic (C2a forward 33.3 -> 26.9 us; 3 waves 28.8,
+// 8 waves 32.8); a wave walks rows rb, rb + 4, ...
+static inline int attn_waves(int S) {
+  int n = (S + 31) / 32;
+  n = n < 1 ? 1 : (n > 4 ? 4 : n);
+  if (const char* v = getenv("TIMHIP_ATTN_WAVES")) {   // (A/B knob: fewer waves than row blocks - a wave then walks several)
+    const int w = atoi(v);
+    if (w >= 1 && w <= 8) n = w;
+  }
+  return n;
+}
 
 template <typename HT, int DH, int NJB>
 int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
