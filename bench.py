@@ -369,7 +369,7 @@ def secondary_block(workload, B, precision, dev, steps, warmup, det_train=False,
     if graph:   # the same step as one HIP-graph replay (child process, as for the headline): the host-bound small model's fast path
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--workload", workload, "--batch", str(B),
-               "--precision", precision, "--steps", str(max(steps, 20)), "--warmup", str(warmup)]
+               "--precision", precision, "--steps", str(max(steps, 20)), "--warmup", str(warmup)] + (["--det-train"] if det_train else [])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -410,6 +410,8 @@ def main():
                          "(profiling runs: the summary then holds only steps like the timed ones)")
     ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay measurement")
     ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--det-train", action="store_true",
+                    help="detection workloads (C4): the true training step (train-mode query draw, labelling, focal + DIoU) instead of the inference form")
     ap.add_argument("--no-per-shape", action="store_true", help="skip the isolated per-shape GEMM loop (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (parity sample, bf16 mode, C2b)")
     args = ap.parse_args()
@@ -446,7 +448,7 @@ def main():
         nv, na = 399, 0          # the dense query pyramid the detection model generates (det tim.py:140-155)
     B = args.batch
     model, sd_np = build_model(cfg, args.precision, dev, seed=0)
-    model.train(not detection)   # C4 (secondary workload) is timed in inference form with gradients: no GT targets needed
+    model.train(not detection or args.det_train)   # C4 without --det-train: inference form with gradients (no GT targets needed)
     run_model = model
     if world > 1:
         from tim_amd.dp import DataParallel
@@ -455,7 +457,7 @@ def main():
         wire = torch.bfloat16 if os.environ.get("TIM_AMD_DP_WIRE", "fp32") == "bf16" else torch.float32
         run_model = DataParallel(model, wire_dtype=wire)
     batch = make_batch(cfg, B, 0 if detection else nv, na, seed=100 + rank, dev=dev)  # each rank its own shard of windows
-    R = [None]
+    R = {"target": make_det_targets(cfg, B, 6, 5 + rank, dev)} if (detection and args.det_train) else [None]
 
     def barrier():
         if world > 1:
@@ -684,7 +686,7 @@ def main():
                     ("c2b", "C2b", B, {}, "C2b: 75+75 feature tokens, 15+10 queries (S = 205), train-mode dropout"),
                     ("c1", "C1", B, {"graph": True}, "C1: visual-only, d_model 256, 2 layers, 4 heads, 50 tokens + 3 x 10 queries (S = 80), train-mode dropout"),
                     ("c3", "C3", B, {}, "C3: Perception Test A+V recognition, 50+50 tokens, 15+10 queries, dropouts 0.1"),
-                    ("c4_train", "C4", 16, {"det_train": True},
+                    ("c4_train", "C4", 16, {"det_train": True, "graph": True},
                      "C4: EPIC-100 detection TRAINING step (det scripts/train.py:212-349): model.train(), 399 queries drawn from the "
                      "training pyramid, IoU labelling on the device, encoder forward, sigmoid focal loss with IoU row weights + 1-D "
                      "DIoU over the positives, full backward (S = 499)")):

@@ -469,6 +469,18 @@ def test_gemm_pingpong_kernel(prec, M, N, K, loaders, monkeypatch):
     steps), against fp64"""
     monkeypatch.setenv("TIMHIP_GEMM_LD", "1" if loaders else "0")
     monkeypatch.setenv("TIMHIP_GEMM_DG", "0")      # this test is about the one-tile-per-block kernel
+    monkeypatch.setenv("TIMHIP_GEMM_PT", "0")
+    _check_layer_gemm_epilogues(prec, M, N, K)
+
+
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("M,N,K", [(9920, 2048, 1024), (9920, 3072, 1024), (9920, 2048, 128), (9925, 3072, 192), (13120, 2048, 64 * 5)])
+def test_gemm_persistent_tile_kernel(prec, M, N, K, monkeypatch):
+    """gemm_nt_pt_kernel (round 3): a block walks 2 or 3 (4 at M = 13120) consecutive 160 x 256 tiles, the next tile's first
+    stages in flight during the epilogue (ring slot 2 is the transposition space); every epilogue, ragged last row panel,
+    2 .. 16 contraction steps"""
+    monkeypatch.setenv("TIMHIP_GEMM_DG", "0")
+    monkeypatch.setenv("TIMHIP_GEMM_PT", "1")
     _check_layer_gemm_epilogues(prec, M, N, K)
 
 

@@ -181,7 +181,7 @@ template <int TMW, int G> struct PpShare {
 template <typename HT, int TMW, int G, bool PROF = false>
 __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* __restrict__ B, int nk, const char* lds, uint32_t lds0,
                                             const uint32_t (&off)[7], int first_piece, int a_frag, int b_frag, int c0, int c1,
-                                            f32x4_t (&acc)[PP_TNW][TMW], long long* prof = nullptr) {
+                                            f32x4_t (&acc)[PP_TNW][TMW], long long* prof = nullptr, bool primed = false) {
   constexpr int BM = 32 * TMW, A_PIECES = BM / 8;
   constexpr int A_BYTES = BM * PP_ROWB, B_BYTES = PP_BN * PP_ROWB, ST_BYTES = A_BYTES + B_BYTES;
   constexpr int CNT = PpShare<TMW, G>::CNT;
@@ -193,15 +193,20 @@ __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* 
     glds16_s(uniform_ptr(g), off[i], lds0 + slot * ST_BYTES + p * 1024);
   };
 
-  // prologue: stages 0 and 1 in flight, stage 0 landed
-#pragma unroll
-  for (int i = 0; i < CNT; ++i) piece(0, 0, i);
-  if (nk > 1) {
-#pragma unroll
-    for (int i = 0; i < CNT; ++i) piece(1, 1, i);
-    glds_wait<CNT>();
-  } else {
+  // prologue: stages 0 and 1 in flight, stage 0 landed.  primed (persistent tile loop): both were issued before the previous
+  // tile's epilogue; everything this wave has outstanding - the two stages and that epilogue's stores - is waited for
+  if (primed) {
     glds_wait<0>();
+  } else {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) piece(0, 0, i);
+    if (nk > 1) {
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) piece(1, 1, i);
+      glds_wait<CNT>();
+    } else {
+      glds_wait<0>();
+    }
   }
   pp_barrier();
   if constexpr (G == 1) pp_barrier();   // half a phase behind G0 from here on
@@ -325,6 +330,78 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const HT* __restrict__ 
       atomicAdd(c + 6, (unsigned long long)(wall_clock64() - w_begin));
       atomicAdd(c + 7, (unsigned long long)(t_end - t_loop));
     }
+  }
+}
+
+// ---- persistent-tile form (gemm_nt_pt_kernel, round 3) -------------------------------------------------------------------------
+// For the shapes that run two or three rounds of 160 x 256 tiles (N = 2048 / 3072 at M = 9920: 496 / 744 tiles) a block walks its
+// tiles itself - the 2 or 3 consecutive column tiles of one row panel (the A panel stays in its XCD's L2) - and issues the
+// NEXT tile's first two stages before it starts the current tile's epilogue: the epilogue transposes through ring slot 2,
+// slots 0 and 1 fill meanwhile, and the next main loop starts without a block launch, a cold prologue or a ragged last round.
+// (The epilogue itself still runs with the matrix pipes idle - see gemm_nt_dg_kernel below for the measured attempt at that.)
+template <typename HT, int EPI, int TMW>
+__global__ __launch_bounds__(512) void gemm_nt_pt_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                         int M, int N, int K, EpiDev e, int tpb) {
+  constexpr int BM = 32 * TMW;
+  constexpr int A_BYTES = BM * PP_ROWB, ST_BYTES = (BM + PP_BN) * PP_ROWB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int tiles_n = (N + PP_BN - 1) / PP_BN;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  const int first_piece = wm == 0 ? 7 * wn : 28 + 6 * wn;
+  const int cnt = wm == 0 ? 7 : 6;
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+  const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
+  const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  const int nk = K / 64;
+
+  uint32_t off[7];
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int t) {
+    m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * PP_BN;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int p = first_piece + i;
+      const bool is_a = p < BM / 8;
+      const int row = (is_a ? p : p - BM / 8) * 8 + lrow;
+      const int c = (lchunk ^ kswz<64>(row)) * 8;
+      off[i] = is_a ? (uint32_t)(((size_t)min(m0 + row, M - 1) * lda + c) * 2) : (uint32_t)(((size_t)min(n0 + row, N - 1) * ldb + c) * 2);
+    }
+  };
+  auto prime = [&]() {   // stages 0 and 1 of the tile `off` describes -> slots 0 and 1
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+        if (i < cnt) {
+          const int p = first_piece + i;
+          const char* g = reinterpret_cast<const char*>(p < BM / 8 ? (const void*)A : (const void*)B) + (size_t)st * PP_ROWB;
+          glds16_s(uniform_ptr(g), off[i], lds0 + st * ST_BYTES + p * 1024);
+        }
+  };
+
+  f32x4_t acc[PP_TNW][TMW];
+  set_tile(lb * tpb);
+  for (int k = 0; k < tpb; ++k) {
+#pragma unroll
+    for (int i = 0; i < PP_TNW; ++i)
+#pragma unroll
+      for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (wm == 0) pp_mainloop<HT, TMW, 0>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, nullptr, k > 0);
+    else pp_mainloop<HT, TMW, 1>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, nullptr, k > 0);
+    __syncthreads();   // every wave is done with the stage ring
+    const int em0 = m0 + wm * 16 * TMW, en0 = n0 + wn * 64;
+    if (k + 1 < tpb) {   // the next tile's first two stages fly during this tile's epilogue
+      set_tile(lb * tpb + k + 1);
+      prime();
+    }
+    float* ep = reinterpret_cast<float*>(lds + 2 * ST_BYTES) + wave * (16 * 68);
+    pp_epilogue<HT, EPI, TMW>(e, acc, em0, en0, M, N, ep, lane);
   }
 }
 
@@ -619,6 +696,22 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   }
   const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
+  if constexpr (EPI != TIMHIP_EPI_DROP_RES_F32) {   // (that epilogue's residual prefetch leaves no registers for the tile loop's state)
+    // two or three full rounds of tiles: the persistent-tile kernel - TIMHIP_GEMM_PT=1 only (a tested A/B switch, not the default:
+    // measured equal to one tile per block within the run-to-run spread, in_proj forward 71.8 vs 71.5 us, linear1 61.8 vs 60.3,
+    // linear2 input gradient 50.7 vs 50.5 - the hardware already overlaps the next round's block launches and prologues with the
+    // current round's tail; what a round costs beyond its main loop is the epilogue's own drain)
+    const int tiles = (int)grid.x, tpb = (tiles + 255) / 256;
+    const char* ptv = getenv("TIMHIP_GEMM_PT");
+    if (tpb >= 2 && tpb <= 4 && tiles % tpb == 0 && ((N + PP_BN - 1) / PP_BN) % tpb == 0 && K >= 128 && ptv && ptv[0] == '1') {
+      static PerDeviceOnce pt_attr;
+      if (pt_attr.first())
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pt_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL((gemm_nt_pt_kernel<HT, EPI, TMW>), dim3(tiles / tpb), dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb,
+                         M, N, K, e, tpb);
+      return;
+    }
+  }
   const char* ldv = getenv("TIMHIP_GEMM_LD");
   if (ldv && ldv[0] == '1') {   // (measured: within +-0.5 % of the 8-wave kernel in the step, whichever epilogues take it)
     hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);

@@ -74,6 +74,7 @@ class DataParallel(nn.Module):
         self.buckets_per_exchange = max(1, int(buckets_per_exchange))
         self._pending = []         # buckets completed but not yet exchanged: (flat, ready)
         self._accumulating = False  # a backward pass ran under no_sync() since the last exchange
+        self._a2a_failed = False    # set when the all-to-all path raised: every later exchange is a plain all-reduce
         rt = module.rt
         rt.bucket_hook = self._on_bucket
         rt.finish_hook = self._on_encoder_done
@@ -142,12 +143,27 @@ class DataParallel(nn.Module):
     def _exchange(self, flat):
         """flat (fp32, 1-D) <- mean over ranks, via all-to-all + fp32 sum + all-gather on `wire_dtype`"""
         W, n = self.world, flat.numel()
-        if os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") == "allreduce":
+        if os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") == "allreduce" or self._a2a_failed:
             # plain fp32 ring all-reduce (A/B switch and a way out should a runtime mishandle the all-to-all)
             dist.all_reduce(flat, group=self.pg)
             flat.mul_(1.0 / W)
             self.bytes_on_wire += 2 * 2 * (n // W) * (W - 1) * 4
             return
+        try:
+            return self._exchange_a2a(flat, W, n)
+        except RuntimeError as e:   # a runtime that cannot run the all-to-all / all-gather pair (never seen; no multi-GPU box was
+            # available to the builder): say so once and use the plain all-reduce from here on - the bucket is still intact,
+            # all-to-all only writes the staging buffer and the all-gather is the last step
+            if flat.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            import warnings
+            warnings.warn("tim_amd.dp: all-to-all gradient exchange failed (%s); falling back to all_reduce" % str(e)[:200])
+            self._a2a_failed = True
+            dist.all_reduce(flat, group=self.pg)
+            flat.mul_(1.0 / W)
+            self.bytes_on_wire += 2 * 2 * (n // W) * (W - 1) * 4
+
+    def _exchange_a2a(self, flat, W, n):
         if self.wire_dtype == torch.float32 and n % (8 * W) == 0 and flat.is_contiguous():
             # fp32 on the wire and a range that splits into W 32-byte-aligned chunks (bucket starts and sizes are multiples of
             # 64 elements, so this is every range when W divides 8): no staging copies - all-to-all out of the bucket,

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Evidence of one round, run on the GPU box through gpurun:  bash tools/collect_evidence.sh r03_a
+# -> gpurun_out/<tag>/: bench_default.json, kernel stats of a 35-step profiled run, PMC passes (FETCH_SIZE / WRITE_SIZE / SQ
+# counters, each in its own run with --kernel-trace only), the library calibration table.
+TAG=${1:-r03}
+OUT=/root/repo/gpurun_out/$TAG
+mkdir -p $OUT
+cd /root/repo
+timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 300 python tools/blas_ref.py > $OUT/blas_ref.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+B="python /root/repo/bench.py --no-cpu-baseline --no-extra-step --no-graph --no-per-shape --no-secondary"
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof -o c2a -- $B --steps 35 --warmup 5 > $OUT/bench_profiled_run.json 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/traffic/f -o p --output-format csv -- $B --steps 9 --warmup 2 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/traffic/w -o p --output-format csv -- $B --steps 9 --warmup 2 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/sq/a -o p --output-format csv -- $B --steps 9 --warmup 2 > /dev/null 2>&1
+cd /root/repo
+python tools/rocpd_stats.py $OUT/prof/c2a_results.db > $OUT/kernel_stats.csv 2> $OUT/kernel_stats.err
+python tools/pmc_traffic.py $OUT/traffic $OUT/pmc_traffic.json > /dev/null 2> $OUT/pmc_traffic.err
+python tools/pmc_summary.py $OUT/sq gemm_nt_pp wgrad_ld attn_fwd attn_bwd_rows ln_bwd ln_fwd8 gemm_nt_h16 > $OUT/pmc_sq_summary.txt 2>&1
+rm -rf $OUT/prof $OUT/traffic $OUT/sq
+ls -la $OUT

@@ -1,4 +1,4 @@
-"""A/B of the one-tile-per-block ping-pong NT kernel (TIMHIP_GEMM_DG=0) against the dual-group persistent kernel
+"""A/B of the one-tile-per-block ping-pong NT kernel (TIMHIP_GEMM_DG=0, TIMHIP_GEMM_PT=0), its persistent-tile form (TIMHIP_GEMM_PT=1) and the dual-group persistent kernel
 (TIMHIP_GEMM_DG=1, several group offsets), interleaved in one process, on the eight NT GEMMs of an encoder layer with the
 epilogues the layer uses (C2a, B = 64: M = 9920)."""
 import os, sys
@@ -26,7 +26,8 @@ for name, N, K, epi in shapes:
     if epi == L.EPI_MULAUX_T: kw.update(aux=o1, ldaux=N)
     run = lambda: rt.gemm(epi, A, B, M, N, K, o0, N, **kw)
     line = "%-15s N%d K%d:" % (name, N, K)
-    for cfgname, env in [("pp", {"TIMHIP_GEMM_DG": "0"})] + [("dg%d" % o, {"TIMHIP_GEMM_DG": "1", "TIMHIP_GEMM_DG_OFFSET": str(o)}) for o in offsets]:
+    for cfgname, env in [("pp", {"TIMHIP_GEMM_DG": "0", "TIMHIP_GEMM_PT": "0"}), ("pt", {"TIMHIP_GEMM_DG": "0", "TIMHIP_GEMM_PT": "1"})] + \
+            [("dg%d" % o, {"TIMHIP_GEMM_DG": "1", "TIMHIP_GEMM_DG_OFFSET": str(o), "TIMHIP_GEMM_PT": "0"}) for o in offsets]:
         best = 1e9
         for rep in range(3):
             os.environ.update(env)
