@@ -614,13 +614,14 @@ def main():
         traffic = None  # HBM-side bytes per launch of the GEMM kernels, from the committed rocprofv3 PMC passes
         tnote = "no PMC summary committed for this configuration"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
+            tfile = [f for f in ("r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
             if args.precision in ("bf16", "fp16") and args.workload == "C2a" and B == 64:
                 ntk, tnk = tj["gemm_nt_pp_kernel"], tj.get("wgrad_ld_kernel", tj.get("wgrad_pp_kernel"))   # 8 NT + 1 grouped TN launch per layer
                 traffic = round((8 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 9.0)
                 tnote = ("average HBM-side bytes per GEMM launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
-                         "profiles/r02_pmc_traffic.json, tools/pmc_traffic.py): NT %.0f MB, grouped TN %.0f MB per launch"
-                         % (ntk["bytes_per_launch"] / 1e6, tnk["bytes_per_launch"] / 1e6))
+                         "profiles/%s, tools/pmc_traffic.py): NT %.0f MB, grouped TN %.0f MB per launch"
+                         % (tfile, ntk["bytes_per_launch"] / 1e6, tnk["bytes_per_launch"] / 1e6))
         except Exception:
             traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",

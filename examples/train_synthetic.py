@@ -96,8 +96,11 @@ def main(argv=None):
         loss = loss + 0.3 * losses.dense_relative_localization_loss_crossmodal(feats[:, :nf], feats[:, nf:], model, 8)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        opt.step()
+        # non-finite guard (what GradScaler.step does in the reference loop, train.py:355-363): the fp16 mode's device-side
+        # gradient scale never skips a step by itself, so the loop does - the clip already computes the norm
+        gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        if torch.isfinite(gnorm):
+            opt.step()
         hist.append(loss.item())
         if rank == 0 and (step % 5 == 0 or step == args.steps - 1):
             print("step %3d  loss %.4f" % (step, hist[-1]), flush=True)

@@ -422,3 +422,78 @@ def test_c2a_ill_conditioned_weights_no_worse_than_reference_fp16_recipe():
     assert errs["fp16"] <= e_recipe
     assert errs["fp32"] <= 5e-4      # (fp32 rounding, 6e-8, times the same ~250x amplification)
     assert errs["bf16x3"] <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# detection in .train(): the step bench.py's c4_train block times (drawn queries, on-device labelling, all dropout sites)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec,B", [("fp32", 2), ("fp16", 2)])
+def test_detection_train_mode_vs_oracle_with_masks(prec, B):
+    """det models/tim.py:272-345 (forward_train): the query set is drawn from the training pyramid, every query labelled
+    against the ground truth, the encoder runs with all dropout sites on.  The model returns the queries it drew; the oracle
+    gets them and the step's masks: classification / regression outputs <= 1e-5 (fp32 kernels) / 1e-3 (fp16), the labelling
+    bit-identical to the oracle's (itself pinned to the reference's label_queries), every parameter gradient of a
+    fixed-cotangent loss within 2e-4 (fp32) / cos >= 0.998 (fp16, toy width)."""
+    im, dm, nc, tag = H.DET_CASES[2]          # audio_visual / audio_visual, verb + noun + action heads and the audio head
+    cfg = H.tiny_cfg("detection", im, dm, tag == "vn", num_class=nc)
+    cfg.feat_drop, cfg.seq_drop, cfg.enc_dropout = 0.3, 0.25, 0.2
+    sd, inp = H.synth_torch(cfg, B, 0, 0, seed=3, dtype=torch.float32)
+    m = build(cfg, prec, sd).train()
+    g = torch.Generator().manual_seed(21)
+    ngt = 4
+    segs = lambda: torch.sort(torch.rand(B, ngt, 2, generator=g), dim=-1)[0]
+    vc = nc[0]
+    ri = lambda hi: torch.randint(0, hi, (B, ngt), generator=g)
+    target = {"v_gt_segments": segs(), "a_gt_segments": segs(), "verb": ri(vc[0]), "noun": ri(vc[1]), "action": ri(vc[2]),
+              "class_id": ri(nc[1])}
+    tdev = {k: v.to(DEV) for k, v in target.items()}
+    vis = inp["visual"].to(DEV).requires_grad_(True)
+    aud = inp["audio"].to(DEV).requires_grad_(True)
+    m.rt.step = 100
+    (cls, reg, feats), offsets, labels, queries, ious = m([vis, aud], "encoder", inp["times"].to(DEV), tdev, label_queries=True)
+    seed = m.rt.last_seed
+    node = cls[2].grad_fn
+    S = node.dims[3]
+    nq = m.num_queries
+    vq, aq = queries[0].detach().cpu().view(B, nq, 2), queries[1].detach().cpu().view(B, nq, 2)
+    assert not torch.equal(vq[0], m.inference_queries[0])          # really the drawn training set
+    # labelling: bit-identical to the oracle on the drawn queries
+    for mod, q, sg, lab, ncs in (("visual", vq, target["v_gt_segments"], torch.stack([target["verb"], target["noun"], target["action"]], -1), list(vc)),
+                                 ("audio", aq, target["a_gt_segments"], target["class_id"].unsqueeze(-1), [nc[1]])):
+        tg, mats, best = O.label_queries(q, sg, lab, m.iou_threshold, m.label_smoothing, ncs)
+        i = 0 if mod == "visual" else 1
+        assert torch.equal(offsets[i].cpu(), tg), mod
+        assert torch.equal(ious[i].cpu(), best), mod
+        got = labels[0] if mod == "visual" else [labels[1]]
+        for a, b in zip(got, mats):
+            assert torch.equal(a.cpu(), b), mod
+    outs = H.named_outputs(cls, feats, reg)
+    gR = torch.Generator().manual_seed(5)
+    R = {k: torch.randn(v.shape, generator=gR) * 0.1 for k, v in outs.items()}
+    sum((outs[k] * R[k].to(DEV)).sum() for k in outs).backward()
+    torch.cuda.synchronize()
+    # the oracle on the same queries under the same masks
+    masks = site_masks(cfg, seed, B, S, inp)
+    sdo = {k: v.double().clone().requires_grad_(True) for k, v in sd.items()}
+    times = torch.cat([inp["times"], vq, aq], 1).double()
+    vo, ao = inp["visual"].double().clone().requires_grad_(True), inp["audio"].double().clone().requires_grad_(True)
+    ocls, ofeats, oreg = O.forward(sdo, cfg, vo, ao, times, nq, nq, masks=masks)
+    oo = H.named_outputs(ocls, ofeats, oreg)
+    assert set(oo) == set(outs)
+    sum((oo[k] * R[k].double()).sum() for k in oo).backward()
+    tol = {"fp32": 1e-5, "fp16": 1e-3}[prec]
+    for k, v in outs.items():
+        e = maxerr(v.detach().cpu(), oo[k].detach()) / max(1.0, amax(oo[k].detach()))
+        assert e <= tol, (prec, k, e)
+    wc, wr = 1.0, 0.0
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    for k, v in sdo.items():
+        if v.grad is None or k.startswith("drloc_mlp"):
+            continue
+        cos, rel = grad_agreement(grads[k], v.grad)
+        wc, wr = min(wc, cos), max(wr, rel)
+        # (fp16 on a 32-wide toy model: a handful of ReLU decisions of the regression MLPs flip under 11-bit operands)
+        assert cos >= (0.999999 if prec == "fp32" else 0.998), (prec, k, cos)
+        assert rel <= (2e-4 if prec == "fp32" else 0.1), (prec, k, rel)
+    assert relerr(vis.grad.cpu(), vo.grad) <= (2e-4 if prec == "fp32" else 0.1)
+    print("detection train mode %s: gradients min cos %.6f, max rel err %.3g" % (prec, wc, wr))
