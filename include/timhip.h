@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 2
+#define TIMHIP_VERSION 3
 
 enum {
   TIMHIP_OK = 0,
