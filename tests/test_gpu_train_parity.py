@@ -18,12 +18,21 @@ pytestmark = pytest.mark.gpu
 
 from oracle import tim_oracle as O  # noqa: E402
 from tests import helpers as H  # noqa: E402
-from tests.test_gpu_parity import build, maxerr, relerr, amax  # noqa: E402
+from tests.test_gpu_parity import build as _build, maxerr, relerr, amax  # noqa: E402
 from tim_amd import _lib as L  # noqa: E402
 from tim_amd.config import named_config  # noqa: E402
 from tim_amd.functional import Runtime, _ru  # noqa: E402
 
 DEV = "cuda:0"
+
+
+def build(cfg, precision, sd):
+    """the model's dropout key derives from torch.initial_seed() when the model is built (functional.Runtime): pinned here to
+    torch's default seed value, so that the masks - and the error realisation the asserts see - do not depend on which tests
+    ran before (other tests call torch.manual_seed).  The logit error of the fp16 mode in training mode varies with the draw:
+    8.1e-4 on this key, 9.5e-4 on the key the full suite's order used to produce (C2a, B = 64)."""
+    torch.manual_seed(67280421310721)
+    return _build(cfg, precision, sd)
 
 
 def st():
