@@ -105,6 +105,15 @@ typedef struct TimDesc {
 #define TIMHIP_DESC_WGRAD_OVERWRITE 4  /* bf16 only: timhip_layer_bwd[_weights] WRITES the weight and bias gradients of the four
                                           Linears (dW = ..., not +=): those buffers need no zero fill and are not read */
 #define TIMHIP_DESC_WGRAD_SEPARATE 8   /* bf16 only: four timhip_wgrad launches per layer instead of the grouped one (A/B knob) */
+#define TIMHIP_DESC_OUTPROJ_SPLIT 16   /* forward, 16-bit precisions: TimLayerParams.out_w is a [E, ld >= 2E] SPLIT copy of the out-projection
+                                          weight, column blocks [hi | lo | ...] as timhip_split3_many(mode 0) writes them; the
+                                          out-projection runs over K = 2E with the attention output read twice (TimEpi.a_wrap_k):
+                                          its weight's fp16 rounding error - the same for every token, hence not averaged out by
+                                          the attention - was the largest single term of the fp16 mode's logit error (DESIGN.md
+                                          section 6).  out_wt (the backward's operand) stays the plain transposed copy. */
+#define TIMHIP_DESC_INPROJ_SPLIT 32    /* the same for in_w ([3E, ld >= 2E]), l1_w ([FF, ld >= 2E]) and l2_w ([E, ld >= 2FF]): with all four */
+#define TIMHIP_DESC_L1_SPLIT 64        /* set every forward GEMM of the layer carries its weight to ~22 bits at twice the matrix */
+#define TIMHIP_DESC_L2_SPLIT 128       /* work (an opt-in margin mode, tim_amd: TIM_AMD_SPLIT_LAYER_WEIGHTS=all); default: out only */
 
 /* One encoder layer.  *_op are operand-dtype working copies made by timhip_prepare_weights:
  * w (as stored, [N,K]) and wt (transposed, [K,N]).  Biases and LayerNorm parameters are the
@@ -195,6 +204,12 @@ typedef struct TimEpi {
    * keeps its gradient OPERANDS multiplied by a power of two S (timhip_grad_scale); an input-gradient GEMM whose result joins
    * the fp32 gradient stream (TIMHIP_EPI_ADD_F32) passes 1/S here. */
   const float* acc_scale;
+  /* optional (0 = off): the A operand has only a_wrap_k columns and is read TWICE along the contraction, K = 2 * a_wrap_k
+   * (a multiple of 64; lda >= a_wrap_k): C = [A | A] B^T.  With B = [w_hi | w_lo] (the first two column blocks of a
+   * timhip_split3_many mode-0 copy of an fp32 weight) the product carries the weight to ~22 bits at twice the matrix work and
+   * no extra activation traffic - what TIMHIP_DESC_OUTPROJ_SPLIT uses.  16-bit precisions only. */
+  int32_t a_wrap_k;
+  int32_t reserved2;
 } TimEpi;
 
 /* n <= 6 independent small problems with the same epilogue as ONE launch (bf16; TIMHIP_EPI_STORE_F32, _ADD_F32, _STORE_T,

@@ -592,3 +592,30 @@ def test_split_operand_gemm(prec):
     assert torch.equal(A4[:, Kp:Kp + 1002], (src - hi4.float()).to(rt.op_dtype))
     assert (A4[:, 1002:Kp] == 0).all()
     assert torch.equal(A5[:, :K].float().cpu(), x.to(rt.op_dtype).float())
+
+
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("M,N,K", [(9920, 1024, 1024), (333, 256, 128), (64, 72, 64)])
+def test_gemm_weight_split_with_wrapped_a_operand(prec, M, N, K):
+    """TimEpi.a_wrap_k (round 3): C = [A | A] [w_hi | w_lo]^T - the A operand read twice along a contraction of 2K, the weight as
+    the first two column blocks of its split copy.  The product must carry the fp32 weight to ~20 bits (against 2^-9 / 2^-12 for
+    the plain 16-bit weight), on the ping-pong kernel (first shape) and the two-blocks-per-CU kernel; with the fused residual
+    epilogue the encoder layer's out-projection uses"""
+    rt = Runtime(prec)
+    A, Ar = to_op(rt, rnd(M, K, seed=1))
+    w = (rnd(N, K, seed=2, scale=K ** -0.5)).to(DEV)
+    W3 = torch.empty((N, 3 * _ru(K)), dtype=rt.op_dtype, device=DEV)
+    rt.split3([(w, N, K, K, W3)], mode=0)
+    ref = Ar.to(DEV).double() @ w.double().t()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    rt.gemm(L.EPI_STORE_F32, A, W3, M, N, 2 * K, out, N, rep=2, a_wrap_k=K)
+    torch.cuda.synchronize()
+    err = (out.double() - ref).abs().max().item()
+    plain = (Ar.to(DEV).double() @ w.to(rt.op_dtype).double().t() - ref).abs().max().item()
+    lim = {"fp16": 3e-6, "bf16": 3e-5}[prec] * max(1.0, ref.abs().max().item())
+    assert err <= lim, (err, plain)
+    assert err <= 0.1 * plain
+    res = rnd(M, N, seed=4).to(DEV)
+    rt.gemm(L.EPI_DROP_RES_F32, A, W3, M, N, 2 * K, out, N, res=res, ldres=N, rep=2, a_wrap_k=K)
+    torch.cuda.synchronize()
+    assert (out.double() - (ref + res.double())).abs().max().item() <= lim * 2

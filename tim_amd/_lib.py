@@ -49,7 +49,8 @@ class TimLayerGrads(C.Structure):
     _fields_ = [(n, vp) for n in _LG]
 
 
-DESC_ATTN_FP32, DESC_ATTN_BWD_ONE_KERNEL, DESC_WGRAD_OVERWRITE, DESC_WGRAD_SEPARATE = 1, 2, 4, 8   # TimDesc.reserved flags
+DESC_ATTN_FP32, DESC_ATTN_BWD_ONE_KERNEL, DESC_WGRAD_OVERWRITE, DESC_WGRAD_SEPARATE, DESC_OUTPROJ_SPLIT = 1, 2, 4, 8, 16
+DESC_INPROJ_SPLIT, DESC_L1_SPLIT, DESC_L2_SPLIT = 32, 64, 128   # TimDesc.reserved flags
 
 
 class TimCastItem(C.Structure):
@@ -64,7 +65,7 @@ class TimEpi(C.Structure):
     _fields_ = [("out0", vp), ("out1", vp), ("bias", vp), ("res", vp), ("aux", vp),
                 ("ld0", i32), ("ld1", i32), ("ldres", i32), ("ldaux", i32),
                 ("p_drop", f32), ("site", u32), ("seed", u64), ("mask", vp), ("ldmask", i32), ("reserved", i32),
-                ("ln_stats", vp), ("ln_w", vp), ("ln_b", vp), ("acc_scale", vp)]
+                ("ln_stats", vp), ("ln_w", vp), ("ln_b", vp), ("acc_scale", vp), ("a_wrap_k", i32), ("reserved2", i32)]
 
 
 class TimGemmItem(C.Structure):

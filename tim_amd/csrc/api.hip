@@ -112,7 +112,7 @@ TimEpi epi0() {
   TimEpi e;
   e.out0 = e.out1 = nullptr; e.bias = e.res = nullptr; e.aux = nullptr;
   e.ld0 = e.ld1 = e.ldres = e.ldaux = 0; e.p_drop = 0.f; e.site = 0; e.seed = 0;
-  e.mask = nullptr; e.ldmask = 0; e.reserved = 0;
+  e.mask = nullptr; e.ldmask = 0; e.reserved = 0; e.a_wrap_k = 0; e.reserved2 = 0;
   e.ln_stats = e.ln_w = e.ln_b = nullptr;
   e.acc_scale = nullptr;
   return e;
@@ -235,9 +235,15 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
   void* u = sv + L.u; void* h = sv + L.h; float* y2 = (float*)(sv + L.y2); float* st2 = (float*)(sv + L.st2);
 
   // 1. packed in-projection (F._in_projection_packed)
+  // (a *_SPLIT flag: that weight pointer is a split copy [hi | lo | ..] with row stride 3 K; the product runs over 2 K with the
+  //  activation operand read twice - TimEpi.a_wrap_k)
+  auto split = [&](int flag) { return (d.reserved & flag) != 0 && h16_storage(prec); };
   TimEpi e = epi0();
   e.out0 = qkv; e.ld0 = 3 * E; e.bias = w->in_b;
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, x_in_T, E, w->in_w, E, M, 3 * E, E, e, 1, s))) return rc;
+  if (split(TIMHIP_DESC_INPROJ_SPLIT)) {
+    e.a_wrap_k = E; e.reserved = 2;
+    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, x_in_T, E, w->in_w, 3 * E, M, 3 * E, 2 * E, e, 1, s))) return rc;
+  } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, x_in_T, E, w->in_w, E, M, 3 * E, E, e, 1, s))) return rc;
   // 2. structured attention
   if ((rc = tim_attention_fwd(d, qkv, o, lse, s))) return rc;
   // 3. out-projection + dropout1 + residual
@@ -249,7 +255,11 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
     e.res = x_in_prenorm; e.ln_stats = x_in_stats; e.ln_w = x_in_lnw; e.ln_b = x_in_lnb;
   }
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP1);
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, E, M, E, E, e, 1, s))) return rc;
+  if (split(TIMHIP_DESC_OUTPROJ_SPLIT)) {
+    // out_w = [w_hi | w_lo | ..] (row stride 3E): o [w_hi | w_lo]^T over K = 2E, o read twice - the weight to ~22 bits
+    e.a_wrap_k = E; e.reserved = 2;
+    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, 3 * E, M, E, 2 * E, e, 1, s))) return rc;
+  } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, E, M, E, E, e, 1, s))) return rc;
   // 4. norm1.  The kernel is HBM-bound with idle VALU: it also draws the keep-bits of the FFN dropout (same Philox
   //    stream as the epilogues would use), which the linear1 epilogue and, in the backward, the gelu' epilogue read
   uint8_t* fmask = d.p_drop > 0.f ? (uint8_t*)(sv + L.ffn_mask) : nullptr;
@@ -262,13 +272,19 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
   e.mask = fmask; e.ldmask = FF / 8;
   // (out1 = `u` holds dropmask * gelu'(linear1 output): the factor the backward multiplies with - it never needs the
   //  pre-activations themselves, so its epilogue is a plain multiply)
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_G2, x1t, E, w->l1_w, E, M, FF, E, e, 1, s))) return rc;
+  if (split(TIMHIP_DESC_L1_SPLIT)) {
+    e.a_wrap_k = E; e.reserved = 2;
+    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_G2, x1t, E, w->l1_w, 3 * E, M, FF, 2 * E, e, 1, s))) return rc;
+  } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_GELU_DROP_G2, x1t, E, w->l1_w, E, M, FF, E, e, 1, s))) return rc;
   // 6. linear2 + dropout2 + residual
   e = epi0();
   e.out0 = y2; e.ld0 = E; e.bias = w->l2_b; e.ldres = E;
   e.res = y1; e.ln_stats = st1; e.ln_w = w->n1_w; e.ln_b = w->n1_b;   // residual = norm1(y1), normalised by the epilogue
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP2);
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, FF, M, E, FF, e, 1, s))) return rc;
+  if (split(TIMHIP_DESC_L2_SPLIT)) {
+    e.a_wrap_k = FF; e.reserved = 2;
+    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, 3 * FF, M, E, 2 * FF, e, 1, s))) return rc;
+  } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, FF, M, E, FF, e, 1, s))) return rc;
   // 7. norm2 (x_out == NULL: only the operand copy and the statistics)
   return tim_layernorm_fwd(prec, y2, M, E, E, 0, w->n2_w, w->n2_b, x_out, E, x_out_T, E, st2, s);
 }

@@ -86,9 +86,11 @@ __device__ __forceinline__ void gemm_nt_h16_body(
     b_off32[i] = (uint32_t)(((size_t)min(n0 + row, N - 1) * ldb + c * 8) * 2);
   }
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  const int a_wrap = e.a_wrap > 0 ? e.a_wrap * (64 / BKT) : 0x7fffffff;   // K-steps after which the A operand repeats
   auto stage = [&](int kt, int buf) {
     const uint32_t base = lds0 + buf * ST_BYTES;
-    glds16_xn<A_INSTR>(reinterpret_cast<const char*>(A) + (size_t)kt * BKT * 2, a_off32, base + wave * A_INSTR * 1024);
+    const int kta = kt >= a_wrap ? kt - a_wrap : kt;   // (the operand repeats once: K = 2 * a_wrap_k)
+    glds16_xn<A_INSTR>(reinterpret_cast<const char*>(A) + (size_t)kta * BKT * 2, a_off32, base + wave * A_INSTR * 1024);
     glds16_xn<B_INSTR>(reinterpret_cast<const char*>(B) + (size_t)kt * BKT * 2, b_off32,
                        base + A_BYTES + wave * B_INSTR * 1024);
   };
@@ -706,7 +708,9 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
   if (M <= 0 || N <= 0 || K <= 0) return TIMHIP_EINVAL;
   if (!valid_precision(precision)) return TIMHIP_EUNSUPPORTED;
   const int Kp = round_up(K, 64);
-  if (lda % 64 || ldb % 64 || lda < Kp || ldb < Kp) return TIMHIP_EALIGN;
+  if (te.a_wrap_k < 0 || te.a_wrap_k % 64 || (te.a_wrap_k > 0 && (Kp != 2 * te.a_wrap_k || !h16_storage(precision) || splitk > 1)))
+    return TIMHIP_EUNSUPPORTED;   // A repeats once after a_wrap_k columns (K = 2 a_wrap_k): whole 64-deep steps, 16-bit kernels, no split of the contraction
+  if (lda % 64 || ldb % 64 || lda < (te.a_wrap_k > 0 ? te.a_wrap_k : Kp) || ldb < Kp) return TIMHIP_EALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return TIMHIP_EALIGN;
   if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldb * 2 >= (1ull << 32)) return TIMHIP_EUNSUPPORTED;  // 32-bit lane offsets
   if (splitk > 1 && epi != TIMHIP_EPI_ATOMIC_F32 && epi != TIMHIP_EPI_STORE_F32) return TIMHIP_EINVAL;
@@ -718,6 +722,7 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
   e.mask = (const uint8_t*)te.mask; e.ldmask = te.ldmask;
   e.ln_stats = te.ln_stats; e.ln_w = te.ln_w; e.ln_b = te.ln_b;
   e.acc_scale = te.acc_scale;
+  e.a_wrap = te.a_wrap_k / 64;
   if (e.ln_stats && (epi != TIMHIP_EPI_DROP_RES_F32 || !e.res || !e.ln_w || !e.ln_b)) return TIMHIP_EINVAL;
   e.slab_stride = splitk > 1 ? (long long)M * te.ld0 : 0;
 

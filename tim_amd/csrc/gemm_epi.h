@@ -23,6 +23,8 @@ struct EpiDev {
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
   int vec8; // the operand-dtype outputs / aux of this epilogue also allow 8-element (16-byte) accesses
   long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)
+  int a_wrap;   // 0, or the number of 64-deep contraction steps after which the A operand repeats (TimEpi.a_wrap_k / 64): the
+                // product of an activation matrix with a weight matrix split into [hi | lo] column blocks reads A twice
 };
 
 template <int EPI, typename T>

@@ -181,15 +181,17 @@ template <int TMW, int G> struct PpShare {
 template <typename HT, int TMW, int G, bool PROF = false>
 __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* __restrict__ B, int nk, const char* lds, uint32_t lds0,
                                             const uint32_t (&off)[7], int first_piece, int a_frag, int b_frag, int c0, int c1,
-                                            f32x4_t (&acc)[PP_TNW][TMW], long long* prof = nullptr, bool primed = false) {
+                                            f32x4_t (&acc)[PP_TNW][TMW], long long* prof = nullptr, bool primed = false,
+                                            int a_wrap = 0x7fffffff) {
   constexpr int BM = 32 * TMW, A_PIECES = BM / 8;
   constexpr int A_BYTES = BM * PP_ROWB, B_BYTES = PP_BN * PP_ROWB, ST_BYTES = A_BYTES + B_BYTES;
   constexpr int CNT = PpShare<TMW, G>::CNT;
 
   // this wave's i-th piece of stage `kt`, into ring slot `slot`
-  auto piece = [&](int kt, int slot, int i) {
+  auto piece = [&](int kt, int slot, int i) {   // (a_wrap: contraction steps after which the A operand repeats, EpiDev.a_wrap)
     const int p = first_piece + i;
-    const char* g = reinterpret_cast<const char*>(p < A_PIECES ? (const void*)A : (const void*)B) + (size_t)kt * PP_ROWB;
+    const char* g = p < A_PIECES ? reinterpret_cast<const char*>(A) + (size_t)(kt >= a_wrap ? kt - a_wrap : kt) * PP_ROWB
+                                 : reinterpret_cast<const char*>(B) + (size_t)kt * PP_ROWB;
     glds16_s(uniform_ptr(g), off[i], lds0 + slot * ST_BYTES + p * 1024);
   };
 
@@ -311,8 +313,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const HT* __restrict__ 
   const int nk = K / 64;
   long long prof[4] = {0, 0, 0, 0}, t_begin = 0, w_begin = 0;
   if constexpr (PROF) { t_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
-  if (wm == 0) pp_mainloop<HT, TMW, 0, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof);
-  else pp_mainloop<HT, TMW, 1, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof);
+  const int a_wrap = e.a_wrap > 0 ? e.a_wrap : 0x7fffffff;
+  if (wm == 0) pp_mainloop<HT, TMW, 0, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof, false, a_wrap);
+  else pp_mainloop<HT, TMW, 1, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof, false, a_wrap);
   long long t_loop = 0;
   if constexpr (PROF) t_loop = __builtin_readcyclecounter();
 
@@ -703,7 +706,7 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     // current round's tail; what a round costs beyond its main loop is the epilogue's own drain)
     const int tiles = (int)grid.x, tpb = (tiles + 255) / 256;
     const char* ptv = getenv("TIMHIP_GEMM_PT");
-    if (tpb >= 2 && tpb <= 4 && tiles % tpb == 0 && ((N + PP_BN - 1) / PP_BN) % tpb == 0 && K >= 128 && ptv && ptv[0] == '1') {
+    if (tpb >= 2 && tpb <= 4 && tiles % tpb == 0 && ((N + PP_BN - 1) / PP_BN) % tpb == 0 && K >= 128 && ptv && ptv[0] == '1' && e.a_wrap == 0) {
       static PerDeviceOnce pt_attr;
       if (pt_attr.first())
         (void)hipFuncSetAttribute((const void*)gemm_nt_pt_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -713,7 +716,7 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     }
   }
   const char* ldv = getenv("TIMHIP_GEMM_LD");
-  if (ldv && ldv[0] == '1') {   // (measured: within +-0.5 % of the 8-wave kernel in the step, whichever epilogues take it)
+  if (ldv && ldv[0] == '1' && e.a_wrap == 0) {   // (measured: within +-0.5 % of the 8-wave kernel in the step, whichever epilogues take it)
     hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
     return;
   }
@@ -750,7 +753,7 @@ int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B
   // pipe, is what bounds these loops; the hidden epilogues do not pay for that - DESIGN.md section 5c);
   // TIMHIP_GEMM_DG_OFFSET: barriers group 1 runs behind group 0 (odd)
   const char* dgv = getenv("TIMHIP_GEMM_DG");
-  if (dgv && dgv[0] == '1' && tim_gemm_dg_ok(M, N, K, e)) {
+  if (dgv && dgv[0] == '1' && tim_gemm_dg_ok(M, N, K, e) && e.a_wrap == 0) {
     const char* ov = getenv("TIMHIP_GEMM_DG_OFFSET");
     int off = ov ? atoi(ov) : 9;
     if (off < 1) off = 1;

@@ -66,6 +66,14 @@ class Runtime:
         # logits) - keep more bits (oracle site analysis).  Those two run with SPLIT operands: every
         # fp32 value as hi + lo fp16 column blocks, one fp16 GEMM over the tripled contraction length (timhip_split3_many).
         self.split = precision == "fp16"
+        # ... and the encoder layers' out-projection WEIGHT (round 3): a weight's rounding error is the same for every token and
+        # survives the attention average (an activation's does not); out_proj is the largest such term at the smallest GEMM of
+        # the layer - its forward runs [o | o] [w_hi | w_lo]^T over K = 2E (TIM_AMD_SPLIT_OUTPROJ=0: off)
+        # TIM_AMD_SPLIT_LAYER_WEIGHTS = out (default) | none | all: "all" splits the weights of all four forward GEMMs of a layer -
+        # the opt-in margin mode (twice the forward matrix work of the layers)
+        sel = os.environ.get("TIM_AMD_SPLIT_LAYER_WEIGHTS", "out") if self.split else "none"
+        self.layer_split = {"none": (), "out": ("out",), "all": ("in", "out", "l1", "l2")}.get(sel, ("out",))
+        self.split_outproj = "out" in self.layer_split
         self._wsplit = {}
         self._wsparams = {}  # id(param) -> weakref: every weight this runtime has split
         # fp16 backward: gradient operands are stored times a power of two chosen per backward pass from the incoming
@@ -164,20 +172,29 @@ class Runtime:
             call("timhip_cast_weights", self.prec, C.cast(arr, C.c_void_p), len(items), _stream())
             self._wcache.update(fresh)
 
-    def weight_split(self, p):
-        """[N, 3 ru(K)] split copy [hi | hi | lo] of an fp32 weight [N, K] (split-operand sites of the fp16 mode).  As in
-        `weight`, one stale copy refreshes every stale split copy this runtime holds in the same grouped launch."""
-        ent = self._wsplit.get(id(p))
+    def layer_split_flags(self):
+        f = {"in": L.DESC_INPROJ_SPLIT, "out": L.DESC_OUTPROJ_SPLIT, "l1": L.DESC_L1_SPLIT, "l2": L.DESC_L2_SPLIT}
+        return sum(f[k] for k in self.layer_split)
+
+    def weight_split(self, p, mode=1):
+        """split copy of an fp32 weight [N, K] as [N, 3 ru(K)] 16-bit column blocks: mode 1 = [hi | hi | lo] (the weight side
+        of a three-term split product: time MLP, heads), mode 0 = [hi | lo | hi] (its first two blocks are the weight side of
+        the TWO-term product [x | x] [w_hi | w_lo]^T of the encoder layers' out-projection, TIMHIP_DESC_OUTPROJ_SPLIT).  As in
+        `weight`, one stale copy refreshes every stale split copy of that mode in the same grouped launch."""
+        key = (id(p), mode)
+        ent = self._wsplit.get(key)
         ver = (p.data_ptr(), p._version)
         if ent is None or ent[0] != ver or ent[1].device != p.device:
-            self._wsparams[id(p)] = weakref.ref(p)
-            self._refresh_split(p.device)
-            ent = self._wsplit[id(p)]
+            self._wsparams[key] = weakref.ref(p)
+            self._refresh_split(p.device, mode)
+            ent = self._wsplit[key]
         return ent[1]
 
-    def _refresh_split(self, dev):
+    def _refresh_split(self, dev, mode):
         items, fresh = [], {}
         for key, ref in list(self._wsparams.items()):
+            if key[1] != mode:
+                continue
             q = ref()
             if q is None:
                 self._wsparams.pop(key, None)
@@ -196,7 +213,7 @@ class Runtime:
             items.append((src, N, K, K, buf))
             fresh[key] = (ver, buf, src)
         if items:
-            self.split3(items, mode=1)
+            self.split3(items, mode=mode)
             self._wsplit.update(fresh)
 
     def split3(self, items, mode, relu=False):
@@ -252,14 +269,14 @@ class Runtime:
 
     # ---- thin op wrappers ------------------------------------------------------------------------
     def gemm(self, epi, A, B, M, N, K, out0, ld0, out1=None, ld1=0, bias=None, res=None, ldres=0, aux=None,
-             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0, ln=None, acc_scale=None, rep=0):
+             ldaux=0, p_drop=0.0, seed=0, site=0, splitk=1, mask=None, ldmask=0, ln=None, acc_scale=None, rep=0, a_wrap_k=0):
         """ln = (stats[M,2], gamma[N], beta[N]): EPI_DROP_RES_F32 takes LayerNorm(res) as its residual (TimEpi.ln_*);
         acc_scale: device pointer (int) of a scalar multiplied into the accumulators, or None"""
         if M == 0 or N == 0:
             return
         st_, g_, b_ = ln if ln is not None else (None, None, None)
         e = L.TimEpi(ptr(out0), ptr(out1), ptr(bias), ptr(res), ptr(aux), ld0, ld1, ldres, ldaux,
-                     float(p_drop), site, seed, ptr(mask), ldmask, rep, ptr(st_), ptr(g_), ptr(b_), acc_scale)
+                     float(p_drop), site, seed, ptr(mask), ldmask, rep, ptr(st_), ptr(g_), ptr(b_), acc_scale, a_wrap_k, 0)
         call("timhip_gemm_nt", self.prec, epi, ptr(A), A.stride(0), ptr(B), B.stride(0), M, N, K,
              C.byref(e), splitk, _stream())
 
@@ -612,7 +629,7 @@ class EncoderFn(torch.autograd.Function):
              ptr(te_c), T, ptr(mod), p_seq, seed, L.SITE_SEQ, ptr(xs_f[0]), ptr(xs_t[0]), st)
 
         # ---- L post-norm encoder layers (transformers.py:44-45,92-111)
-        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, 0, None)
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, rt.layer_split_flags(), None)
         saved_bytes = L.load().timhip_layer_saved_bytes(C.byref(desc))
         ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
         ws = model._workspace(ws_bytes, dev)

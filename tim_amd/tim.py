@@ -353,10 +353,12 @@ class TIM(nn.Module):
     @staticmethod
     def _layer_params(rt, P, pre):
         from .functional import _f32c
-        keep = [rt.weight(P[pre + "self_attn.in_proj_weight"]), rt.weight(P[pre + "self_attn.in_proj_weight"], True),
-                rt.weight(P[pre + "self_attn.out_proj.weight"]), rt.weight(P[pre + "self_attn.out_proj.weight"], True),
-                rt.weight(P[pre + "linear1.weight"]), rt.weight(P[pre + "linear1.weight"], True),
-                rt.weight(P[pre + "linear2.weight"]), rt.weight(P[pre + "linear2.weight"], True)]
+        def fwd_w(key, name):   # the forward operand of a Linear: plain 16-bit copy, or its split copy (Runtime.layer_split)
+            return rt.weight_split(P[pre + name], mode=0) if key in rt.layer_split else rt.weight(P[pre + name])
+        keep = [fwd_w("in", "self_attn.in_proj_weight"), rt.weight(P[pre + "self_attn.in_proj_weight"], True),
+                fwd_w("out", "self_attn.out_proj.weight"), rt.weight(P[pre + "self_attn.out_proj.weight"], True),
+                fwd_w("l1", "linear1.weight"), rt.weight(P[pre + "linear1.weight"], True),
+                fwd_w("l2", "linear2.weight"), rt.weight(P[pre + "linear2.weight"], True)]
         keep += [_f32c(P[pre + n]) for n in ("self_attn.in_proj_bias", "self_attn.out_proj.bias", "linear1.bias",
                                              "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight",
                                              "norm2.bias")]

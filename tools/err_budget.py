@@ -87,6 +87,9 @@ def main():
     rep("  linear1", lambda n: n.endswith("linear1.weight"))
     rep("  linear2", lambda n: n.endswith("linear2.weight"))
     rep("layers except in_proj + embedders", lambda n: (layer(n) and not n.endswith("in_proj_weight")) or "embedder" in n)
+    # the fp16 mode with out_proj's WEIGHTS exact (split [hi | lo], round 3): activations of out_proj still rounded
+    state_w = lambda n: (layer(n) and not n.endswith("out_proj.weight")) or "embedder" in n
+    rep("fp16 mode, out_proj weights exact (approx: others both + out_proj x)", lambda n: True if state_w(n) else False)
     for l in range(cfg.num_layers):
         rep("  layer %d only" % l, lambda n, l=l: (".layers.%d." % l) in n)
 
