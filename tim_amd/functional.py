@@ -66,13 +66,14 @@ class Runtime:
         # logits) - keep more bits (oracle site analysis).  Those two run with SPLIT operands: every
         # fp32 value as hi + lo fp16 column blocks, one fp16 GEMM over the tripled contraction length (timhip_split3_many).
         self.split = precision == "fp16"
-        # ... and the encoder layers' out-projection WEIGHT (round 3): a weight's rounding error is the same for every token and
-        # survives the attention average (an activation's does not); out_proj is the largest such term at the smallest GEMM of
-        # the layer - its forward runs [o | o] [w_hi | w_lo]^T over K = 2E (TIM_AMD_SPLIT_OUTPROJ=0: off)
-        # TIM_AMD_SPLIT_LAYER_WEIGHTS = out (default) | none | all: "all" splits the weights of all four forward GEMMs of a layer -
-        # the opt-in margin mode (twice the forward matrix work of the layers)
-        sel = os.environ.get("TIM_AMD_SPLIT_LAYER_WEIGHTS", "out") if self.split else "none"
-        self.layer_split = {"none": (), "out": ("out",), "all": ("in", "out", "l1", "l2")}.get(sel, ("out",))
+        # Opt-in margin modes (round 3), TIM_AMD_SPLIT_LAYER_WEIGHTS = none (default) | out | all, or `rt.layer_split = (...)`
+        # before the first forward: the WEIGHTS of the encoder layers' forward GEMMs as hi + lo halves - a weight's rounding error
+        # is the same for every token and survives the attention average (an activation's does not).  The product runs
+        # [x | x] [w_hi | w_lo]^T over K = 2K with the activation operand read twice (TimEpi.a_wrap_k).  Measured on C2a, B = 64
+        # (DESIGN.md section 6): none 8.1e-4 max logit error; "out" (the out-projection: largest single term, smallest GEMM)
+        # 7.2e-4 at +2 % of the step; "all" 5.3e-4 at +15 %.
+        sel = os.environ.get("TIM_AMD_SPLIT_LAYER_WEIGHTS", "none") if self.split else "none"
+        self.layer_split = {"none": (), "out": ("out",), "all": ("in", "out", "l1", "l2")}.get(sel, ())
         self.split_outproj = "out" in self.layer_split
         self._wsplit = {}
         self._wsparams = {}  # id(param) -> weakref: every weight this runtime has split
