@@ -178,7 +178,11 @@ template <int TMW, int G> struct PpShare {
   static_assert(4 * 7 + 4 * 6 == 2 * TMW * 2 + 32, "the share table is written for the 160 x 256 tile");
 };
 
-template <typename HT, int TMW, int G, bool PROF = false>
+// ABL (tuning builds): 0 the kernel; 1 no DMA in the loop (the ring keeps its prologue contents); 2 no MFMAs; 3 DMA only (no
+// fragment reads, no MFMAs); LATE: this wave's pieces of stage t + 1 are waited for at the END of MFMA phase t (counted wait,
+// the pieces of stage t + 2 stay in flight) instead of at the end of LOAD phase t: half a step more flight time
+// (G0 only: G1's pieces of stage t + 1 are read by G0 half a step after G1's LOAD phase t ends, so G1 has to keep its wait there)
+template <typename HT, int TMW, int G, bool PROF = false, int ABL = 0, bool LATE_ = false>
 __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* __restrict__ B, int nk, const char* lds, uint32_t lds0,
                                             const uint32_t (&off)[7], int first_piece, int a_frag, int b_frag, int c0, int c1,
                                             f32x4_t (&acc)[PP_TNW][TMW], long long* prof = nullptr, bool primed = false,
@@ -186,10 +190,16 @@ __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* 
   constexpr int BM = 32 * TMW, A_PIECES = BM / 8;
   constexpr int A_BYTES = BM * PP_ROWB, B_BYTES = PP_BN * PP_ROWB, ST_BYTES = A_BYTES + B_BYTES;
   constexpr int CNT = PpShare<TMW, G>::CNT;
+  constexpr bool LATE = LATE_ && G == 0;
 
   // this wave's i-th piece of stage `kt`, into ring slot `slot`
   auto piece = [&](int kt, int slot, int i) {   // (a_wrap: contraction steps after which the A operand repeats, EpiDev.a_wrap)
     const int p = first_piece + i;
+    if constexpr (ABL == 4) {   // tuning: what would tile-major operands buy?  off[] = packed offsets (tile, piece, lane), see the kernel
+      const char* g = p < A_PIECES ? reinterpret_cast<const char*>(A) + (size_t)kt * A_BYTES : reinterpret_cast<const char*>(B) + (size_t)kt * B_BYTES;
+      glds16_s(uniform_ptr(g), off[i], lds0 + slot * ST_BYTES + p * 1024);
+      return;
+    }
     const char* g = p < A_PIECES ? reinterpret_cast<const char*>(A) + (size_t)(kt >= a_wrap ? kt - a_wrap : kt) * PP_ROWB
                                  : reinterpret_cast<const char*>(B) + (size_t)kt * PP_ROWB;
     glds16_s(uniform_ptr(g), off[i], lds0 + slot * ST_BYTES + p * 1024);
@@ -231,15 +241,19 @@ __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* 
     const char* base = lds + slot * ST_BYTES;
     const int nslot = slot >= 1 ? slot - 1 : PP_NST - 1;   // (t + 2) % 3
     // ---- LOAD phase: the fragments of step t
+    if constexpr (ABL < 3) {   // (3 ... 8: DMA only)
 #pragma unroll
-    for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c0);
+      for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c0);
 #pragma unroll
-    for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c0);
+      for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c0);
 #pragma unroll
-    for (int j = 0; j < TMW; ++j) xb[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c1);
+      for (int j = 0; j < TMW; ++j) xb[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c1);
 #pragma unroll
-    for (int i = 0; i < PP_TNW; ++i) wc[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c1);
-    glds_wait<0>();   // every piece of stage t + 1 issued by this wave (during the previous MFMA phase) has landed
+      for (int i = 0; i < PP_TNW; ++i) wc[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c1);
+    }
+    if constexpr (ABL == 5) glds_wait<2 * CNT>();        // tuning, DMA only: two / four more stages in flight than the ring allows
+    else if constexpr (ABL == 6) glds_wait<4 * CNT>();   // (nobody reads the data): is the DMA stream latency- or rate-bound?
+    else if constexpr (!LATE) glds_wait<0>();   // every piece of stage t + 1 issued by this wave (during the previous MFMA phase) has landed
     pp_wait_lds();
     lap(t_load);
     pp_barrier();
@@ -251,14 +265,21 @@ __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* 
       for (int j = 0; j < TMW; ++j)
 #pragma unroll
         for (int i = 0; i < PP_TNW; ++i) {
-          acc[i][j] = half == 0 ? mfma16x16<HT>(wb[i], xa[j], acc[i][j]) : mfma16x16<HT>(wc[i], xb[j], acc[i][j]);
+          if constexpr (ABL < 2) acc[i][j] = half == 0 ? mfma16x16<HT>(wb[i], xa[j], acc[i][j]) : mfma16x16<HT>(wc[i], xb[j], acc[i][j]);
+          else if constexpr (ABL == 2) {   // keep the fragments alive
+            if (half == 0) asm volatile("" ::"v"(wb[i]), "v"(xa[j])); else asm volatile("" ::"v"(wc[i]), "v"(xb[j]));
+          }
           const int q = half * (TMW * PP_TNW) + j * PP_TNW + i, k = q / 5;
-          if (MORE && q % 5 == 2 && k < CNT) {
+          if (MORE && ABL != 1 && q % 5 == 2 && k < CNT) {
             __builtin_amdgcn_sched_barrier(0);
             piece(t + 2, nslot, k);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+    if constexpr (LATE) {   // stage t + 1 (issued during MFMA phase t - 1) has landed; this phase's pieces of stage t + 2 may fly
+      __builtin_amdgcn_sched_barrier(0);
+      if (MORE && ABL != 1) glds_wait<CNT>(); else glds_wait<0>();
+    }
     lap(t_mma);
     pp_barrier();
     lap(t_bar_b);
@@ -271,7 +292,7 @@ __device__ __forceinline__ void pp_mainloop(const HT* __restrict__ A, const HT* 
   if constexpr (PROF) { prof[0] = t_load; prof[1] = t_bar_a; prof[2] = t_mma; prof[3] = t_bar_b; }
 }
 
-template <typename HT, int EPI, int TMW, bool PROF = false>
+template <typename HT, int EPI, int TMW, bool PROF = false, int ABL = 0, bool LATE = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
                                                          int M, int N, int K, EpiDev e) {
   constexpr int BM = 32 * TMW;
@@ -296,6 +317,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const HT* __restrict__ 
     const int row = (is_a ? p : p - BM / 8) * 8 + lrow;    // row of the A / B tile
     const int c = (lchunk ^ kswz<64>(row)) * 8;
     off[i] = is_a ? (uint32_t)(((size_t)min(m0 + row, M - 1) * lda + c) * 2) : (uint32_t)(((size_t)min(n0 + row, N - 1) * ldb + c) * 2);
+    if constexpr (ABL == 7)   // tuning, DMA only: every block stages tile (0, 0) - all L2 hits after the first touch
+      off[i] = is_a ? (uint32_t)(((size_t)row * lda + c) * 2) : (uint32_t)(((size_t)row * ldb + c) * 2);
+    if constexpr (ABL == 8)   // tuning, DMA only: every block of an XCD stages the XCD's first tile - one set of misses per XCD and step
+      off[i] = is_a ? (uint32_t)(((size_t)min((blockIdx.x & 7) * BM + row, M - 1) * lda + c) * 2) : (uint32_t)(((size_t)row * ldb + c) * 2);
+    if constexpr (ABL == 4)   // operand tiles [tile][K / 64][rows][64]: a stage's tile is one contiguous block, a piece 1 KiB of it
+      off[i] = is_a ? (uint32_t)((size_t)(m0 / BM) * (K / 64) * A_BYTES + p * 1024 + lane * 16)
+                    : (uint32_t)((size_t)(n0 / PP_BN) * (K / 64) * (PP_BN * PP_ROWB) + (p - BM / 8) * 1024 + lane * 16);
   }
   // fragment reads: lane -> (row = lane & 15 of a 16-row tile, 16-B chunk 4 half + (lane >> 4)), swizzled like the stage
   const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
@@ -314,8 +342,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const HT* __restrict__ 
   long long prof[4] = {0, 0, 0, 0}, t_begin = 0, w_begin = 0;
   if constexpr (PROF) { t_begin = __builtin_readcyclecounter(); w_begin = wall_clock64(); }
   const int a_wrap = e.a_wrap > 0 ? e.a_wrap : 0x7fffffff;
-  if (wm == 0) pp_mainloop<HT, TMW, 0, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof, false, a_wrap);
-  else pp_mainloop<HT, TMW, 1, PROF>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof, false, a_wrap);
+  if (wm == 0) pp_mainloop<HT, TMW, 0, PROF, ABL, LATE>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof, false, a_wrap);
+  else pp_mainloop<HT, TMW, 1, PROF, ABL, LATE>(A, B, nk, lds, lds0, off, first_piece, a_frag, b_frag, c0, c1, acc, prof, false, a_wrap);
   long long t_loop = 0;
   if constexpr (PROF) t_loop = __builtin_readcyclecounter();
 
@@ -412,15 +440,90 @@ __global__ __launch_bounds__(512) void gemm_nt_pt_kernel(const HT* __restrict__ 
 // Waves 0-7 keep the merged LOAD / MFMA phases without a single DMA instruction; waves 8-11 issue the stage's 52 pieces as 13
 // groups of four (A: groups 0-4, B: groups 5-12; loaders take 4 / 3 / 3 / 3 groups), two groups per wave in window A_t, the rest
 // in window B_t.
-template <typename HT, int TMW, int G>
-__device__ __forceinline__ void pl_consume(int nk, const char* lds, int a_frag, int b_frag, int c0, int c1, f32x4_t (&acc)[PP_TNW][TMW]) {
+// L2 prefetch (round 3): the DMA stream of the loop is what bounds it (the loop with nothing but its DMA pieces takes as long as
+// the whole loop), and a fifth of it is the misses: 18-30 % of a stage's lines are first touches of this XCD's L2, they return
+// from the fabric in 1-2 us, and loads return in order - nearly every 8-line piece waits for one.  With every line an L2 hit the
+// DMA-only loop is 20-30 % shorter.  So each tile touches ITS SHARE of the lines its XCD will need pf_dist stages later with one
+// plain dword load per line: the A panel's 160 rows are split between the tiles_n column tiles that share it, the B tile's 256
+// rows between the 8 consecutive row panels that run on one XCD.  One load instruction per step from wave 0 (A) and wave 4 (B)
+// of the consumer group, which have no other vector-memory operation in the loop (loads return in order: a wave that also
+// issued DMA pieces would wait for its prefetches).  The loaded dword is never used.
+struct PlPrefetch { const void* base; uint32_t off; int on, dist; };
+
+// ONEBAR (gemm_nt_ld kernel with one barrier per contraction step): with no DMA instruction and no vmcnt wait in the consumer
+// waves, the antiphase of the two groups can come from program order instead of a second barrier -
+//     interval t (between barriers B_t and B_t+1):   G1:  LOAD(t);  MFMA(t)          G0:  MFMA(t - 1);  LOAD(t)
+//     loaders:  issue stage t + 2 -> slot (t + 2) % 3;  wait until stage t + 1 has landed;  barrier
+// G1's MFMAs follow G0's on the pipe without a barrier in between, G0 reads its fragments under G1's MFMAs, and a stage has one
+// to two whole steps of flight time (issued in interval t, waited for at the end of interval t + 1, read in interval t + 2).
+//   RAW  stage t is read in interval t by both groups; the loaders waited for it before B_t.
+//   WAR  slot (t + 2) % 3 = (t - 1) % 3 is refilled in interval t; both groups read stage t - 1 in interval t - 1 (lgkmcnt
+//        before B_t).
+template <typename HT, int TMW, int G, bool ONEBAR = false>
+__device__ __forceinline__ void pl_consume(int nk, const char* lds, int a_frag, int b_frag, int c0, int c1, f32x4_t (&acc)[PP_TNW][TMW],
+                                           const PlPrefetch& pf) {
   constexpr int BM = 32 * TMW;
   constexpr int ST_BYTES = (BM + PP_BN) * PP_ROWB;
+  if constexpr (ONEBAR) {
+    vec8<HT> xa[TMW], wb[PP_TNW], xb[TMW], wc[PP_TNW];
+    uint32_t pf_sink = 0;
+    auto load = [&](int slot) {
+      const char* base = lds + slot * ST_BYTES;
+#pragma unroll
+      for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c0);
+#pragma unroll
+      for (int i = 0; i < PP_TNW; ++i) wb[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c0);
+#pragma unroll
+      for (int j = 0; j < TMW; ++j) xb[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c1);
+#pragma unroll
+      for (int i = 0; i < PP_TNW; ++i) wc[i] = *reinterpret_cast<const vec8<HT>*>(base + b_frag + i * (16 * PP_ROWB) + c1);
+    };
+    auto mma = [&]() {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int j = 0; j < TMW; ++j)
+#pragma unroll
+          for (int i = 0; i < PP_TNW; ++i)
+            acc[i][j] = half == 0 ? mfma16x16<HT>(wb[i], xa[j], acc[i][j]) : mfma16x16<HT>(wc[i], xb[j], acc[i][j]);
+    };
+    int slot = 0;
+    pp_barrier();   // B_0
+    for (int t = 0; t < nk; ++t) {
+      if (pf.on && t + pf.dist < nk) {
+        const char* g = reinterpret_cast<const char*>(pf.base) + pf.off + (size_t)(t + pf.dist) * PP_ROWB;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(g) : "memory");
+      }
+      if constexpr (G == 1) {
+        load(slot);
+        pp_wait_lds();
+        __builtin_amdgcn_sched_barrier(0);
+        mma();
+      } else {
+        if (t > 0) mma();
+        __builtin_amdgcn_sched_barrier(0);
+        load(slot);
+        pp_wait_lds();
+      }
+      pp_barrier();   // B_t+1
+      slot = slot + 1 == PP_NST ? 0 : slot + 1;
+    }
+    if constexpr (G == 0) mma();   // MFMA(nk - 1)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");
+    return;
+  }
   pp_barrier();                        // b0
   if constexpr (G == 1) pp_barrier();
   vec8<HT> xa[TMW], wb[PP_TNW], xb[TMW], wc[PP_TNW];
   int slot = 0;
+  uint32_t pf_sink = 0;
   for (int t = 0; t < nk; ++t) {
+    if (pf.on && t + pf.dist < nk) {
+      const char* g = reinterpret_cast<const char*>(pf.base) + pf.off + (size_t)(t + pf.dist) * PP_ROWB;
+      // "+v": the sink stays one dedicated register from here to the wait after the loop - the data returns asynchronously, a
+      // register the compiler considered dead after the asm would be reused (e.g. for the next address) and overwritten late
+      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(g) : "memory");
+    }
     const char* base = lds + slot * ST_BYTES;
 #pragma unroll
     for (int j = 0; j < TMW; ++j) xa[j] = *reinterpret_cast<const vec8<HT>*>(base + a_frag + j * (16 * PP_ROWB) + c0);
@@ -443,9 +546,10 @@ __device__ __forceinline__ void pl_consume(int nk, const char* lds, int a_frag, 
     slot = slot + 1 == PP_NST ? 0 : slot + 1;
   }
   if constexpr (G == 0) pp_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");   // the sink register is free for reuse only now
 }
 
-template <typename HT, int TMW>
+template <typename HT, int TMW, bool ONEBAR = false>
 __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb, int M, int N, int m0, int n0,
                                         int nk, uint32_t lds0, int lw, int lane) {
   constexpr int BM = 32 * TMW, A_GROUPS = BM / 32;
@@ -477,6 +581,20 @@ __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const
   }
   pp_barrier();   // b0
   int slot = 0;
+  if constexpr (ONEBAR) {
+    for (int t = 0; t < nk; ++t) {
+      const int nslot = slot >= 1 ? slot - 1 : PP_NST - 1;
+      if (t + 2 < nk) {
+        group(t + 2, nslot, 0); group(t + 2, nslot, 1); group(t + 2, nslot, 2); group(t + 2, nslot, 3);
+        if (lw == 0) glds_wait<16>(); else glds_wait<12>();   // stage t + 1 (issued one interval earlier) has landed
+      } else {
+        glds_wait<0>();
+      }
+      pp_barrier();        // B_t+1
+      slot = slot + 1 == PP_NST ? 0 : slot + 1;
+    }
+    return;
+  }
   for (int t = 0; t < nk; ++t) {
     const int nslot = slot >= 1 ? slot - 1 : PP_NST - 1;
     const bool more = t + 2 < nk;
@@ -494,9 +612,9 @@ __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const
   pp_barrier();            // b_2nk+1
 }
 
-template <typename HT, int EPI, int TMW>
+template <typename HT, int EPI, int TMW, bool ONEBAR = false>
 __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
-                                                         int M, int N, int K, EpiDev e) {
+                                                         int M, int N, int K, EpiDev e, int pf_dist, int pf_mode) {
   constexpr int BM = 32 * TMW;
   constexpr int A_BYTES = BM * PP_ROWB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -508,7 +626,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
   const int nk = K / 64;
   if (wave >= 8) {
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-    pl_load<HT, TMW>(A, lda, B, ldb, M, N, m0, n0, nk, lds0, wave - 8, lane);
+    pl_load<HT, TMW, ONEBAR>(A, lda, B, ldb, M, N, m0, n0, nk, lds0, wave - 8, lane);
     __syncthreads();
     return;
   }
@@ -522,8 +640,27 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
   for (int i = 0; i < PP_TNW; ++i)
 #pragma unroll
     for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (wm == 0) pl_consume<HT, TMW, 0>(nk, lds, a_frag, b_frag, c0, c1, acc);
-  else pl_consume<HT, TMW, 1>(nk, lds, a_frag, b_frag, c0, c1, acc);
+  // this tile's share of the XCD's L2 prefetch, one line per lane: the list [A rows a0 .. a0 + a_cnt) [B rows b0 .. b0 + b_cnt), 64
+  // entries per consumer wave.  pf_mode 1: the A panel's rows split between the tiles_n column tiles that share it, the B tile's
+  // rows between the row panels that run on one XCD at a time (32 CUs / tiles_n, at most 8); 2: every line of the tile
+  PlPrefetch pf{nullptr, 0u, 0, pf_dist};
+  if (pf_dist > 0) {
+    const int conc = max(1, min(8, 32 / tiles_n));
+    const int a_cnt = pf_mode == 2 ? BM : (BM + tiles_n - 1) / tiles_n, a0 = pf_mode == 2 ? 0 : (t % tiles_n) * a_cnt;
+    const int b_cnt = pf_mode == 2 ? PP_BN : PP_BN / conc, b0 = pf_mode == 2 ? 0 : ((t / tiles_n) % conc) * b_cnt;
+    const int li = wave * 64 + lane;
+    if (li < a_cnt) {
+      const int row = a0 + li;
+      pf.base = A; pf.on = row < BM && m0 + row < M;
+      pf.off = (uint32_t)((size_t)min(m0 + row, M - 1) * lda * 2);
+    } else if (li - a_cnt < b_cnt) {
+      const int row = b0 + li - a_cnt;
+      pf.base = B; pf.on = n0 + row < N;
+      pf.off = (uint32_t)((size_t)min(n0 + row, N - 1) * ldb * 2);
+    }
+  }
+  if (wm == 0) pl_consume<HT, TMW, 0, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+  else pl_consume<HT, TMW, 1, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
   __syncthreads();   // every wave is done with the stage ring: it becomes the epilogue's transposition space
   float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
   pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
@@ -686,9 +823,23 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
 #ifdef TIMHIP_TUNING   // per-phase cycle counters (tools/pp_phase.py)
   if constexpr (EPI == TIMHIP_EPI_STORE_T) {
     if (getenv("TIMHIP_PP_PROF")) {
+      const char* ab = getenv("TIMHIP_PP_ABL");   // 1 no DMA, 2 no MFMAs, 3 DMA only, L the late wait (two-barrier loop)
+      const dim3 g_(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
+#define PP_ABL_LAUNCH(ABLV, LATEV) do { \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW, true, ABLV, LATEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW, true, ABLV, LATEV>), g_, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e); } while (0)
+      if (ab && ab[0] == '1') { PP_ABL_LAUNCH(1, false); return; }
+      if (ab && ab[0] == '2') { PP_ABL_LAUNCH(2, false); return; }
+      if (ab && ab[0] == '3') { PP_ABL_LAUNCH(3, false); return; }
+      if (ab && ab[0] == '4') { PP_ABL_LAUNCH(4, false); return; }
+      if (ab && ab[0] == '5') { PP_ABL_LAUNCH(5, false); return; }
+      if (ab && ab[0] == '7') { PP_ABL_LAUNCH(7, false); return; }
+      if (ab && ab[0] == '8') { PP_ABL_LAUNCH(8, false); return; }
+      if (ab && ab[0] == '6') { PP_ABL_LAUNCH(6, false); return; }
+      if (ab && ab[0] == 'L') { PP_ABL_LAUNCH(0, true); return; }
+#undef PP_ABL_LAUNCH
       (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW, true>), dim3(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN)), dim3(512), shmem, s,
-                         (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+      hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW, true>), g_, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
       return;
     }
   }
@@ -715,9 +866,25 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
       return;
     }
   }
+  // Default: the loader-wave kernel with the L2 prefetch (round 3: in the step 5.66 ms with the 8-wave kernel, 5.60-5.65 with
+  // loader waves, 5.41-5.44 with loader waves + prefetch 4 stages ahead, NT GEMMs 763 -> 816 TFLOP/s; prefetch distance 2 / 3 / 5
+  // / 6 / 8: +1.0 / +0.5 / +0.2 / +0.7 / +0.8 % of the step; every tile prefetching ALL its lines: 5.83-5.89 ms, the
+  // prefetch loads then take the vector-memory path's time themselves).  TIMHIP_GEMM_LD=0: the 8-wave kernels.
   const char* ldv = getenv("TIMHIP_GEMM_LD");
-  if (ldv && ldv[0] == '1' && e.a_wrap == 0) {   // (measured: within +-0.5 % of the 8-wave kernel in the step, whichever epilogues take it)
-    hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+  if (!(ldv && ldv[0] == '0') && e.a_wrap == 0) {
+    const char* pfv = getenv("TIMHIP_GEMM_PF");   // L2 prefetch distance in stages (0: off)
+    const char* pfm = getenv("TIMHIP_GEMM_PF_MODE");
+    const char* l1v = getenv("TIMHIP_GEMM_LD1");   // 1: one barrier per contraction step
+    if (l1v && l1v[0] == '1') {
+      static PerDeviceOnce attr_l1;
+      if (attr_l1.first())
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW, true>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
+                         pfv ? atoi(pfv) : 4, pfm ? atoi(pfm) : 1);
+      return;
+    }
+    hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
+                       pfv ? atoi(pfv) : 4, pfm ? atoi(pfm) : 1);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);

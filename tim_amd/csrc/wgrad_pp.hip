@@ -43,6 +43,7 @@ struct WpGroup {
   int tile0[WP_MAX + 1];
   int n, M, accumulate;
   const float* out_scale;
+  int pf_dist;   // wgrad_ld_kernel: L2 prefetch distance in 64-row stages (0: off)
 };
 
 __device__ __forceinline__ void wp_barrier() {
@@ -390,9 +391,17 @@ __device__ __forceinline__ void wp_mainloop_free(const WpTile& a, int M, const c
 // Barriers b0, b1, ...: G0's LOAD(t) runs in window A_t = (b_2t, b_2t+1), its MFMA(t) in B_t = (b_2t+1, b_2t+2); G1 one
 // barrier later.  Loaders: pieces 0-7 of stage t+2 in A_t, 8-11 in B_t, into slot (t-1) % 3 - free since G1's reads of
 // stage t-1 were waited for before b_2t; "stage t+1 has landed" (vmcnt) before b_2t+1, two barriers before its first reader.
+// L2 prefetch (round 3, as in gemm_pp.hip's loader kernel): a consumer wave has no vector-memory operation of its own, so
+// it can touch - one plain dword load per 128-byte line, never used - this tile's SHARE of the lines its XCD's tiles will
+// stage `dist` steps later: the dY lines of a stage (64 rows x 2) are split between the k tiles that share the dY panel, the X
+// lines (64 rows x 4) between the n tiles that run on the XCD at the same time.  pf_on: this lane has a line; pf_base / pf_ld:
+// its address at stage 0 and the byte distance between stages.
+struct WlPrefetch { const char* base; long long step; int on, dist; };
+
 template <typename HT, int G, int ABL>
-__device__ __forceinline__ void wl_consume(const char* lds, int M, int wave, int lane, f32x4_t (&acc)[4][4]) {
+__device__ __forceinline__ void wl_consume(const char* lds, int M, int wave, int lane, f32x4_t (&acc)[4][4], const WlPrefetch& pf) {
   const int nk = (M + WP_M - 1) / WP_M;
+  uint32_t pf_sink = 0;
   const bool partial = (M % WP_M) != 0;
   const int wk = wave & 3, gid = lane >> 4, p = lane & 15;
   // fragment offsets of MFMA tile 0 (rows r = 0, 1 of a fragment); tile i is at (offset ^ (i << 5)): the tile index sits in
@@ -411,6 +420,11 @@ __device__ __forceinline__ void wl_consume(const char* lds, int M, int wave, int
   for (int t = 0; t < nk; ++t) {
     const char* sY = lds + slot * WP_STAGE;
     const char* sX = sY + WP_SUB + (wk >> 1) * WP_SUB;
+    if (pf.on && t + pf.dist < nk - 1) {   // (not the last stage: its rows may lie past M)
+      const char* g = pf.base + (long long)(t + pf.dist) * pf.step;
+      // "+v": the sink is one dedicated register until the wait after the loop (the data returns asynchronously)
+      asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(g) : "memory");
+    }
     if (!(ABL & 1) || t == 0) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -449,6 +463,7 @@ __device__ __forceinline__ void wl_consume(const char* lds, int M, int wave, int
     slot = slot + 1 == WP_NST ? 0 : slot + 1;
   }
   if constexpr (G == 0) wp_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");   // the sink register is free for reuse only now
 }
 
 template <typename HT, int ABL, int NA = 2>   // NA: how many of a wave's three piece groups go out in window A_t (0 / 1 / 3: within noise of 2 or slower)
@@ -590,8 +605,22 @@ __global__ __launch_bounds__(768) void wgrad_ld_kernel(const WpGroup g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (wn == 0) wl_consume<HT, 0, ABL>(lds, g.M, wave, lane, acc);
-  else wl_consume<HT, 1, ABL>(lds, g.M, wave, lane, acc);
+  WlPrefetch pf{nullptr, 0, 0, g.pf_dist};
+  if (g.pf_dist > 0) {
+    const int sy = min(tiles_k, 8), sx = max(1, min(8, 32 / tiles_k));          // tiles sharing a dY panel / an X column block
+    const int ny = (2 * WP_M + sy - 1) / sy, nx = (4 * WP_M + sx - 1) / sx;      // lines of a stage this tile touches
+    const int y0 = ((tl % tiles_k) % sy) * ny, x0 = ((tl / tiles_k) % sx) * nx;
+    const int li = wave * 64 + lane;
+    if (li < ny && y0 + li < 2 * WP_M) {
+      const int l = y0 + li, row = l >> 1, col = a.n0 + (l & 1) * 64;
+      if (col < a.N) { pf.base = a.dY + ((size_t)row * a.ldy + col) * 2; pf.step = (long long)WP_M * a.ldy * 2; pf.on = 1; }
+    } else if (li >= ny && li - ny < nx && x0 + li - ny < 4 * WP_M) {
+      const int l = x0 + li - ny, row = l >> 2, col = a.k0 + (l & 3) * 64;
+      if (col < a.K) { pf.base = a.X + ((size_t)row * a.ldx + col) * 2; pf.step = (long long)WP_M * a.ldx * 2; pf.on = 1; }
+    }
+  }
+  if (wn == 0) wl_consume<HT, 0, ABL>(lds, g.M, wave, lane, acc, pf);
+  else wl_consume<HT, 1, ABL>(lds, g.M, wave, lane, acc, pf);
 
   const int N = a.N, K = a.K;
 #pragma unroll
@@ -720,6 +749,7 @@ int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int 
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
   WpGroup g;
   g.n = n; g.M = M; g.accumulate = accumulate ? 1 : 0; g.out_scale = out_scale;
+  { const char* v = getenv("TIMHIP_WGRAD_PF"); g.pf_dist = v ? atoi(v) : 4; }
   g.tile0[0] = 0;
   for (int i = 0; i < WP_MAX; ++i) {
     if (i >= n) {
