@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtimhip.so")
+LIB_PATH = os.environ.get("TIM_AMD_LIB") or os.path.join(_HERE, "libtimhip.so")   # (TIM_AMD_LIB: an A/B build of the library, tools only)
 
 PREC_BF16, PREC_BF16X3, PREC_FP32, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32, "fp16": PREC_F16}
