@@ -471,6 +471,7 @@ def test_gemm_pingpong_kernel(prec, M, N, K, loaders, monkeypatch):
     (rows past M, columns past N, one / two / three contraction steps), against fp64"""
     monkeypatch.setenv("TIMHIP_GEMM_LD", "0" if loaders is False else "1")
     monkeypatch.setenv("TIMHIP_GEMM_PF", "0" if loaders == "no_prefetch" else "4")
+    monkeypatch.setenv("TIMHIP_GEMM_PF_MR", "0" if loaders == "no_prefetch" else "4")   # (multi-round shapes: off by default)
     monkeypatch.setenv("TIMHIP_GEMM_PF_MODE", "2" if loaders == "prefetch_all" else "1")
     monkeypatch.setenv("TIMHIP_GEMM_LD1", "1" if loaders == "one_barrier" else "0")
     monkeypatch.setenv("TIMHIP_GEMM_DG", "0")      # this test is about the one-tile-per-block kernel

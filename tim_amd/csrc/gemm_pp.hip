@@ -877,17 +877,21 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
   if (!(ldv && ldv[0] == '0') && e.a_wrap == 0) {
     const char* pfv = getenv("TIMHIP_GEMM_PF");   // L2 prefetch distance in stages (0: off)
     const char* pfm = getenv("TIMHIP_GEMM_PF_MODE");
+    // multi-round shapes (more than 256 tiles; TIMHIP_GEMM_PF_MR): no prefetch - their tiles drift apart after the first round and
+    // a share covers a twelfth of a panel; in the step distance 0 / 2 / 4 / 6 / 8 / 12 for them: 5.29 / 5.32 / 5.32 / 5.34 / 5.34 / 5.34 ms
+    const char* pfmr = getenv("TIMHIP_GEMM_PF_MR");
+    const int pf_d_ = grid.x > 256 ? (pfmr ? atoi(pfmr) : 0) : (pfv ? atoi(pfv) : 4);
     const char* l1v = getenv("TIMHIP_GEMM_LD1");   // 1: one barrier per contraction step
     if (l1v && l1v[0] == '1') {
       static PerDeviceOnce attr_l1;
       if (attr_l1.first())
         (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW, true>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
-                         pfv ? atoi(pfv) : 4, pfm ? atoi(pfm) : 1);
+                         pf_d_, pfm ? atoi(pfm) : 1);
       return;
     }
     hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
-                       pfv ? atoi(pfv) : 4, pfm ? atoi(pfm) : 1);
+                       pf_d_, pfm ? atoi(pfm) : 1);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
