@@ -20,7 +20,6 @@ struct AttnArgsM {
   float scale;
   uint32_t thr; float dscale; TimSeed seed; uint32_t site;
   int abl;  // tuning builds only (TimDesc.reserved >> 8): 1 no scratch stores, 2 no dqkv stores, 4 operand rows alias row 0
-  uint32_t bwd_delay;   // 10-ns ticks the second half of the FIRST round of blocks waits before its first load (0: none)
 };
 #ifdef TIMHIP_TUNING
 #define ATT_ABL(a, bit) (((a).abl & (bit)) != 0)
@@ -83,12 +82,6 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
   const float* lsebase = lse + ((size_t)b * a.H + h) * S;
   HT* dSs = dS_scr + (size_t)blockIdx.x * S * FP;
   HT* Pts = Pt_scr + (size_t)blockIdx.x * S * FP;
-  // One block per CU at a time, two rounds: every CU would load, compute and store in lockstep.  Half of the first round's
-  // blocks start late, and their CUs stay half a block out of phase for the rest of the launch.
-  if (a.bwd_delay && blockIdx.x >= 128 && blockIdx.x < 256) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)a.bwd_delay) __builtin_amdgcn_s_sleep(16);
-  }
   stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
   stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
@@ -462,7 +455,6 @@ AttnArgsM make_args2(const TimDesc& d) {
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
   a.abl = d.reserved >> 8;
-  { const char* v = getenv("TIMHIP_ATTN_BWD_DELAY_US"); a.bwd_delay = v ? (uint32_t)(atof(v) * 100.0) : 0u; }
   return a;
 }
 

@@ -26,7 +26,6 @@ struct AttnArgsM {
   int S, F, E, H, LP;
   float scale;
   uint32_t thr; float dscale; TimSeed seed; uint32_t site;
-  uint32_t fwd_delay;   // forward: 10-ns ticks the second half of the grid waits before its first load (0: none)
 };
 
 __device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
@@ -80,13 +79,6 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t ld = (size_t)3 * E;
   const HT* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
-  // All blocks of the grid are co-resident (two per CU) and would load (60 MB at the HBM rate), then compute, then store in
-  // lockstep.  The second half of the grid starts its loads a few microseconds late: a CU then computes one block while the
-  // other block's operands arrive.
-  if (a.fwd_delay && blockIdx.x >= (gridDim.x >> 1)) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)a.fwd_delay) __builtin_amdgcn_s_sleep(16);
-  }
   stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
   stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
@@ -471,7 +463,6 @@ AttnArgsM make_args(const TimDesc& d) {
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
-  { const char* v = getenv("TIMHIP_ATTN_DELAY_US"); a.fwd_delay = v ? (uint32_t)(atof(v) * 100.0) : 0u; }
   return a;
 }
 
