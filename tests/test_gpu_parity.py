@@ -526,3 +526,39 @@ def test_c2a_production_batch_end_to_end(prec):
         assert rel <= rel_max, (prec, k, rel)
     print("C2a B=64 %s: worst |dlogit| %.3g over %d logits, worst gradient-norm deviation %.3g, elementwise min cos %.6f max rel err %.3g"
           % (prec, worst, sum(v.numel() for k, v in res["outs"].items() if k != "feats"), wg, wc, wr))
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_c2a_fused_residual_layernorm_epilogue(train, monkeypatch):
+    """gemm_nt_ldln_kernel (TIMHIP_FUSE_LN=1, round 3): out-projection / linear2 with the LayerNorm that
+    follows inside the GEMM's epilogue - the four column tiles of a row panel exchange per-row (sum, sum of squares) through
+    memory.  At the production batch (M = 9920: the only shapes it takes) the whole model, forward and backward, must (a) stay
+    within the fp16 tolerance of the fp32 oracle (the two paths are two fp16 evaluations: the statistics are summed in another
+    order, ~2e-7 relative, which flips the fp16 rounding of a few operand elements per LayerNorm - they agree with each other to
+    the same 1e-3, not closer: measured 4.1e-4), in evaluation and in training mode (the FFN keep-bits are drawn in the fused epilogue), and (b) give
+    BIT-IDENTICAL outputs to the two-kernel path when every tile's wait is made to time out at once
+    (TIMHIP_FUSE_LN_SPIN=0): then the stand-by LayerNorm launch behind each fused GEMM does the work."""
+    c = _c2a_b64_oracle()
+    cfg, nv, na = c["cfg"], 15, 10
+    m = build(cfg, "fp16", c["sd"])
+    if train:
+        m.train()
+    runs = {}
+    for name, env in (("two_kernels", {"TIMHIP_FUSE_LN": "0"}), ("fused", {"TIMHIP_FUSE_LN": "1", "TIMHIP_FUSE_LN_SPIN": "100000"}),
+                      ("timed_out", {"TIMHIP_FUSE_LN": "1", "TIMHIP_FUSE_LN_SPIN": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m.zero_grad(set_to_none=True)
+        m.rt.step = 100          # the same dropout key (functional.Runtime.next_seed) for every run
+        runs[name] = run_model(m, c["inp"], nv, na, True, c["R"])
+    ref = runs["two_kernels"]
+    for k, v in ref["outs"].items():
+        assert maxerr(runs["fused"]["outs"][k], v) <= TOL_BF16 * max(1.0, amax(v)), ("fused vs two kernels", k)
+        assert torch.equal(runs["timed_out"]["outs"][k], v), ("stand-by LayerNorm", k)
+        if k != "feats" and not train:
+            assert maxerr(runs["fused"]["outs"][k], c["o32"][k]) <= TOL_BF16, ("fused vs oracle", k)
+    for k, v in ref["grads"].items():
+        a, b = runs["fused"]["grads"][k].double().flatten(), v.double().flatten()
+        assert (a @ b / (a.norm() * b.norm() + 1e-300)).item() >= 0.9999, ("fused gradient", k)
+        # (the backward's atomic reductions make parameter gradients differ in the last bits between any two runs)
+        assert relerr(runs["timed_out"]["grads"][k], v) <= 1e-5, ("stand-by LayerNorm gradient", k)

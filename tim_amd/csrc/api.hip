@@ -255,16 +255,31 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
     e.res = x_in_prenorm; e.ln_stats = x_in_stats; e.ln_w = x_in_lnw; e.ln_b = x_in_lnb;
   }
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP1);
-  if (split(TIMHIP_DESC_OUTPROJ_SPLIT)) {
-    // out_w = [w_hi | w_lo | ..] (row stride 3E): o [w_hi | w_lo]^T over K = 2E, o read twice - the weight to ~22 bits
-    e.a_wrap_k = E; e.reserved = 2;
-    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, 3 * E, M, E, 2 * E, e, 1, s))) return rc;
-  } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, E, M, E, E, e, 1, s))) return rc;
+  uint8_t* fmask = d.p_drop > 0.f ? (uint8_t*)(sv + L.ffn_mask) : nullptr;
+  // TIMHIP_FUSE_LN=1 (round 3, opt-in): the LayerNorm that follows the out-projection / linear2 inside the GEMM's epilogue
+  // (gemm_nt_ldln_kernel: the column tiles of a row panel exchange row statistics); the stand-alone LayerNorm stays behind it as
+  // a launch that exits at once unless a tile's wait timed out.  Falls back to the two kernels wherever the shape does not fit.
+  const char* fuse_v = getenv("TIMHIP_FUSE_LN");   // (read per call: tests switch it inside one process)
+  const bool fuse_ln = fuse_v && fuse_v[0] == '1';
+  const uint32_t* ln_run_if = nullptr;
+  bool fused1 = false;
+  if (fuse_ln && h16_storage(prec) && !split(TIMHIP_DESC_OUTPROJ_SPLIT)) {
+    TimLnFuse lf{x1t, E, nullptr, 0, st1, w->n1_w, w->n1_b, fmask, FF, d.p_drop, d.seed, layer_site(d.layer, SITE_L_FFN)};
+    rc = tim_gemm_nt_fuse_ln(prec, o, E, w->out_w, E, M, E, E, e, lf, &ln_run_if, s);
+    if (rc == TIMHIP_OK) fused1 = true;
+    else if (rc != TIMHIP_EUNSUPPORTED) return rc;
+  }
+  if (!fused1) {
+    if (split(TIMHIP_DESC_OUTPROJ_SPLIT)) {
+      // out_w = [w_hi | w_lo | ..] (row stride 3E): o [w_hi | w_lo]^T over K = 2E, o read twice - the weight to ~22 bits
+      e.a_wrap_k = E; e.reserved = 2;
+      if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, 3 * E, M, E, 2 * E, e, 1, s))) return rc;
+    } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, o, E, w->out_w, E, M, E, E, e, 1, s))) return rc;
+  }
   // 4. norm1.  The kernel is HBM-bound with idle VALU: it also draws the keep-bits of the FFN dropout (same Philox
   //    stream as the epilogues would use), which the linear1 epilogue and, in the backward, the gelu' epilogue read
-  uint8_t* fmask = d.p_drop > 0.f ? (uint8_t*)(sv + L.ffn_mask) : nullptr;
   if ((rc = tim_layernorm_fwd(prec, y1, M, E, E, 0, w->n1_w, w->n1_b, nullptr, 0, x1t, E, st1, s, fmask, FF, d.p_drop, d.seed,
-                              layer_site(d.layer, SITE_L_FFN)))) return rc;
+                              layer_site(d.layer, SITE_L_FFN), fused1 ? ln_run_if : nullptr))) return rc;
   // 5. linear1 + GELU(erf) + dropout
   e = epi0();
   e.out0 = h; e.ld0 = FF; e.out1 = u; e.ld1 = FF; e.bias = w->l1_b;
@@ -281,12 +296,22 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
   e.out0 = y2; e.ld0 = E; e.bias = w->l2_b; e.ldres = E;
   e.res = y1; e.ln_stats = st1; e.ln_w = w->n1_w; e.ln_b = w->n1_b;   // residual = norm1(y1), normalised by the epilogue
   e.p_drop = d.p_drop; e.seed = d.seed; e.site = layer_site(d.layer, SITE_L_DROP2);
-  if (split(TIMHIP_DESC_L2_SPLIT)) {
-    e.a_wrap_k = FF; e.reserved = 2;
-    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, 3 * FF, M, E, 2 * FF, e, 1, s))) return rc;
-  } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, FF, M, E, FF, e, 1, s))) return rc;
+  bool fused2 = false;
+  if (fuse_ln && h16_storage(prec) && !split(TIMHIP_DESC_L2_SPLIT)) {
+    TimLnFuse lf{x_out_T, E, x_out, E, st2, w->n2_w, w->n2_b, nullptr, 0, 0.f, 0, 0};
+    rc = tim_gemm_nt_fuse_ln(prec, h, FF, w->l2_w, FF, M, E, FF, e, lf, &ln_run_if, s);
+    if (rc == TIMHIP_OK) fused2 = true;
+    else if (rc != TIMHIP_EUNSUPPORTED) return rc;
+  }
+  if (!fused2) {
+    if (split(TIMHIP_DESC_L2_SPLIT)) {
+      e.a_wrap_k = FF; e.reserved = 2;
+      if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, 3 * FF, M, E, 2 * FF, e, 1, s))) return rc;
+    } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_DROP_RES_F32, h, FF, w->l2_w, FF, M, E, FF, e, 1, s))) return rc;
+  }
   // 7. norm2 (x_out == NULL: only the operand copy and the statistics)
-  return tim_layernorm_fwd(prec, y2, M, E, E, 0, w->n2_w, w->n2_b, x_out, E, x_out_T, E, st2, s);
+  return tim_layernorm_fwd(prec, y2, M, E, E, 0, w->n2_w, w->n2_b, x_out, E, x_out_T, E, st2, s, nullptr, 0, 0.f, 0, 0,
+                           fused2 ? ln_run_if : nullptr);
 }
 
 int timhip_layer_fwd(const TimDesc* dp, const TimLayerParams* w, const float* x_in, const void* x_in_T, float* x_out,

@@ -369,6 +369,15 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
 int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, hipStream_t s);
 // gemm_pp.hip: the one-block-per-CU ping-pong kernel for the encoder-layer shapes (epi_dev: the caller's EpiDev)
 bool tim_gemm_pp_wins(int M, int N, int K, int splitk);
+// gemm_pp.hip: out-projection / linear2 with the LayerNorm that follows fused into the epilogue (gemm_nt_ldln_kernel)
+struct TimLnFuse {
+  void* xt; int ldt; float* xf; int ldx; float* stats; const float* g; const float* b;            // LayerNorm outputs / parameters
+  uint8_t* mask_out; int mask_cols; float mask_p; uint64_t mask_seed; uint32_t mask_site;           // keep-bits as tim_layernorm_fwd draws them
+};
+int tim_gemm_nt_pp_ln(int precision, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
+                      const TimLnFuse& lf, const uint32_t** fail, hipStream_t s);
+int tim_gemm_nt_fuse_ln(int precision, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const TimEpi& te,
+                        const TimLnFuse& lf, const uint32_t** fail, hipStream_t s);
 int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
                    hipStream_t s);
 int tim_transpose(int precision, const void* src, int rows, int cols, int lds, void* dst, int ld,
@@ -392,7 +401,8 @@ int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act,
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,
                       float* stats, hipStream_t s, uint8_t* mask_out = nullptr, int mask_cols = 0, float mask_p = 0.f,
-                      uint64_t mask_seed = 0, uint32_t mask_site = 0);
+                      uint64_t mask_seed = 0, uint32_t mask_site = 0,
+                      const uint32_t* run_if = nullptr);   // run_if: device word; the launch does nothing while it is 0
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
                       const float* stats, int rows, int cols, int act, const float* w, float* dy_f32,
                       int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,

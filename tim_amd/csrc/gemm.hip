@@ -790,6 +790,16 @@ int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, h
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
+int tim_gemm_nt_fuse_ln(int precision, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const TimEpi& te,
+                        const TimLnFuse& lf, const uint32_t** fail, hipStream_t s) {
+  EpiDev e;
+  const int rc0 = prepare_gemm(precision, TIMHIP_EPI_DROP_RES_F32, A, lda, B, ldb, M, N, K, te, 1, e);
+  if (rc0) return rc0;
+  if (K % 64) return TIMHIP_EUNSUPPORTED;
+  TimGemmScope timing(2.0 * M * N * K, s);
+  return tim_gemm_nt_pp_ln(precision, A, lda, B, ldb, M, N, K, &e, lf, fail, s);
+}
+
 int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N,
                 int K, const TimEpi& te, int splitk, hipStream_t s) {
   if (splitk < 1) splitk = 1;

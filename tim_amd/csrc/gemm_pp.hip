@@ -669,6 +669,227 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
   pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
 }
 
+// ---- residual + LayerNorm fused into the epilogue (gemm_nt_ldln_kernel, round 3) ---------------------------
+// out-projection / linear2 of an encoder layer: y = res + dropout(A B^T + bias) AND LayerNorm(y) in ONE launch, for N = the
+// LayerNorm width <= 1024 at M a multiple of 160 (one round of tiles: every block co-resident).  A 160 x 256 tile holds a
+// quarter of a row, so the tiles_n column tiles of a row panel exchange per-row (sum, sum of squares) through memory:
+//   pass 1   the loader-wave kernel's main loop and its dropout + residual epilogue; y goes to memory (fp32: the backward and
+//            the next residual read it) AND stays in registers (80 per lane); per-row partial sums over the wave's 64 columns
+//            (16-lane shuffles), over the block's 256 columns through LDS
+//   publish  part[tile][160] as 8-byte agent-scope atomic stores (write-through), drained (vmcnt) by the storing waves ->
+//            __syncthreads -> lane 0: relaxed agent store of flag[tile] = epoch + 1 (MI355X_MICROARCH.md: "8-B agent atomics both
+//            sides" - no L2 write-back fence: a release fence here would flush the XCD's 5 MB of freshly written y); y is stored
+//            AFTER the publish, so the drain does not wait for it and the partners catch up meanwhile
+//   wait     lane 0 polls the partners' flags (relaxed agent loads, s_sleep, BOUNDED) -> __syncthreads -> the partners'
+//            partials by agent-scope atomic loads (past the L1)
+//   pass 2   mean / rstd per row, the normalised rows from the registers: 16-bit operand copy (+ fp32 rows when asked), the
+//            statistics from column tile 0; the FFN keep-bits LayerNorm-1 used to draw are drawn here (before the wait)
+// epoch: ctl[0], read by every block at its start and advanced by the LAST block to finish (ctl[1] counts them) - no host
+// state, graph-replay safe, flags never need a reset.  A tile whose wait times out (co-residency is not guaranteed: another
+// process on the GPU, a CU mask) sets ctl[2] and skips pass 2; the caller launches the stand-alone LayerNorm with
+// run_if = ctl + 2 behind this kernel, which exits at once unless that happened - results are right either way.
+struct LnFuseDev {
+  void* xt; int ldt; float* xf; int ldx; float* stats; const float* g; const float* b;
+  uint32_t* mbits; int mwords; uint32_t mthr; TimSeed mseed; uint32_t msite;
+  float2* part; uint32_t* flags; uint32_t* ctl; uint32_t spin_limit;
+};
+
+template <typename HT, int TMW>
+__global__ __launch_bounds__(768) void gemm_nt_ldln_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                           int M, int N, int K, EpiDev e, LnFuseDev f, int pf_dist) {
+  constexpr int BM = 32 * TMW;
+  constexpr int A_BYTES = BM * PP_ROWB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = N / PP_BN, tiles_m = M / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = t / tiles_n, tn = t % tiles_n;
+  const int m0 = tm * BM, n0 = tn * PP_BN;
+  const int nk = K / 64;
+  if (wave >= 8) {
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    pl_load<HT, TMW>(A, lda, B, ldb, M, N, m0, n0, nk, lds0, wave - 8, lane);
+    __syncthreads();
+    return;
+  }
+  const uint32_t epoch = __hip_atomic_load(&f.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+  const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
+  const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
+  f32x4_t acc[PP_TNW][TMW];
+#pragma unroll
+  for (int i = 0; i < PP_TNW; ++i)
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  PlPrefetch pf{nullptr, 0u, 0, pf_dist};
+  if (pf_dist > 0) {   // the tile's share of its XCD's lines, as in gemm_nt_ld_kernel
+    const int conc = max(1, min(8, 32 / tiles_n));
+    const int a_cnt = (BM + tiles_n - 1) / tiles_n, a0 = tn * a_cnt;
+    const int b_cnt = PP_BN / conc, b0 = (tm % conc) * b_cnt;
+    const int li = wave * 64 + lane;
+    if (li < a_cnt) {
+      const int row = a0 + li;
+      pf.base = A; pf.on = row < BM;
+      pf.off = (uint32_t)((size_t)min(m0 + row, M - 1) * lda * 2);
+    } else if (li - a_cnt < b_cnt) {
+      const int row = b0 + li - a_cnt;
+      pf.base = B; pf.on = 1;
+      pf.off = (uint32_t)((size_t)(n0 + row) * ldb * 2);
+    }
+  }
+  if (wm == 0) pl_consume<HT, TMW, 0>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+  else pl_consume<HT, TMW, 1>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+  __syncthreads();   // every wave is done with the stage ring (the loader waves leave here)
+
+  // ---- pass 1: y = res + dropout(acc + bias), to memory and kept; row sums ------------------------------------------------
+  constexpr int EP_LD = 68, RBS = 16, NIT = 4;   // 16 x 64 fp32 row block through a wave-private region; 4 quads per lane
+  float* ep = reinterpret_cast<float*>(lds) + wave * (RBS * EP_LD);
+  float2* rp = reinterpret_cast<float2*>(lds + 40 * 1024);             // [160][4] per-wave-column partial (sum, sumsq)
+  float2* rs = reinterpret_cast<float2*>(lds + 48 * 1024);             // [160] (mean, rstd)
+  int* sh_ok = reinterpret_cast<int*>(lds + 52 * 1024);
+  const float asc = e.acc_scale ? *e.acc_scale : 1.f;
+  const int ch = lane & 15, rl = lane >> 4;                            // this lane's quad column / row within a group of 4 rows
+  const int wr0 = wm * 16 * TMW, ncol = n0 + wn * 64 + ch * 4;
+  const float4 bias4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool res_ln = e.ln_stats != nullptr;
+  float4 lng = make_float4(1.f, 1.f, 1.f, 1.f), lnb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (res_ln) { lng = *reinterpret_cast<const float4*>(e.ln_w + ncol); lnb = *reinterpret_cast<const float4*>(e.ln_b + ncol); }
+  float4 yreg[TMW][NIT];
+  float4 rbuf[2][NIT];
+  float2 sbuf[2][NIT];
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  auto fetch_res = [&](int j) {   // the residual rows of row block j -> ring entry j & 1
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wr0 + j * RBS + it * 4 + rl;
+      const f4_t q_ = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(e.res + (size_t)m * e.ldres + ncol));
+      rbuf[j & 1][it] = make_float4(q_[0], q_[1], q_[2], q_[3]);
+      if (res_ln) sbuf[j & 1][it] = *reinterpret_cast<const float2*>(e.ln_stats + 2 * (size_t)m);
+    }
+  };
+  fetch_res(0);
+  if (TMW > 1) fetch_res(1);
+  static_for<TMW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+#pragma unroll
+    for (int i = 0; i < PP_TNW; ++i)
+      *reinterpret_cast<float4*>(ep + frow * EP_LD + i * 16 + 4 * fk) =
+          make_float4(acc[i][j][0] * asc, acc[i][j][1] * asc, acc[i][j][2] * asc, acc[i][j][3] * asc);
+    pp_wait_lds();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * 4 + rl, m = m0 + wr0 + j * RBS + row;
+      float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
+      if (e.thr != 0u) drop_mask4(e.seed, e.site, ((uint64_t)m * (uint64_t)N + (uint64_t)ncol) >> 2, e.thr, e.scale, k0, k1, k2, k3);
+      float4 r = rbuf[j & 1][it];
+      if (res_ln) {
+        const float2 st = sbuf[j & 1][it];
+        r.x = (r.x - st.x) * st.y * lng.x + lnb.x; r.y = (r.y - st.x) * st.y * lng.y + lnb.y;
+        r.z = (r.z - st.x) * st.y * lng.z + lnb.z; r.w = (r.w - st.x) * st.y * lng.w + lnb.w;
+      }
+      const float4 y = make_float4(r.x + v.x * k0, r.y + v.y * k1, r.z + v.z * k2, r.w + v.w * k3);
+      yreg[j][it] = y;   // (stored after the partial sums are published: the publishing waves wait for their own stores)
+      float s1 = (y.x + y.y) + (y.z + y.w), s2 = (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      if (ch == 0) rp[(wr0 + j * RBS + row) * 4 + wn] = make_float2(s1, s2);
+    }
+    if constexpr (j + 2 < TMW) fetch_res(j + 2);
+    pp_wait_lds();
+  });
+  __syncthreads();
+  const int ctid = tid;   // 0 .. 511: the consumer threads
+  // publish: 8-byte agent-scope atomic stores (write-through, no L2 write-back fence needed), drained by the storing waves
+  // before the barrier in front of the flag; the partners read them with agent-scope atomic loads (past their L1)
+  if (ctid < BM) {
+    const float2 a0 = rp[ctid * 4], a1 = rp[ctid * 4 + 1], a2 = rp[ctid * 4 + 2], a3 = rp[ctid * 4 + 3];
+    const float2 q = make_float2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &q, 8);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(f.part + (size_t)t * BM + ctid), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (ctid == 0) __hip_atomic_store(&f.flags[t], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // y to memory (fp32: the backward and the next residual read it) while the partners catch up
+  static_for<TMW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wr0 + j * RBS + it * 4 + rl;
+      const float4 y = yreg[j][it];
+      store4<float>((float*)e.out0 + (size_t)m * e.ld0 + ncol, y.x, y.y, y.z, y.w);
+    }
+  });
+  if (f.mbits) {   // keep-bits of the dropout site the next GEMM's epilogue applies: this tile's share of its panel's words
+    const int wpt = f.mwords / tiles_n;
+    for (int q = ctid; q < BM * wpt; q += 512) {
+      const int row = m0 + q / wpt, wd = tn * wpt + q % wpt;
+      f.mbits[(size_t)row * f.mwords + wd] = drop_bits32(f.mseed, f.msite, ((uint64_t)row * f.mwords + wd) * 8, f.mthr);
+    }
+  }
+  if (ctid == 0) {
+    int ok = 1;
+    for (int p = 0; p < tiles_n && ok; ++p) {
+      if (p == tn) continue;
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&f.flags[tm * tiles_n + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch + 1u) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > f.spin_limit) { ok = 0; break; }
+      }
+    }
+    if (!ok) atomicOr(&f.ctl[2], 1u);
+    *sh_ok = ok;
+  }
+  __syncthreads();
+  if (*sh_ok) {
+    if (ctid < BM) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int p = 0; p < tiles_n; ++p) {
+        const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(f.part + (size_t)(tm * tiles_n + p) * BM + ctid),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float2 q;
+        __builtin_memcpy(&q, &bits, 8);
+        s1 += q.x; s2 += q.y;
+      }
+      const float mean = s1 / (float)N;
+      const float var = fmaxf(s2 / (float)N - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + 1e-5f);
+      rs[ctid] = make_float2(mean, rstd);
+      if (tn == 0 && f.stats) *reinterpret_cast<float2*>(f.stats + 2 * (size_t)(m0 + ctid)) = make_float2(mean, rstd);
+    }
+    __syncthreads();
+    // ---- pass 2: the normalised rows from the registers
+    const float4 g4 = *reinterpret_cast<const float4*>(f.g + ncol), b4 = *reinterpret_cast<const float4*>(f.b + ncol);
+    static_for<TMW>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = wr0 + j * RBS + it * 4 + rl, m = m0 + r;
+        const float2 st = rs[r];
+        const float4 y = yreg[j][it];
+        const float o0 = (y.x - st.x) * st.y * g4.x + b4.x, o1 = (y.y - st.x) * st.y * g4.y + b4.y;
+        const float o2 = (y.z - st.x) * st.y * g4.z + b4.z, o3 = (y.w - st.x) * st.y * g4.w + b4.w;
+        if (f.xt) store4<HT>((HT*)f.xt + (size_t)m * f.ldt + ncol, o0, o1, o2, o3);
+        if (f.xf) store4<float>(f.xf + (size_t)m * f.ldx + ncol, o0, o1, o2, o3);
+      }
+    });
+  }
+  // the last block to finish advances the epoch (every block of this launch read the old value at its start)
+  if (ctid == 0) {
+    const uint32_t done = atomicAdd(&f.ctl[1], 1u);
+    if (done == (uint32_t)(tiles_m * tiles_n) - 1u) {
+      __hip_atomic_store(&f.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&f.ctl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- dual-group persistent form (gemm_nt_dg_kernel, round 3) -----------------------------------------------------------------
 // What the 160 x 256 kernel above cannot do: keep the matrix pipes busy while a tile's epilogue moves its bytes.  Every block of
 // a round finishes its main loop at the same moment, then all of them store (and, for the "+ residual" epilogues, read) at
@@ -898,6 +1119,49 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
 }
 
 }  // namespace
+
+// residual + LayerNorm fused into the GEMM (gemm_nt_ldln_kernel).  TIMHIP_EUNSUPPORTED: the caller runs the two kernels.
+// `fail` (out): the device word the stand-alone LayerNorm behind this launch takes as run_if (see the kernel's header).
+int tim_gemm_nt_pp_ln(int precision, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
+                      const TimLnFuse& lf, const uint32_t** fail, hipStream_t s) {
+  const EpiDev& e = *reinterpret_cast<const EpiDev*>(epi_dev);
+  constexpr int TMW = 5, BM = 32 * TMW;
+  if (!h16_storage(precision) || M % BM || N % PP_BN || K % 64 || K < 128 || !e.vec || e.a_wrap != 0 || !e.res || !lf.xt || !lf.stats ||
+      !lf.g || !lf.b)
+    return TIMHIP_EUNSUPPORTED;
+  const int tiles = (M / BM) * (N / PP_BN);
+  if (tiles > 256 || tiles < 128 || N / PP_BN > 8 || (lf.ldt % 4) || (lf.xf && lf.ldx % 4)) return TIMHIP_EUNSUPPORTED;   // one co-resident round
+  if (lf.mask_out && (lf.mask_cols % (32 * (N / PP_BN)) || ((uintptr_t)lf.mask_out & 3))) return TIMHIP_EUNSUPPORTED;
+  // per-device scratch: partial sums, flags, {epoch, done, fail}
+  struct Scratch { float2* part; uint32_t* flags; uint32_t* ctl; };
+  static Scratch scr[32] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = dev < 0 ? 0 : (dev > 31 ? 31 : dev);
+  if (!scr[dev].part) {   // (first use: not inside a graph capture)
+    char* p = nullptr;
+    const size_t bytes = 256 * (size_t)BM * sizeof(float2) + 256 * 4 + 64;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return TIMHIP_EUNSUPPORTED;
+    scr[dev].part = (float2*)p; scr[dev].flags = (uint32_t*)(p + 256 * (size_t)BM * sizeof(float2)); scr[dev].ctl = scr[dev].flags + 256;
+  }
+  LnFuseDev f;
+  f.xt = lf.xt; f.ldt = lf.ldt; f.xf = lf.xf; f.ldx = lf.ldx; f.stats = lf.stats; f.g = lf.g; f.b = lf.b;
+  f.mbits = (lf.mask_out && lf.mask_p > 0.f) ? (uint32_t*)lf.mask_out : nullptr;
+  f.mwords = lf.mask_cols / 32; f.mthr = lf.mask_p > 0.f ? drop_threshold(lf.mask_p) : 0u; f.mseed = TimSeed(lf.mask_seed); f.msite = lf.mask_site;
+  f.part = scr[dev].part; f.flags = scr[dev].flags; f.ctl = scr[dev].ctl;
+  const char* sl = getenv("TIMHIP_FUSE_LN_SPIN");   // polls (~0.3 us each) before a tile gives up: default ~30 ms
+  f.spin_limit = sl ? (uint32_t)atoi(sl) : 100000u;
+  const size_t shmem = (size_t)PP_NST * (BM + PP_BN) * PP_ROWB;
+  const char* pfv = getenv("TIMHIP_GEMM_PF");
+  static PerDeviceOnce attr_set[2];
+  const int hi = precision == TIMHIP_PREC_F16 ? 1 : 0;
+  if (attr_set[hi].first())
+    DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)gemm_nt_ldln_kernel<HT, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  DISPATCH_H16(precision, hipLaunchKernelGGL((gemm_nt_ldln_kernel<HT, TMW>), dim3(tiles), dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B,
+                                            ldb, M, N, K, e, f, pfv ? atoi(pfv) : 4));
+  if (fail) *fail = scr[dev].ctl + 2;
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
 
 // Is this problem one for the ping-pong kernel?  It needs enough 160 x 256 tiles to fill the 256 CUs about evenly: the
 // encoder-layer GEMMs of a production batch (M = B * S in the thousands, N a multiple of 256 from 1024 up).

@@ -325,11 +325,12 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w, const float* __restrict__ b,
                                                       float* __restrict__ xf, int ldx, T* __restrict__ xt, int ldt,
                                                       float* __restrict__ stats, uint32_t* __restrict__ mbits, int mwords,
-                                                      uint32_t mthr, TimSeed mseed, uint32_t msite) {
+                                                      uint32_t mthr, TimSeed mseed, uint32_t msite, const uint32_t* __restrict__ run_if) {
+  if (run_if && *run_if == 0u) return;   // the stand-by launch behind a GEMM that already normalised its rows (gemm_nt_ldln_kernel)
   constexpr int cols = NS * 512;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  // (a stand-by launch is a small grid that walks the rows; the normal launch has a block per four rows: one trip)
+  for (int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (blockDim.x >> 6)) {
   float4 v[NS][2], gw[NS][2], gb[NS][2];
   const float* yr = y + (size_t)row * ldy;
 #pragma unroll
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
         store4<T>(xt + (size_t)row * ldt + c + 4, o[4], o[5], o[6], o[7]);
       }
     }
+  }
   }
 }
 
@@ -1009,7 +1011,8 @@ int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float
 
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w,
                       const float* b, float* xf, int ldx, void* xt, int ldt, float* stats, hipStream_t s,
-                      uint8_t* mask_out, int mask_cols, float mask_p, uint64_t mask_seed, uint32_t mask_site) {
+                      uint8_t* mask_out, int mask_cols, float mask_p, uint64_t mask_seed, uint32_t mask_site,
+                      const uint32_t* run_if) {
   if (!y || !w || !b || rows <= 0) return TIMHIP_EINVAL;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || (xf && ldx % 4) || (xt && ldt % 4)) return TIMHIP_EUNSUPPORTED;
   dim3 grid((rows + 3) / 4);
@@ -1026,8 +1029,10 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
   // encoder widths (512 / 1024 / 2048 columns, 16-byte aligned rows): the 8-columns-per-lane kernel
   const bool al8 = (ldy % 4) == 0 && (!xt || ldt % 8 == 0) && (!xf || ldx % 4 == 0) &&
                    ((((uintptr_t)y | (uintptr_t)xt | (uintptr_t)xf | (uintptr_t)w | (uintptr_t)b) & 15) == 0);
-#define LN_FWD8(NS) hipLaunchKernelGGL((ln_fwd8_kernel<T, NS>), grid, dim3(256), 0, s, y, rows, ldy, act, w, b, xf, ldx, (T*)xt, ldt, \
-                                     stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site)
+  const dim3 grid8 = run_if ? dim3(min((int)grid.x, 256)) : grid;
+#define LN_FWD8(NS) hipLaunchKernelGGL((ln_fwd8_kernel<T, NS>), grid8, dim3(256), 0, s, y, rows, ldy, act, w, b, xf, ldx, (T*)xt, ldt, \
+                                     stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site, run_if)
+  if (run_if && !(al8 && (cols == 512 || cols == 1024 || cols == 2048))) return TIMHIP_EUNSUPPORTED;   // (only the 8-column kernel has the switch)
   if (al8 && (cols == 512 || cols == 1024 || cols == 2048)) {
     DISPATCH_T(precision, if (cols == 512) LN_FWD8(1); else if (cols == 1024) LN_FWD8(2); else LN_FWD8(4));
   } else {
