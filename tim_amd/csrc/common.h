@@ -402,7 +402,7 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,
                       float* stats, hipStream_t s, uint8_t* mask_out = nullptr, int mask_cols = 0, float mask_p = 0.f,
                       uint64_t mask_seed = 0, uint32_t mask_site = 0,
-                      const uint32_t* run_if = nullptr);   // run_if: device word; the launch does nothing while it is 0
+                      const uint32_t* run_if = nullptr);   // run_if: control words of gemm_nt_ldln_kernel; the launch does nothing unless a tile of the launch in front of it timed out
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
                       const float* stats, int rows, int cols, int act, const float* w, float* dy_f32,
                       int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,

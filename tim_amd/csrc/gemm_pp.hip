@@ -686,8 +686,10 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
 //            statistics from column tile 0; the FFN keep-bits LayerNorm-1 used to draw are drawn here (before the wait)
 // epoch: ctl[0], read by every block at its start and advanced by the LAST block to finish (ctl[1] counts them) - no host
 // state, graph-replay safe, flags never need a reset.  A tile whose wait times out (co-residency is not guaranteed: another
-// process on the GPU, a CU mask) sets ctl[2] and skips pass 2; the caller launches the stand-alone LayerNorm with
-// run_if = ctl + 2 behind this kernel, which exits at once unless that happened - results are right either way.
+// process on the GPU, a CU mask) sets this launch's time-out word ctl[2 + (epoch & 1)] and skips pass 2; the caller launches
+// the stand-alone LayerNorm with run_if = ctl behind this kernel: it reads ctl[2 + ((ctl[0] - 1) & 1)] - the word of the launch
+// that has just advanced the epoch - and exits at once unless a tile timed out; the last block of a launch clears the
+// OTHER word for the launch after it.  Results are right either way.
 struct LnFuseDev {
   void* xt; int ldt; float* xf; int ldx; float* stats; const float* g; const float* b;
   uint32_t* mbits; int mwords; uint32_t mthr; TimSeed mseed; uint32_t msite;
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ldln_kernel(const HT* __restrict_
     }
   }
   if (ctid == 0) {
-    int ok = 1;
+    int ok = f.spin_limit != 0u;   // (0: every tile gives up at once - the test of the stand-by path)
     for (int p = 0; p < tiles_n && ok; ++p) {
       if (p == tn) continue;
       uint32_t spins = 0;
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ldln_kernel(const HT* __restrict_
         if (++spins > f.spin_limit) { ok = 0; break; }
       }
     }
-    if (!ok) atomicOr(&f.ctl[2], 1u);
+    if (!ok) atomicOr(&f.ctl[2 + (epoch & 1u)], 1u);   // this launch's word (the stand-by launch reads it: run_if convention)
     *sh_ok = ok;
   }
   __syncthreads();
@@ -885,6 +887,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ldln_kernel(const HT* __restrict_
     const uint32_t done = atomicAdd(&f.ctl[1], 1u);
     if (done == (uint32_t)(tiles_m * tiles_n) - 1u) {
       __hip_atomic_store(&f.ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&f.ctl[2 + ((epoch + 1u) & 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch's time-out word
       __hip_atomic_store(&f.ctl[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1159,7 +1162,7 @@ int tim_gemm_nt_pp_ln(int precision, const void* A, int lda, const void* B, int 
     DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)gemm_nt_ldln_kernel<HT, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   DISPATCH_H16(precision, hipLaunchKernelGGL((gemm_nt_ldln_kernel<HT, TMW>), dim3(tiles), dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B,
                                             ldb, M, N, K, e, f, pfv ? atoi(pfv) : 4));
-  if (fail) *fail = scr[dev].ctl + 2;
+  if (fail) *fail = scr[dev].ctl;   // (run_if convention of tim_layernorm_fwd: see the kernel's header)
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 

@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
                                                       float* __restrict__ xf, int ldx, T* __restrict__ xt, int ldt,
                                                       float* __restrict__ stats, uint32_t* __restrict__ mbits, int mwords,
                                                       uint32_t mthr, TimSeed mseed, uint32_t msite, const uint32_t* __restrict__ run_if) {
-  if (run_if && *run_if == 0u) return;   // the stand-by launch behind a GEMM that already normalised its rows (gemm_nt_ldln_kernel)
+  // the stand-by launch behind a GEMM that already normalised its rows (gemm_nt_ldln_kernel): run_if = that kernel's control
+  // words {epoch, done, time-out word of even launches, of odd launches}; the launch in front of this one has advanced the epoch
+  if (run_if && run_if[2 + ((run_if[0] - 1u) & 1u)] == 0u) return;
   constexpr int cols = NS * 512;
   const int lane = threadIdx.x & 63;
   // (a stand-by launch is a small grid that walks the rows; the normal launch has a block per four rows: one trip)
