@@ -615,15 +615,71 @@ __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const
   pp_barrier();            // b_2nk+1
 }
 
+template <typename HT, int EPI, int TMW, bool ONEBAR = false>
+__global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                         int M, int N, int K, EpiDev e, int pf_dist, int pf_mode) {
+  constexpr int BM = 32 * TMW;
+  constexpr int A_BYTES = BM * PP_ROWB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (N + PP_BN - 1) / PP_BN, tiles_m = (M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * PP_BN;
+  const int nk = K / 64;
+  if (wave >= 8) {
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+    pl_load<HT, TMW, ONEBAR>(A, lda, B, ldb, M, N, m0, n0, nk, lds0, wave - 8, lane);
+    __syncthreads();
+    return;
+  }
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+  const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
+  const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
+  f32x4_t acc[PP_TNW][TMW];
+#pragma unroll
+  for (int i = 0; i < PP_TNW; ++i)
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // this tile's share of the XCD's L2 prefetch, one line per lane: the list [A rows a0 .. a0 + a_cnt) [B rows b0 .. b0 + b_cnt), 64
+  // entries per consumer wave.  pf_mode 1: the A panel's rows split between the tiles_n column tiles that share it, the B tile's
+  // rows between the row panels that run on one XCD at a time (32 CUs / tiles_n, at most 8); 2: every line of the tile
+  PlPrefetch pf{nullptr, 0u, 0, pf_dist};
+  if (pf_dist > 0) {
+    const int conc = max(1, min(8, 32 / tiles_n));
+    const int a_cnt = pf_mode == 2 ? BM : (BM + tiles_n - 1) / tiles_n, a0 = pf_mode == 2 ? 0 : (t % tiles_n) * a_cnt;
+    const int b_cnt = pf_mode == 2 ? PP_BN : PP_BN / conc, b0 = pf_mode == 2 ? 0 : ((t / tiles_n) % conc) * b_cnt;
+    const int li = wave * 64 + lane;
+    if (li < a_cnt) {
+      const int row = a0 + li;
+      pf.base = A; pf.on = row < BM && m0 + row < M;
+      pf.off = (uint32_t)((size_t)min(m0 + row, M - 1) * lda * 2);
+    } else if (li - a_cnt < b_cnt) {
+      const int row = b0 + li - a_cnt;
+      pf.base = B; pf.on = n0 + row < N;
+      pf.off = (uint32_t)((size_t)min(n0 + row, N - 1) * ldb * 2);
+    }
+  }
+  if (wm == 0) pl_consume<HT, TMW, 0, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+  else pl_consume<HT, TMW, 1, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+  __syncthreads();   // every wave is done with the stage ring: it becomes the epilogue's transposition space
+  float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
+  pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
+}
+
 // tpb > 1 (round 3, the shapes of two or three rounds of tiles): a block walks tpb consecutive column tiles of its row panel
 // itself.  The grid is then ONE round of co-resident blocks that stay in step - 8 row panels x (tiles_n / tpb) blocks per XCD,
 // every block on column tile k of its group at the same time - so the L2 prefetch shares below are as meaningful as for the
 // single-round shapes (with one tile per block the tiles of later rounds drift apart, and a share covered a twelfth of a
 // panel).  The loader waves issue the next tile's first two stages right after the barrier that ends a tile's loop, i.e. under
 // the consumers' epilogue, which transposes through ring slot 2.
-template <typename HT, int EPI, int TMW, bool ONEBAR = false>
-__global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
-                                                         int M, int N, int K, EpiDev e, int pf_dist, int pf_mode, int tpb) {
+// (a kernel of its own: the epilogues of the one-tile kernel above sit at the 168-VGPR limit of three waves per SIMD, and the
+//  same source with a tile loop around it spilled up to 132 registers there; this one spills 9-21, in its epilogue)
+template <typename HT, int EPI, int TMW>
+__global__ __launch_bounds__(768) void gemm_nt_ldp_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                          int M, int N, int K, EpiDev e, int pf_dist, int pf_mode, int tpb) {
   constexpr int BM = 32 * TMW;
   constexpr int A_BYTES = BM * PP_ROWB, ST_BYTES = (BM + PP_BN) * PP_ROWB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -637,19 +693,21 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
     for (int k = 0; k < tpb; ++k) {
       const int t = lb * tpb + k;
-      pl_load<HT, TMW, ONEBAR>(A, lda, B, ldb, M, N, (t / tiles_n) * BM, (t % tiles_n) * PP_BN, nk, lds0, wave - 8, lane);
+      pl_load<HT, TMW>(A, lda, B, ldb, M, N, (t / tiles_n) * BM, (t % tiles_n) * PP_BN, nk, lds0, wave - 8, lane);
       __syncthreads();
     }
     return;
   }
   const int wm = wave >> 2, wn = wave & 3;
-  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
-  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
-  const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
-  const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
+#pragma unroll 1
   for (int k = 0; k < tpb; ++k) {
-    const int t = lb * tpb + k;
-    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * PP_BN;
+    const int t = __builtin_amdgcn_readfirstlane(lb * tpb + k);
+    const int m0 = __builtin_amdgcn_readfirstlane((t / tiles_n) * BM), n0 = __builtin_amdgcn_readfirstlane((t % tiles_n) * PP_BN);
+    // (fragment offsets recomputed per tile: not live across the epilogue)
+    const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+    const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+    const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
+    const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
     f32x4_t acc[PP_TNW][TMW];
 #pragma unroll
     for (int i = 0; i < PP_TNW; ++i)
@@ -674,10 +732,10 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
         pf.off = (uint32_t)((size_t)min(n0 + row, N - 1) * ldb * 2);
       }
     }
-    if (wm == 0) pl_consume<HT, TMW, 0, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
-    else pl_consume<HT, TMW, 1, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+    if (wm == 0) pl_consume<HT, TMW, 0>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+    else pl_consume<HT, TMW, 1>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
     __syncthreads();   // every wave is done with the stage ring: slot 2 (slot 0 for a single tile) becomes the epilogue's transposition space
-    float* ep = reinterpret_cast<float*>(lds + (tpb > 1 ? 2 * ST_BYTES : 0)) + wave * (16 * 68);
+    float* ep = reinterpret_cast<float*>(lds + 2 * ST_BYTES) + wave * (16 * 68);
     pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
   }
 }
@@ -1117,14 +1175,16 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     // multi-round shapes (more than 256 tiles; TIMHIP_GEMM_PF_MR): no prefetch - their tiles drift apart after the first round and
     // a share covers a twelfth of a panel; in the step distance 0 / 2 / 4 / 6 / 8 / 12 for them: 5.29 / 5.32 / 5.32 / 5.34 / 5.34 / 5.34 ms
     const char* pfmr = getenv("TIMHIP_GEMM_PF_MR");
-    // two to four full rounds of tiles run as ONE round of blocks that walk tpb column tiles each (TIMHIP_GEMM_LDP=0: one tile per
-    // block).  In the step, C2a: 5.70 -> 5.55 ms on one box, 5.48 -> 5.43 on another (NT GEMMs 770 -> 794, 808 -> 819 TFLOP/s);
-    // without the prefetch the same walk is a loss (5.53 against 5.48): what it buys is tiles that stay in step, so that the
-    // prefetch shares mean something; C3 4.77 -> 4.70, C2b 7.54 -> 7.51 ms
+    // TIMHIP_GEMM_LDP=1 (a tested A/B arm, not the default): two to four full rounds of tiles as ONE round of blocks that walk tpb
+    // column tiles each (gemm_nt_ldp_kernel) - the tiles of an XCD stay in step, so the prefetch shares apply to them.  Against
+    // the one-tile kernel it is 1.3 % of the step SLOWER (5.44 against 5.36 ms, four interleaved runs per arm).  A first
+    // comparison had said -2.6 %: both arms then came from one kernel source with a tile loop, whose one-tile instance
+    // spilled 20-132 VGPRs in its epilogues (they sit at the 168-register limit) - the baseline was broken, not the idea
+    // good.  The persistent kernel itself still spills 9-21 registers around its epilogue (none inside the main loop).
     const char* ldpv = getenv("TIMHIP_GEMM_LDP");
     const int tiles_ = (int)grid.x, tiles_n_ = (N + PP_BN - 1) / PP_BN;
     int tpb = 1;
-    if (!(ldpv && ldpv[0] == '0') && tiles_ > 256) {
+    if (ldpv && ldpv[0] == '1' && tiles_ > 256) {
       const int want = (tiles_ + 255) / 256;
       if (want <= 4 && tiles_n_ % want == 0 && tiles_ % want == 0 && K >= 128) tpb = want;
     }
@@ -1135,12 +1195,20 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
       static PerDeviceOnce attr_l1;
       if (attr_l1.first())
         (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW, true>), grid_, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
-                         pf_d_, pfm ? atoi(pfm) : 1, tpb);
+      hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW, true>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
+                         grid.x > 256 ? (pfmr ? atoi(pfmr) : 0) : (pfv ? atoi(pfv) : 4), pfm ? atoi(pfm) : 1);
       return;
     }
-    hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid_, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
-                       pf_d_, pfm ? atoi(pfm) : 1, tpb);
+    if (tpb > 1) {
+      static PerDeviceOnce attr_p;
+      if (attr_p.first())
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ldp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL((gemm_nt_ldp_kernel<HT, EPI, TMW>), grid_, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N,
+                         K, e, pf_d_, pfm ? atoi(pfm) : 1, tpb);
+      return;
+    }
+    hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
+                       pf_d_, pfm ? atoi(pfm) : 1);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
