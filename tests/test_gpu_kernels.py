@@ -462,12 +462,12 @@ def test_fp16_scaled_gradient_operands():
 
 @pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("M,N,K", [(9920, 1024, 1024), (9920, 3072, 1024), (9920, 1024, 2048), (9925, 1000, 192), (3000, 2056, 64)])
-@pytest.mark.parametrize("loaders", [False, True, "no_prefetch", "prefetch_all", "one_barrier", "persistent"])
+@pytest.mark.parametrize("loaders", [False, True, "no_prefetch", "prefetch_all", "one_barrier", "one_tile_per_block"])
 def test_gemm_pingpong_kernel(prec, M, N, K, loaders, monkeypatch):
     """gemm_pp.hip (one block per CU, 160 x 256 tiles, three-stage LDS ring): 8 consumer + 4 DMA loader waves with the L2
     prefetch of the tile's share of its XCD's lines (the default; also without the prefetch, with every line prefetched, and
-    with one barrier per contraction step instead of two, TIMHIP_GEMM_LD1=1, and as one round of blocks that walk several
-    tiles each, TIMHIP_GEMM_LDP=1), or 8 waves that issue their DMA pieces themselves
+    with one barrier per contraction step instead of two, TIMHIP_GEMM_LD1=1, and with one tile per block where the default
+    walks several, TIMHIP_GEMM_LDP=0), or 8 waves that issue their DMA pieces themselves
     (gemm_nt_pp_kernel, TIMHIP_GEMM_LD=0): every epilogue the kernel carries, on the encoder layer's shapes and on ragged edges
     (rows past M, columns past N, one / two / three contraction steps), against fp64"""
     monkeypatch.setenv("TIMHIP_GEMM_LD", "0" if loaders is False else "1")
@@ -475,8 +475,8 @@ def test_gemm_pingpong_kernel(prec, M, N, K, loaders, monkeypatch):
     monkeypatch.setenv("TIMHIP_GEMM_PF_MR", "0" if loaders == "no_prefetch" else "4")   # (multi-round shapes: off by default)
     monkeypatch.setenv("TIMHIP_GEMM_PF_MODE", "2" if loaders == "prefetch_all" else "1")
     monkeypatch.setenv("TIMHIP_GEMM_LD1", "1" if loaders == "one_barrier" else "0")
-    # (TIMHIP_GEMM_LDP=1: the 744-tile shape as 248 blocks of three tiles, gemm_nt_ldp_kernel)
-    monkeypatch.setenv("TIMHIP_GEMM_LDP", "1" if loaders == "persistent" else "0")
+    # (the 744-tile shape runs as 248 blocks of three tiles by default, gemm_nt_ldp_kernel; TIMHIP_GEMM_LDP=0: one tile per block)
+    monkeypatch.setenv("TIMHIP_GEMM_LDP", "0" if loaders == "one_tile_per_block" else "1")
     monkeypatch.setenv("TIMHIP_GEMM_DG", "0")      # this test is about the one-tile-per-block kernel
     monkeypatch.setenv("TIMHIP_GEMM_PT", "0")
     _check_layer_gemm_epilogues(prec, M, N, K)

@@ -676,7 +676,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
 // panel).  The loader waves issue the next tile's first two stages right after the barrier that ends a tile's loop, i.e. under
 // the consumers' epilogue, which transposes through ring slot 2.
 // (a kernel of its own: the epilogues of the one-tile kernel above sit at the 168-VGPR limit of three waves per SIMD, and the
-//  same source with a tile loop around it spilled up to 132 registers there; this one spills 9-21, in its epilogue)
+//  same source with a tile loop around it spilled up to 132 registers there; this one spills 1-8 on the epilogues that use it)
 template <typename HT, int EPI, int TMW>
 __global__ __launch_bounds__(768) void gemm_nt_ldp_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
                                                           int M, int N, int K, EpiDev e, int pf_dist, int pf_mode, int tpb) {
@@ -701,10 +701,14 @@ __global__ __launch_bounds__(768) void gemm_nt_ldp_kernel(const HT* __restrict__
   const int wm = wave >> 2, wn = wave & 3;
 #pragma unroll 1
   for (int k = 0; k < tpb; ++k) {
+    // the lane id is laundered once per tile: everything the epilogue derives from it (its LDS offsets, column offsets, ...)
+    // is loop-invariant, the compiler hoists it in front of the tile loop, and 20 registers held across the main loop spill
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     const int t = __builtin_amdgcn_readfirstlane(lb * tpb + k);
     const int m0 = __builtin_amdgcn_readfirstlane((t / tiles_n) * BM), n0 = __builtin_amdgcn_readfirstlane((t % tiles_n) * PP_BN);
     // (fragment offsets recomputed per tile: not live across the epilogue)
-    const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+    const int frow = ln & 15, fk = ln >> 4, sw = (frow >> 1) & 7;
     const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
     const int a_frag = (wm * 16 * TMW + frow) * PP_ROWB;
     const int b_frag = A_BYTES + (wn * 64 + frow) * PP_ROWB;
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ldp_kernel(const HT* __restrict__
       const int conc = max(1, min(8, 32 / groups_n));
       const int a_cnt = pf_mode == 2 ? BM : (BM + groups_n - 1) / groups_n, a0 = pf_mode == 2 ? 0 : ((t % tiles_n) / tpb) * a_cnt;
       const int b_cnt = pf_mode == 2 ? PP_BN : PP_BN / conc, b0 = pf_mode == 2 ? 0 : ((t / tiles_n) % conc) * b_cnt;
-      const int li = wave * 64 + lane;
+      const int li = wave * 64 + ln;
       if (li < a_cnt) {
         const int row = a0 + li;
         pf.base = A; pf.on = row < BM && m0 + row < M;
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ldp_kernel(const HT* __restrict__
     else pl_consume<HT, TMW, 1>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
     __syncthreads();   // every wave is done with the stage ring: slot 2 (slot 0 for a single tile) becomes the epilogue's transposition space
     float* ep = reinterpret_cast<float*>(lds + 2 * ST_BYTES) + wave * (16 * 68);
-    pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
+    pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, ln);
   }
 }
 
@@ -1175,16 +1179,17 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     // multi-round shapes (more than 256 tiles; TIMHIP_GEMM_PF_MR): no prefetch - their tiles drift apart after the first round and
     // a share covers a twelfth of a panel; in the step distance 0 / 2 / 4 / 6 / 8 / 12 for them: 5.29 / 5.32 / 5.32 / 5.34 / 5.34 / 5.34 ms
     const char* pfmr = getenv("TIMHIP_GEMM_PF_MR");
-    // TIMHIP_GEMM_LDP=1 (a tested A/B arm, not the default): two to four full rounds of tiles as ONE round of blocks that walk tpb
-    // column tiles each (gemm_nt_ldp_kernel) - the tiles of an XCD stay in step, so the prefetch shares apply to them.  Against
-    // the one-tile kernel it is 1.3 % of the step SLOWER (5.44 against 5.36 ms, four interleaved runs per arm).  A first
-    // comparison had said -2.6 %: both arms then came from one kernel source with a tile loop, whose one-tile instance
-    // spilled 20-132 VGPRs in its epilogues (they sit at the 168-register limit) - the baseline was broken, not the idea
-    // good.  The persistent kernel itself still spills 9-21 registers around its epilogue (none inside the main loop).
+    // Two to four full rounds of tiles run as ONE round of blocks that walk tpb column tiles each (gemm_nt_ldp_kernel;
+    // TIMHIP_GEMM_LDP=0: one tile per block) - the tiles of an XCD stay in step, so the prefetch shares apply to them.  In the
+    // step 5.343 -> 5.314 ms (four interleaved runs per arm, every run of the walk below every run of the one-tile kernel).
+    // The history of that number is in DESIGN.md section 5d: a first A/B had said -2.6 % against a one-tile instance that
+    // spilled; against the restored spill-free one-tile kernel the walk first LOST 1.3 % - it spilled 9-21 registers itself,
+    // the epilogue's loop-invariant lane arithmetic having been hoisted in front of the tile loop and held across the main
+    // loop; with the lane id laundered once per tile (8 / 5 / 1 spills on the three epilogues that use it) it wins 0.5 %.
     const char* ldpv = getenv("TIMHIP_GEMM_LDP");
     const int tiles_ = (int)grid.x, tiles_n_ = (N + PP_BN - 1) / PP_BN;
     int tpb = 1;
-    if (ldpv && ldpv[0] == '1' && tiles_ > 256) {
+    if (!(ldpv && ldpv[0] == '0') && tiles_ > 256) {
       const int want = (tiles_ + 255) / 256;
       if (want <= 4 && tiles_n_ % want == 0 && tiles_ % want == 0 && K >= 128) tpb = want;
     }
