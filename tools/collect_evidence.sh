@@ -17,6 +17,6 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCL
 cd /root/repo
 python tools/rocpd_stats.py $OUT/prof/c2a_results.db > $OUT/kernel_stats.csv 2> $OUT/kernel_stats.err
 python tools/pmc_traffic.py $OUT/traffic $OUT/pmc_traffic.json > /dev/null 2> $OUT/pmc_traffic.err
-python tools/pmc_summary.py $OUT/sq gemm_nt_ld gemm_nt_pp wgrad_ld attn_fwd attn_bwd_rows ln_bwd ln_fwd8 gemm_nt_h16 > $OUT/pmc_sq_summary.txt 2>&1
+python tools/pmc_summary.py $OUT/sq gemm_nt_ldp gemm_nt_ld gemm_nt_pp wgrad_ld attn_fwd attn_bwd_rows ln_bwd ln_fwd8 gemm_nt_h16 > $OUT/pmc_sq_summary.txt 2>&1
 rm -rf $OUT/prof $OUT/traffic $OUT/sq
 ls -la $OUT
