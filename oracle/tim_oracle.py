@@ -10,7 +10,11 @@ Parity pin: the reference repository holds no tests or golden vectors for this
 path, so the oracle is pinned by golden vectors that
 `tests/golden/make_golden.py` produced by importing the reference itself in the
 build container (`/root/reference`, torch 2.10 CPU, fp64 and fp32) — see
-`tests/test_oracle_golden.py`.  The reference's arithmetic lives in PyTorch
+`tests/test_oracle_golden.py`.  The training branch (`masks=`: the five dropout
+sites) is pinned the same way: `tests/golden/make_golden_train.py` runs the
+reference in `.train()` with `torch.nn.functional.dropout` replaced by a recorder
+of seeded keep-masks (4 recognition combinations + detection `forward_train`),
+`test_tiny_train_mode_fp64` / `test_tiny_detection_forward_train_fp64` feed them here.  The reference's arithmetic lives in PyTorch
 (`nn.MultiheadAttention`, `nn.Linear`, `nn.LayerNorm`, `F.gelu`; pinned
 pytorch=1.11.0 in environment.yml:13); the published semantics of those ops are
 restated here op by op.

@@ -341,6 +341,32 @@ def test_c2a_production_batch_train_mode_fp16():
     print("C2a B=64 fp16 TRAIN mode: worst |dlogit| %.3g over %d logits; gradients min cos %.6f, max rel err %.3g" % (worst, n, wc, wr))
 
 
+@pytest.mark.parametrize("key,step", [(1, 7), (20260930, 1234), (0x5EED5EED5EED, 99991)])
+def test_c2a_production_batch_train_mode_fp16_other_draws(key, step):
+    """the 1e-3 claim as a statement about the DISTRIBUTION of draws, not one pinned key: the same B = 64 training forward
+    under three unrelated (model key, step) pairs - different masks at every site - each against the fp32 oracle under ITS
+    masks.  Forward only (the gradients' agreement does not depend on the draw: see the pinned case above)."""
+    cfg = named_config("C2a")
+    B, nv, na = 64, 15, 10
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
+    torch.manual_seed(key)
+    m = _build(cfg, "fp16", sd).train()
+    m.rt.step = step
+    with torch.no_grad():
+        te = m(inp["times"].to(DEV).float(), "time_mlp")
+        cls, feats = m([inp["visual"].to(DEV).float(), inp["audio"].to(DEV).float()], "encoder", te, nv, na)
+    seed = m.rt.last_seed
+    outs = {k: v.cpu() for k, v in H.named_outputs(cls, feats).items()}
+    S = cfg.F + cfg.num_queries(nv, na)
+    masks = site_masks(cfg, seed, B, S, inp)
+    with torch.no_grad():
+        o = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na, masks=masks))
+    errs = {k: maxerr(outs[k], o[k]) for k in outs if k != "feats"}
+    print("C2a B=64 fp16 TRAIN mode, key %d step %d (seed %d): worst |dlogit| %.3g  %s"
+          % (key, step, seed, max(errs.values()), {k: "%.2e" % v for k, v in errs.items()}))
+    assert max(errs.values()) <= 1e-3, errs
+
+
 # ------------------------------------------------------------------------------------------------
 # the fp16 mode on a second weight / input distribution ("trained-like": heavier tails, non-unit LayerNorm gains)
 # ------------------------------------------------------------------------------------------------
