@@ -84,12 +84,13 @@ def _worker(rank, world, port, q, bpe=3):
         dist.broadcast(both, 0)
         assert torch.equal(both, got)          # every rank ends with the SAME gradients (all-gather of the reduced shards)
         assert dp.bytes_on_wire > 0
-        # TIM_AMD_DP_COLLECTIVE=allreduce: the plain fp32 all-reduce path gives the exact mean
-        os.environ["TIM_AMD_DP_COLLECTIVE"] = "allreduce"
+        # the plain fp32 all-reduce path (what the group falls back to TOGETHER, test_collective_choice_is_collective)
+        assert dp.collective == "a2a"
+        dp.collective = "allreduce"       # (every rank of this test alike)
         z = x.clone()
         dp._exchange(z)
         assert torch.allclose(z, exact, rtol=1e-6, atol=1e-9)
-        del os.environ["TIM_AMD_DP_COLLECTIVE"]
+        dp.collective = "a2a"
         # odd lengths that W does not divide, both wire formats, against the exact mean (staging path with padded chunks)
         for n_odd in (1, 7, 100003, 64 * 5):
             for wd in (torch.float32, torch.bfloat16):
@@ -155,6 +156,103 @@ def _worker(rank, world, port, q, bpe=3):
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+def _choice_worker(rank, world, port, q, mode):
+    """mode "preflight": rank 1 alone refuses the all-to-all path before any collective; "env": rank 0 alone carries the A/B
+    switch; "raise": the all-to-all raises (on every rank: a backend without it); "wrong": rank 1's probe comes back with
+    a wrong mean; "step_error": after a healthy construction a step's exchange raises on one rank - and must propagate."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import warnings
+        from tim_amd import dp as DP
+        from tim_amd.tim import TIM
+        cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+        m = TIM(cfg.num_class, visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2, num_feats=6)
+        a2a_calls = []
+        real_a2a = dist.all_to_all_single
+        if mode == "preflight" and rank == 1:
+            def refuse(self):
+                raise RuntimeError("forced: this rank cannot run the all-to-all path")
+            DP.DataParallel._preflight = refuse
+        if mode == "env" and rank == 0:
+            os.environ["TIM_AMD_DP_COLLECTIVE"] = "allreduce"
+        if mode == "raise":
+            def broken(*a, **k):
+                raise RuntimeError("forced: backend has no all_to_all")
+            DP.dist.all_to_all_single = broken
+        if mode == "wrong" and rank == 1:
+            orig = DP.DataParallel._reduce_chunks
+
+            def off_by_one(self, st, W, per, on_gpu):
+                orig(self, st, W, per, on_gpu)
+                st["shard"].add_(1.0)
+            DP.DataParallel._reduce_chunks = off_by_one
+        if mode in ("preflight", "env"):
+            def counted(*a, **k):
+                a2a_calls.append(1)
+                return real_a2a(*a, **k)
+            DP.dist.all_to_all_single = counted
+        with warnings.catch_warnings(record=True) as wrn:
+            warnings.simplefilter("always")
+            dp = DP.DataParallel(m)
+        want = "a2a" if mode == "step_error" else "allreduce"
+        assert dp.collective == want, dp.collective
+        agreed = torch.tensor([1.0 if dp.collective == "allreduce" else 0.0])
+        lo, hi = agreed.clone(), agreed.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert lo.item() == hi.item()                      # THE SAME decision on every rank
+        if mode in ("preflight", "env"):
+            assert not a2a_calls                           # nobody issued an all-to-all a peer would not join
+        if mode != "env" and mode != "step_error" and rank == 0:
+            assert any("agreed on plain all_reduce" in str(w.message) for w in wrn)
+        if mode == "wrong" and rank == 1:
+            DP.DataParallel._reduce_chunks = orig
+        if mode == "step_error":
+            # no per-rank fallback any more: an error inside a step's exchange propagates on the rank that saw it
+            if rank == 1:
+                def boom(*a, **k):
+                    raise RuntimeError("forced: out of memory")
+                dp._exchange_a2a = boom
+                try:
+                    dp._exchange(torch.ones(64))
+                    raise AssertionError("the error was swallowed")
+                except RuntimeError as e:
+                    assert "forced" in str(e)
+                assert dp.collective == "a2a"
+        else:
+            # the fallback exchanges correctly, on every rank
+            x = torch.full((1000,), float(rank + 1))
+            dp._exchange(x)
+            assert torch.allclose(x, torch.full((1000,), (1 + world) / 2.0))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize("mode", ["preflight", "env", "raise", "wrong", "step_error"])
+def test_collective_choice_is_collective(mode):
+    """tim_amd/dp.py:_choose_collective - the all-to-all -> all-reduce fallback is decided once, by the whole group: a refusal,
+    an exception or a wrong probe result on ONE rank moves EVERY rank to all_reduce before a step runs; after construction
+    nothing switches collectives on its own (an error in a step's exchange is raised, not absorbed)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_choice_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
 @pytest.mark.parametrize("world,bpe", [(2, 3), (3, 1), (4, 4)])

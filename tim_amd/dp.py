@@ -74,7 +74,8 @@ class DataParallel(nn.Module):
         self.buckets_per_exchange = max(1, int(buckets_per_exchange))
         self._pending = []         # buckets completed but not yet exchanged: (flat, ready)
         self._accumulating = False  # a backward pass ran under no_sync() since the last exchange
-        self._a2a_failed = False    # set when the all-to-all path raised: every later exchange is a plain all-reduce
+        self.collective = "a2a"     # or "allreduce": agreed by the whole group in _choose_collective, never changed afterwards
+        self._why = ""
         rt = module.rt
         rt.bucket_hook = self._on_bucket
         rt.finish_hook = self._on_encoder_done
@@ -85,6 +86,12 @@ class DataParallel(nn.Module):
         if self.active:
             for p in self._small:
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._on_small_grad))
+            dev = next(module.parameters()).device
+            self.collective = self._choose_collective(dev)
+            if self.collective != "a2a" and self.rank == 0 and os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") != "allreduce":
+                import warnings
+                warnings.warn("tim_amd.dp: the group agreed on plain all_reduce for the gradient exchange (%s)"
+                              % (self._why or "a peer refused the all-to-all path"))
             if broadcast_parameters:
                 self.broadcast_parameters()
 
@@ -140,28 +147,67 @@ class DataParallel(nn.Module):
             st["acc"].mul_(1.0 / W)
             st["shard"].copy_(st["acc"])
 
+    # ---- which collective: decided ONCE, by every rank together ------------------------------------
+    def _preflight(self):
+        """Everything about the all-to-all path that can fail on THIS rank without entering a collective: the A/B switch
+        in the environment, the two collectives' presence in this torch build, the wire dtype.  Raises or returns False for
+        'not here'; tests replace it on one rank to force a rank-asymmetric refusal."""
+        if os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") == "allreduce":
+            return False
+        if not (hasattr(dist, "all_to_all_single") and hasattr(dist, "all_gather_into_tensor")):
+            return False
+        return self.wire_dtype in (torch.float32, torch.bfloat16, torch.float16)
+
+    def _agree(self, ok, dev):
+        """logical AND of `ok` over the group (one small all-reduce; the only collective every backend runs)"""
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        return bool(flag.item() >= 0.5)
+
+    @torch.no_grad()
+    def _choose_collective(self, dev):
+        """-> "a2a" | "allreduce", the same answer on every rank, for the life of the wrapper.
+
+        A rank must never switch collectives on its own: peers that did not see its error are still inside all_to_all /
+        all_gather, and a clean crash would become a collective mismatch (a hang, or wrongly summed buckets).  So (1) every
+        rank runs its local preflight and the group ANDs the results - a refusal anywhere sends EVERYBODY to all_reduce
+        before any all-to-all was issued; (2) the group runs one probe exchange on a small vector with a known answer
+        through the very code path the step uses; an exception or a wrong mean on any rank is ANDed again.  After that
+        `_exchange` has no fallback: an error in a step's exchange propagates (out of memory included) - the job stops
+        instead of diverging."""
+        try:
+            ok = bool(self._preflight())
+        except Exception as e:  # noqa: BLE001  (a preflight that raises is a refusal, with the reason kept for the warning)
+            ok, self._why = False, "preflight: %s" % str(e)[:200]
+        if not self._agree(ok, dev):
+            return "allreduce"
+        W = self.world
+        n = 64 * W + 24                      # not a multiple of 8 W: the staged (padded) form; 64 W alone = the zero-copy form
+        ok = True
+        try:
+            for numel in (n, 64 * W):
+                probe = torch.arange(numel, dtype=torch.float32, device=dev) * (self.rank + 1)
+                self._exchange_a2a(probe, W, numel)
+                want = torch.arange(numel, dtype=torch.float32, device=dev) * ((W + 1) / 2.0)
+                tol = 0.0 if self.wire_dtype == torch.float32 else 2.0 ** -7
+                if not bool(((probe - want).abs() <= tol * want.abs() + 1e-6).all()):
+                    ok, self._why = False, "probe exchange returned a wrong mean"
+        except RuntimeError as e:            # raised on every rank alike (a backend without the collective)
+            ok, self._why = False, "probe exchange: %s" % str(e)[:200]
+        self._stage.clear()
+        self.bytes_on_wire = 0
+        return "a2a" if self._agree(ok, dev) else "allreduce"
+
     def _exchange(self, flat):
-        """flat (fp32, 1-D) <- mean over ranks, via all-to-all + fp32 sum + all-gather on `wire_dtype`"""
+        """flat (fp32, 1-D) <- mean over ranks: all-to-all + fp32 sum + all-gather on `wire_dtype`, or - when the group
+        agreed so at construction (`self.collective`) - one fp32 all-reduce.  No per-rank fallback (see _choose_collective)."""
         W, n = self.world, flat.numel()
-        if os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") == "allreduce" or self._a2a_failed:
-            # plain fp32 ring all-reduce (A/B switch and a way out should a runtime mishandle the all-to-all)
+        if self.collective == "allreduce":
             dist.all_reduce(flat, group=self.pg)
             flat.mul_(1.0 / W)
             self.bytes_on_wire += 2 * 2 * (n // W) * (W - 1) * 4
             return
-        try:
-            return self._exchange_a2a(flat, W, n)
-        except RuntimeError as e:   # a runtime that cannot run the all-to-all / all-gather pair (never seen; no multi-GPU box was
-            # available to the builder): say so once and use the plain all-reduce from here on - the bucket is still intact,
-            # all-to-all only writes the staging buffer and the all-gather is the last step
-            if flat.is_cuda:
-                torch.cuda.current_stream().synchronize()
-            import warnings
-            warnings.warn("tim_amd.dp: all-to-all gradient exchange failed (%s); falling back to all_reduce" % str(e)[:200])
-            self._a2a_failed = True
-            dist.all_reduce(flat, group=self.pg)
-            flat.mul_(1.0 / W)
-            self.bytes_on_wire += 2 * 2 * (n // W) * (W - 1) * 4
+        return self._exchange_a2a(flat, W, n)
 
     def _exchange_a2a(self, flat, W, n):
         if self.wire_dtype == torch.float32 and n % (8 * W) == 0 and flat.is_contiguous():
