@@ -252,7 +252,14 @@ int timhip_dp_reduce(int wire_bf16, const void* recv, int world, long long per, 
  * wraps its step in a GradScaler for that reason, recognition/scripts/train.py:82,355-363).  Here the scale is chosen per
  * backward pass ON THE DEVICE from the cotangents entering it: S = 2^floor(log2(target / max|cot|)), out[0] = S,
  * out[1] = 1/S (S = 1 when every cotangent is 0).  cot / counts: HOST arrays of n <= 8 device pointers / element counts;
- * out: 4 floats in device memory, out[2..3] zero before the first call (scratch, left zero).  One launch, no host sync. */
+ * out: 8 floats in device memory, out[2..7] zero before the first call (out[2..3] scratch, left zero).  One launch, no host sync.
+ *
+ * NON-FINITE WATCH (out[4], read as uint32): every entry point below that takes `out_scale` expects NULL or &out[1] of such a
+ * block, multiplies what it writes by out[1] = 1/S, and ORs 1 into out[4] when a FINAL fp32 gradient it writes is inf or nan
+ * (timhip_wgrad, timhip_wgrad_group, timhip_time_l1_bwd - every weight / bias gradient of the fp16 backward).  An overflow of
+ * a 16-bit gradient operand anywhere in the chain reaches every weight gradient upstream of it, so the flag is what the
+ * reference's GradScaler inf check computes (recognition/scripts/train.py:351,357-363: skip the step, halve the scale)
+ * without a pass over the gradients and without a host synchronisation until somebody reads the word. */
 int timhip_grad_scale(const float* const* cot, const long long* counts, int n, float target, float* out, void* stream);
 
 /* fp32 -> T with optional dropout (p_drop > 0) and zero padding to ld; scale: optional device scalar multiplied in */

@@ -83,3 +83,49 @@ def test_training_steps_follow_the_oracle(prec, tol):
     # fraction of 6 * 2 * lr = 2.4e-2, not of the gradient accuracy
     worst = max((p.detach().cpu().double() - ref[n].detach()).abs().max().item() for n, p in model.named_parameters())
     assert worst <= (4e-3 if prec == "fp32" else 2.4e-2), worst
+
+
+def test_fp16_nonfinite_gradient_flag():
+    """`model.rt.grads_finite()` - the device-side word the weight-gradient kernels OR when they write inf / nan (include/timhip.h:
+    timhip_grad_scale), the fp16 mode's counterpart of GradScaler's inf check (reference scripts/train.py:351,357-363).
+    A healthy step reads True; a step whose gradient operands were pushed over the fp16 range (scale target 2^60: S is clamped
+    to 2^40, every cotangent of order 1e-2 becomes inf in 16 bits) reads False - and the parameter gradients really are
+    non-finite; reading resets the watch, the next healthy step is True again.  fp32 / bf16: always True."""
+    cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+    B, nv, na, nf = 4, 4, 2, cfg.num_feats
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=3, dtype=torch.float32)
+    ta, tb = _targets(B, nv, na, 1), _targets(B, nv, na, 2)
+    g = torch.Generator().manual_seed(5)
+    pos = (torch.randint(nf, (B, 5), generator=g), torch.randint(nf, (B, 5), generator=g))
+    dinp = {k: v.to(DEV) for k, v in inp.items()}
+    for prec in ("fp16", "bf16"):
+        model = TIM(cfg.num_class, visual_input_dim=cfg.visual_input_dim, audio_input_dim=cfg.audio_input_dim,
+                    d_model=cfg.d_model, nhead=cfg.nhead, num_layers=cfg.num_layers, num_feats=nf, precision=prec)
+        model.load_state_dict(sd)
+        model = model.to(DEV).train()
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            _loss_hip(model, dinp, ta, tb, 0.7, pos, nv, na, nf).backward()
+            return all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+
+        assert step() and model.rt.grads_finite()
+        assert model.rt.grads_finite()                      # nothing since the last read
+        if prec != "fp16":
+            continue
+        target = model.rt.grad_scale_target
+        model.rt.grad_scale_target = 2.0 ** 60
+        finite = step()
+        model.rt.grad_scale_target = target
+        assert not finite                                   # the overflow is real ...
+        assert not model.rt.grads_finite(reset=False)       # ... and the kernels saw it, without a pass over the gradients
+        assert not model.rt.grads_finite()
+        assert step() and model.rt.grads_finite()           # reading reset the watch
+        # many passes without a reader: folded on the device, an early overflow is not forgotten
+        model.rt.grad_scale_target = 2.0 ** 60
+        step()
+        model.rt.grad_scale_target = target
+        for _ in range(12):
+            assert step()
+        assert not model.rt.grads_finite()

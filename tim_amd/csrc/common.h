@@ -269,6 +269,16 @@ __device__ __forceinline__ void gelu_both_f(float x, float& gl, float& dg) {
   dg = fmaf(x * kInvSqrt2Pi, e, ph);
 }
 
+// Non-finite watch of the fp16 gradient path.  `out_scale` (where a kernel takes one) points at word 1 of the block
+// timhip_grad_scale writes: {S, 1/S, scratch, scratch, FLAG, 0, 0, 0}.  Every kernel that writes FINAL fp32 gradients
+// through out_scale folds what it writes into `chk` (0 * v stays 0 unless v is inf / nan, then chk is nan for good) and ORs
+// the flag word once per lane that saw one: what GradScaler's inf check (reference scripts/train.py:351,357-363) looks
+// for, found where the values are produced instead of in a pass over 233 MB of gradients.
+__device__ __forceinline__ void nf_note(float& chk, float v) { chk = fmaf(v, 0.f, chk); }
+__device__ __forceinline__ void nf_commit(const float* out_scale, float chk) {
+  if (out_scale != nullptr && chk != chk) atomicOr(reinterpret_cast<unsigned*>(const_cast<float*>(out_scale)) + 3, 1u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -564,6 +564,7 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
                                                           float* __restrict__ dt, int rows_pb,
                                                           const float* __restrict__ out_scale) {
   const float os = out_scale ? *out_scale : 1.f;   // factor on everything written (1 / gradient scale of the fp16 mode)
+  float chk = 0.f;
   // one block: rows [r0, r1).  dw/db: a thread owns 4 consecutive columns (one vector load per row) and every RL-th row;
   // the row lanes are combined through LDS before the block's atomics (3 per column).  per-row dt via wave reduction
   const int r0 = blockIdx.x * rows_pb, r1 = min(rows, r0 + rows_pb);
@@ -607,6 +608,7 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
         for (int u = 0; u < 4; ++u) {
           const int j = 4 * q + u;
           atomicAdd(dw + 2 * j, v0[u] * os); atomicAdd(dw + 2 * j + 1, v1[u] * os); atomicAdd(db + j, v2[u] * os);
+          nf_note(chk, v0[u]); nf_note(chk, v1[u]); nf_note(chk, v2[u]);
         }
       }
     }
@@ -618,8 +620,10 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
         a0 += g * times[2 * r]; a1 += g * times[2 * r + 1]; a2 += g;
       }
       atomicAdd(dw + 2 * j, a0 * os); atomicAdd(dw + 2 * j + 1, a1 * os); atomicAdd(db + j, a2 * os);
+      nf_note(chk, a0); nf_note(chk, a1); nf_note(chk, a2);
     }
   }
+  nf_commit(out_scale, chk);
   if (dt) {
     for (int r = r0 + wave; r < r1; r += 4) {
       float s0 = 0.f, s1 = 0.f;

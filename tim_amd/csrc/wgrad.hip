@@ -35,6 +35,7 @@ struct WgTile {
   const HT* dY; const HT* X; float* out; float* db_out;
   int ldy, ldx, M, N, K, n0, k0, s0, s1, do_bias, accumulate;
   float alpha;   // factor on what is written (1 for slabs; 1 / gradient scale for final outputs of the fp16 mode)
+  const float* nf;   // out_scale when this tile writes FINAL gradients (non-finite watch, common.h:nf_note), else NULL
 };
 
 template <typename HT>
@@ -162,6 +163,7 @@ __device__ __forceinline__ void wgrad_tile(const WgTile<HT>& a, char* lds) {
   constexpr int EP_LD = 64 + 4;
   __syncthreads();
   float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EP_LD);
+  float chk = 0.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -177,6 +179,7 @@ __device__ __forceinline__ void wgrad_tile(const WgTile<HT>& a, char* lds) {
       const int row = idx >> 4, ch = idx & 15;
       float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
       v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+      nf_note(chk, v.x); nf_note(chk, v.y); nf_note(chk, v.z); nf_note(chk, v.w);
       const int n = n0 + wn * 64 + j * 32 + row;
       const int k = k0 + wk * 64 + ch * 4;
       if (n < N) {
@@ -203,6 +206,7 @@ __device__ __forceinline__ void wgrad_tile(const WgTile<HT>& a, char* lds) {
       if (g == 0 && n < N) a.db_out[n] = a.accumulate ? a.db_out[n] + t2 : t2;
     }
   }
+  nf_commit(a.nf, chk);
 }
 
 template <typename HT>
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const HT* __restrict__ dY
   const int t = w - zsplit * ntiles;
   const int nsteps = (M + WM - 1) / WM;
   WgTile<HT> a;
-  a.alpha = 1.f;
+  a.alpha = 1.f; a.nf = nullptr;
   a.dY = dY; a.X = X; a.ldy = ldy; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
   // consecutive work items share the dY panel (same n-tile): k-tile fastest
   a.n0 = (t / tiles_k) * WT; a.k0 = (t % tiles_k) * WT;
@@ -281,9 +285,9 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g) {
   a.s1 = min(nsteps, a.s0 + g.steps_per_split);
   if (g.splits == 1) {
     a.out = dW; a.db_out = db; a.accumulate = g.accumulate;
-    a.alpha = g.out_scale ? *g.out_scale : 1.f;
+    a.alpha = g.out_scale ? *g.out_scale : 1.f; a.nf = g.out_scale;
   } else {
-    a.alpha = 1.f;
+    a.alpha = 1.f; a.nf = nullptr;
     a.out = g.slab + (long long)zsplit * g.off[g.n] + off;
     a.db_out = g.db_slab + (long long)zsplit * g.boff[g.n] + boff;
     a.accumulate = 0;
@@ -296,6 +300,7 @@ __global__ void wgrad_group_reduce_kernel(const WgGroup g) {
   const long long nq = g.off[g.n] >> 2;           // every N*K is a multiple of 4 (checked by the launcher)
   const int nb = g.boff[g.n];
   const float alpha = g.out_scale ? *g.out_scale : 1.f;
+  float chk = 0.f;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq + nb; q += (long long)gridDim.x * blockDim.x) {
     if (q < nq) {
       const long long i = q << 2;
@@ -309,6 +314,7 @@ __global__ void wgrad_group_reduce_kernel(const WgGroup g) {
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
       acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+      nf_note(chk, acc.x); nf_note(chk, acc.y); nf_note(chk, acc.z); nf_note(chk, acc.w);
       if (g.accumulate) {
         const float4 o = *reinterpret_cast<const float4*>(dst);
         acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
@@ -326,6 +332,7 @@ __global__ void wgrad_group_reduce_kernel(const WgGroup g) {
       *dst = acc * alpha + (g.accumulate ? *dst : 0.f);
     }
   }
+  nf_commit(g.out_scale, chk);
 }
 
 // dW[i] += sum_z slab[z*n + i] (float4) and db[j] += sum_z dbs[z*nb + j]: one launch for both
@@ -335,6 +342,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n,
                                     const float* __restrict__ out_scale) {
   const long long nq = n >> 2;
   const float alpha = out_scale ? *out_scale : 1.f;
+  float chk = 0.f;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq + nb; q += (long long)gridDim.x * blockDim.x) {
     if (q < nq) {
       const long long i = q << 2;
@@ -344,6 +352,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n,
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
       }
       a.x *= alpha; a.y *= alpha; a.z *= alpha; a.w *= alpha;
+      nf_note(chk, a.x); nf_note(chk, a.y); nf_note(chk, a.z); nf_note(chk, a.w);
       if (accumulate) {
         const float4 o = *reinterpret_cast<const float4*>(dW + i);
         a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
@@ -356,17 +365,21 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, long long n,
       db[j] = a * alpha + (accumulate ? db[j] : 0.f);
     }
   }
+  nf_commit(out_scale, chk);
 }
 
 // out[i] += sum_z slab[z*stride + i]
 __global__ void slab_reduce2_kernel(const float* __restrict__ slab, long long n, long long stride, int nslab,
                                     float* __restrict__ out, int accumulate, const float* __restrict__ out_scale) {
   const float alpha = out_scale ? *out_scale : 1.f;
+  float chk = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     float a = 0.f;
     for (int z = 0; z < nslab; ++z) a += slab[(long long)z * stride + i];
+    nf_note(chk, a);
     out[i] = a * alpha + (accumulate ? out[i] : 0.f);
   }
+  nf_commit(out_scale, chk);
 }
 
 }  // namespace

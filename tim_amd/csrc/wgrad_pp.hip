@@ -623,6 +623,7 @@ __global__ __launch_bounds__(768) void wgrad_ld_kernel(const WpGroup g) {
   else wl_consume<HT, 1, ABL>(lds, g.M, wave, lane, acc, pf);
 
   const int N = a.N, K = a.K;
+  float chk = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = a.n0 + wn * 64 + j * 16 + p;
@@ -631,6 +632,7 @@ __global__ __launch_bounds__(768) void wgrad_ld_kernel(const WpGroup g) {
       const int k = a.k0 + wk * 64 + i * 16 + 4 * gid;
       if (n < N && k < K) {
         float v[4] = {acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha};
+        nf_note(chk, v[0]); nf_note(chk, v[1]); nf_note(chk, v[2]); nf_note(chk, v[3]);
         float* dst = dW + (size_t)n * K + k;
         if (k + 3 < K && ((((size_t)n * K + k) & 3) == 0)) {
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(768) void wgrad_ld_kernel(const WpGroup g) {
       }
     }
   }
+  nf_commit(g.out_scale, chk);   // (the loader waves' bias sums come from the same dY rows: what overflows there overflows here)
 }
 
 template <typename HT, int ABL = 0, int MODE = 2>
@@ -707,6 +710,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpGroup g) {
   // D[row = k: 4 gid + r][col = n: p] per MFMA tile (i: k tile, j: n tile): a lane owns 4 consecutive k of one row n of dW
   const float alpha = g.out_scale ? *g.out_scale : 1.f;
   const int N = a.N, K = a.K;
+  float chk = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = a.n0 + wn * 64 + j * 16 + p;
@@ -715,6 +719,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpGroup g) {
       const int k = a.k0 + wk * 64 + i * 16 + 4 * gid;
       if (n < N && k < K) {
         float v[4] = {acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha};
+        nf_note(chk, v[0]); nf_note(chk, v[1]); nf_note(chk, v[2]); nf_note(chk, v[3]);
         float* dst = dW + (size_t)n * K + k;
         if (k + 3 < K && ((((size_t)n * K + k) & 3) == 0)) {
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -736,6 +741,7 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpGroup g) {
       db[n] = g.accumulate ? db[n] + s : s;
     }
   }
+  nf_commit(g.out_scale, chk);
 }
 
 }  // namespace

@@ -82,6 +82,8 @@ class Runtime:
         # the fp16 maximum for gradients that grow along the backward chain (LayerNorm's 1/std) and 2^-18 of the largest
         # cotangent before values go subnormal
         self.grad_scale_target = 16.0
+        self._gs_blocks = []   # this runtime's timhip_grad_scale blocks since the last grads_finite() (word 4 = non-finite flag)
+        self._nf_acc = None
         self._wcache = {}
         self._wparams = {}  # id(param) -> weakref: every weight this runtime has cast
         # dropout stream: seeded from torch's generator (torch.manual_seed / args.seed select the run's masks, as they do in the
@@ -257,7 +259,10 @@ class Runtime:
         from the largest |cotangent| - no host synchronisation."""
         if self.prec != L.PREC_F16:
             return None
-        gs = torch.zeros(4, dtype=torch.float32, device=dev)
+        gs = torch.zeros(8, dtype=torch.float32, device=dev)   # {S, 1/S, scratch, scratch, non-finite flag, 0, 0, 0}
+        self._gs_blocks.append(gs)
+        if len(self._gs_blocks) > 16:    # (many backward passes without a reader: fold on the device, no sync)
+            self._fold_flags()
         cots = [c for c in cotangents if c is not None and c.numel() > 0]
         if not cots:
             gs[:2] = 1.0
@@ -267,6 +272,26 @@ class Runtime:
             call("timhip_grad_scale", _parr(grp), (C.c_longlong * len(grp))(*[c.numel() for c in grp]), len(grp),
                  float(self.grad_scale_target), ptr(gs), _stream())
         return gs
+
+    def _fold_flags(self):
+        if self._gs_blocks:
+            f = torch.stack([g[4] for g in self._gs_blocks]).view(torch.int32).ne(0).any()
+            self._nf_acc = f if self._nf_acc is None else (self._nf_acc | f)
+            self._gs_blocks = []
+
+    def grads_finite(self, reset=True):
+        """False iff a weight / bias gradient written since the last call (by this runtime's backward passes) was inf or nan -
+        the fp16 mode's counterpart of GradScaler's inf check (reference scripts/train.py:351,357-363: skip the optimizer
+        step).  The kernels that write the gradients OR one device word (include/timhip.h: timhip_grad_scale); nothing is
+        synchronised until this call reads it.  Always True in the fp32 / bf16 modes (8 exponent bits: no overflow to watch).
+        Under HIP-graph replay the word belongs to the captured backward: it describes the latest replay."""
+        self._fold_flags()
+        if self._nf_acc is None:
+            return True
+        bad = bool(self._nf_acc.item())
+        if reset:
+            self._nf_acc = None
+        return not bad
 
     # ---- thin op wrappers ------------------------------------------------------------------------
     def gemm(self, epi, A, B, M, N, K, out0, ld0, out1=None, ld1=0, bias=None, res=None, ldres=0, aux=None,
