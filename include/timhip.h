@@ -143,6 +143,11 @@ int timhip_ln_partials_reduce(const float* partials, int nsets, int rows, int co
                               float* const* dbeta, void* stream);
 
 int timhip_version(void);
+/* The launchers' A/B knobs (TIMHIP_* environment variables, tim_amd/csrc/common.h: TimKnobs) are read once, at the first
+ * launch.  Test hook: read them again after changing the environment inside a process. */
+void timhip_reload_env(void);
+/* bit 0: the library was built with TUNING=1 (carries the measured-slower kernel variants and the ablation hooks) */
+int timhip_build_flags(void);
 const char* timhip_strerror(int code);
 
 /* bytes of the per-layer saved-for-backward block and of the scratch workspace */

@@ -64,7 +64,7 @@ def salt_off():
     F.graph_safe_dropout(DEV, enable=False)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16", "fp32", "fp16"])
 def test_replay_is_the_eager_step(prec, salt_off):
     cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
     B, nv, na = 4, 4, 2
@@ -137,3 +137,107 @@ def test_backward_of_a_stale_forward_is_refused(salt_off):
     model([static["visual"], static["audio"]], "encoder", te.detach(), nv, na)   # advances the salt
     with pytest.raises(RuntimeError, match="graph-safe dropout"):
         feats.sum().backward()
+
+
+def test_c2a_production_batch_replay_is_the_eager_step_fp16(salt_off):
+    """WHERE THE `graph_replay` NUMBERS OF THE BENCH LINE ARE QUOTED: C2a, B = 64 windows, fp16, .train() with the reference's
+    dropout rates - the production kernels (loader-wave / tile-walk NT GEMMs, grouped weight gradients, chained layers, fused
+    attention backward).  A replay and an eager step under the same dropout salt: identical logits, every gradient equal up
+    to the order of a few fp32 atomics."""
+    from tests.test_gpu_parity import build
+    from tim_amd.config import named_config
+    cfg = named_config("C2a")
+    B, nv, na = 64, 15, 10
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=2, dtype=torch.float32)
+    model = build(cfg, "fp16", sd).train()
+    static = {k: v.to(DEV).clone() for k, v in inp.items()}
+    R = []
+    fn = _step(model, static, nv, na, R)
+    word = F.graph_safe_dropout(DEV)
+    gs = GraphedStep(model, fn)
+    word.fill_(_i64(5 * K2 - F._SALT_STEP))
+    rep = _snap(model, gs())
+    word.fill_(_i64(5 * K2 - F._SALT_STEP))
+    eager = _snap(model, fn())
+    _same(rep, eager, 0)
+    assert len(rep[1]) == len(list(model.parameters())) - sum(1 for n, _ in model.named_parameters() if n.startswith("drloc_mlp"))
+    assert model.rt.grads_finite()
+    # the next replay draws other masks (the salt advanced on the device) and is again reproducible eagerly
+    rep2 = _snap(model, gs())
+    assert not torch.equal(rep2[0][0], rep[0][0])
+    word.fill_(_i64(5 * K2))                     # (where the word stood before that replay's own increment)
+    _same(rep2, _snap(model, fn()), 0)
+
+
+def test_detection_training_step_replay_is_the_eager_step(salt_off, monkeypatch):
+    """bench.py's `c4_train` graph replay: the detection TRAINING step (det tim.py:272-337 + scripts/train.py:212-349) captured
+    whole - query draw on the device (torch.randperm under capture, detection.py), on-device IoU labelling, encoder, focal +
+    DIoU losses, the EMA normaliser, backward.  A replay must equal an eager step fed THE SAME permutation and dropout
+    salt: drawn queries, regression targets, smoothed labels, IoUs, logits, loss, every gradient; consecutive replays draw
+    different queries and advance the EMA normaliser on the device."""
+    import bench
+    from tim_amd.config import named_config
+    cfg = named_config("C4")
+    cfg.num_layers = 2                                   # (two layers keep the eager reference run short; shapes are C4's)
+    B = 4
+    model, _ = bench.build_model(cfg, "fp16", torch.device(DEV), seed=0)
+    model.train()
+    batch = bench.make_batch(cfg, B, 0, 0, seed=100, dev=torch.device(DEV))
+    R = {"target": bench.make_det_targets(cfg, B, 6, 5, torch.device(DEV))}
+    word = F.graph_safe_dropout(DEV)
+    gs = GraphedStep(model, lambda: bench.det_train_step(model, batch, R["target"], R))
+    norm = R[("norm", 0)]
+    seen = []
+    for it in range(2):
+        word.fill_(_i64((7 + it) * K2 - F._SALT_STEP))
+        norm_before = norm.clone()
+        out = gs()
+        torch.cuda.synchronize()
+        rep = {"loss": out["loss"].clone(), "q": out["queries"][0].clone(), "off": out["offsets"][0].clone(),
+               "iou": out["ious"][0].clone(), "lab": [t.clone() for t in out["labels"][0]],
+               "cls": [t.detach().clone() for t in out["output"][0] if t is not None],
+               "reg": out["output"][1][0].detach().clone(),
+               "grads": {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}}
+        norm_after = norm.clone()
+        # the permutation the replay drew: every query is a row of the training pyramid, the same rows for every window
+        nq = model.num_queries
+        q = rep["q"].reshape(B, nq, 2)
+        assert torch.equal(q[0], q[-1])
+        pool = model.train_pool[0].to(DEV)
+        hit = (q[0][:, None, :] == pool[None]).all(-1)
+        assert bool((hit.sum(1) == 1).all())
+        sel = hit.float().argmax(1).cpu()
+        assert sel.unique().numel() == nq                                   # drawn without replacement
+        seen.append(sel)
+        # positives exist and the EMA advanced on the device by exactly the reference's recursion (det train.py:230)
+        npos = int(torch.isfinite(rep["off"][:, 0]).sum())
+        assert npos > 0
+        assert abs(norm_after.item() - (0.9 * norm_before.item() + 0.1 * max(npos, 1))) <= 1e-3
+        # eager step with the same permutation, salt and normaliser state
+        rest = torch.tensor([i for i in range(pool.shape[0]) if i not in set(sel.tolist())], dtype=torch.int64)
+        perm = torch.cat([sel, rest])
+        real_randperm = torch.randperm
+
+        def fed(n, *a, **kw):      # the eager draw is `torch.randperm(pool size)` on the host (detection.py, det tim.py:281)
+            return perm.clone() if (n == pool.shape[0] and not a and not kw) else real_randperm(n, *a, **kw)
+        monkeypatch.setattr(torch, "randperm", fed)
+        word.fill_(_i64((7 + it) * K2 - F._SALT_STEP))
+        norm.copy_(norm_before)
+        eg = bench.det_train_step(model, batch, R["target"], R)
+        torch.cuda.synchronize()
+        monkeypatch.undo()
+        assert torch.equal(eg["queries"][0], rep["q"])
+        assert torch.equal(eg["offsets"][0], rep["off"]) and torch.equal(eg["ious"][0], rep["iou"])
+        for a, b in zip(eg["labels"][0], rep["lab"]):
+            assert torch.equal(a, b)
+        for a, b in zip([t for t in eg["output"][0] if t is not None], rep["cls"]):
+            assert torch.equal(a.detach(), b)
+        assert torch.equal(eg["output"][1][0].detach(), rep["reg"])
+        assert abs(eg["loss"].item() - rep["loss"].item()) <= 1e-5 * max(1.0, abs(rep["loss"].item()))
+        assert abs(norm.item() - norm_after.item()) <= 1e-4
+        for n, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            s = rep["grads"][n].abs().max().item() + 1e-12
+            assert (p.grad - rep["grads"][n]).abs().max().item() <= 1e-4 * s, n
+    assert not torch.equal(seen[0], seen[1])                                 # a fresh draw per replay

@@ -277,13 +277,13 @@ def test_gemm_dropout_keep_bits(epi, M, N, prec):
     (2100, [(2000, 1000), (1000, 2000), (3000, 1000)]),                # one-block-per-CU kernels with ragged n / k tiles and rows
 ])
 @pytest.mark.parametrize("loaders", [True, False])
-def test_wgrad_group(M, shapes, accumulate, prec, loaders, monkeypatch):
+def test_wgrad_group(M, shapes, accumulate, prec, loaders, knobs):
     """several Linear weight gradients sharing M in one launch == the per-layer reference; biases optional.
     loaders: the one-block-per-CU kernel with four DMA loader waves (default) / its 8-wave form (TIMHIP_WGRAD_LD=0)"""
     if not loaders:
         if M < 2048:
             pytest.skip("small groups do not take the one-block-per-CU kernels")
-        monkeypatch.setenv("TIMHIP_WGRAD_LD", "0")
+        knobs(TIMHIP_WGRAD_LD="0")
     rt = Runtime(prec)
     items, refs = [], []
     for i, (N, K) in enumerate(shapes):
@@ -388,10 +388,10 @@ def test_attention_dropout(prec):
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("B,S,F,H,Dh,p", [(3, 155, 100, 2, 128, 0.1), (2, 125, 100, 1, 128, 0.0), (1, 160, 128, 2, 128, 0.1),
                                           (2, 192, 97, 1, 128, 0.0)])
-def test_attention_backward_fused_and_two_kernel(prec, fused, B, S, F, H, Dh, p, monkeypatch):
+def test_attention_backward_fused_and_two_kernel(prec, fused, B, S, F, H, Dh, p, knobs):
     """the production-shape backward in both forms: rows + keys kernels with the dS / P~ scratch (TIMHIP_ATTN_FUSED=0) and the
     one-kernel form that keeps dS / P~ in LDS (128-wide heads, 97..128 feature keys, S <= 192); with attention dropout"""
-    monkeypatch.setenv("TIMHIP_ATTN_FUSED", fused)
+    knobs(TIMHIP_ATTN_FUSED=fused)
     _attn_case(prec, B, S, F, H, Dh, p=p)
 
 
@@ -460,48 +460,66 @@ def test_fp16_scaled_gradient_operands():
     assert ref_dx.abs().max().item() > 0 and float(g.cpu().to(torch.float16).abs().max()) < 2e-6
 
 
+_PP_SHAPES = [(9920, 1024, 1024), (9920, 3072, 1024), (9920, 1024, 2048), (9925, 1000, 192), (3000, 2056, 64)]
+
+
+def _pp_knobs(knobs, loaders):
+    knobs(TIMHIP_GEMM_LD="0" if loaders is False else "1",
+          TIMHIP_GEMM_PF="0" if loaders == "no_prefetch" else "4",
+          TIMHIP_GEMM_PF_MR="0" if loaders == "no_prefetch" else "4",          # (multi-round shapes: off by default)
+          TIMHIP_GEMM_PF_MODE="2" if loaders == "prefetch_all" else "1",
+          TIMHIP_GEMM_LD1="1" if loaders == "one_barrier" else "0",
+          # (the 744-tile shape runs as 248 blocks of three tiles by default, gemm_nt_ldp_kernel; TIMHIP_GEMM_LDP=0: one tile per block)
+          TIMHIP_GEMM_LDP="0" if loaders == "one_tile_per_block" else "1",
+          TIMHIP_GEMM_DG="0", TIMHIP_GEMM_PT="0")
+
+
 @pytest.mark.parametrize("prec", H16)
-@pytest.mark.parametrize("M,N,K", [(9920, 1024, 1024), (9920, 3072, 1024), (9920, 1024, 2048), (9925, 1000, 192), (3000, 2056, 64)])
-@pytest.mark.parametrize("loaders", [False, True, "no_prefetch", "prefetch_all", "one_barrier", "one_tile_per_block"])
-def test_gemm_pingpong_kernel(prec, M, N, K, loaders, monkeypatch):
-    """gemm_pp.hip (one block per CU, 160 x 256 tiles, three-stage LDS ring): 8 consumer + 4 DMA loader waves with the L2
-    prefetch of the tile's share of its XCD's lines (the default; also without the prefetch, with every line prefetched, and
-    with one barrier per contraction step instead of two, TIMHIP_GEMM_LD1=1, and with one tile per block where the default
-    walks several, TIMHIP_GEMM_LDP=0), or 8 waves that issue their DMA pieces themselves
-    (gemm_nt_pp_kernel, TIMHIP_GEMM_LD=0): every epilogue the kernel carries, on the encoder layer's shapes and on ragged edges
-    (rows past M, columns past N, one / two / three contraction steps), against fp64"""
-    monkeypatch.setenv("TIMHIP_GEMM_LD", "0" if loaders is False else "1")
-    monkeypatch.setenv("TIMHIP_GEMM_PF", "0" if loaders == "no_prefetch" else "4")
-    monkeypatch.setenv("TIMHIP_GEMM_PF_MR", "0" if loaders == "no_prefetch" else "4")   # (multi-round shapes: off by default)
-    monkeypatch.setenv("TIMHIP_GEMM_PF_MODE", "2" if loaders == "prefetch_all" else "1")
-    monkeypatch.setenv("TIMHIP_GEMM_LD1", "1" if loaders == "one_barrier" else "0")
-    # (the 744-tile shape runs as 248 blocks of three tiles by default, gemm_nt_ldp_kernel; TIMHIP_GEMM_LDP=0: one tile per block)
-    monkeypatch.setenv("TIMHIP_GEMM_LDP", "0" if loaders == "one_tile_per_block" else "1")
-    monkeypatch.setenv("TIMHIP_GEMM_DG", "0")      # this test is about the one-tile-per-block kernel
-    monkeypatch.setenv("TIMHIP_GEMM_PT", "0")
+@pytest.mark.parametrize("M,N,K", _PP_SHAPES)
+@pytest.mark.parametrize("loaders", [False, True, "no_prefetch", "one_tile_per_block"])
+def test_gemm_pingpong_kernel(prec, M, N, K, loaders, knobs):
+    """gemm_pp.hip (one block per CU, 160 x 256 tiles, three-stage LDS ring) - the three kernels the product library carries:
+    8 consumer + 4 DMA loader waves with the L2 prefetch of the tile's share of its XCD's lines, one tile per block
+    (gemm_nt_ld_kernel) or a walk of 2-4 tiles (gemm_nt_ldp_kernel; the default for multi-round shapes, TIMHIP_GEMM_LDP=0: off),
+    also without the prefetch; and the 8 waves that issue their DMA pieces themselves (gemm_nt_pp_kernel, TIMHIP_GEMM_LD=0, the
+    fallback): every epilogue the kernel carries, on the encoder layer's shapes and on ragged edges (rows past M, columns
+    past N, one / two / three contraction steps), against fp64"""
+    _pp_knobs(knobs, loaders)
     _check_layer_gemm_epilogues(prec, M, N, K)
 
 
+@pytest.mark.tuning
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("M,N,K", _PP_SHAPES)
+@pytest.mark.parametrize("loaders", ["prefetch_all", "one_barrier"])
+def test_gemm_pingpong_kernel_tuning_variants(prec, M, N, K, loaders, knobs):
+    """TUNING=1 builds only: every line prefetched (measured: the scattered loads take the vector-memory path's time
+    themselves), one barrier per contraction step (TIMHIP_GEMM_LD1=1: +0.5 % of the step)"""
+    _pp_knobs(knobs, loaders)
+    _check_layer_gemm_epilogues(prec, M, N, K)
+
+
+@pytest.mark.tuning
 @pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("M,N,K", [(9920, 2048, 1024), (9920, 3072, 1024), (9920, 2048, 128), (9925, 3072, 192), (13120, 2048, 64 * 5)])
-def test_gemm_persistent_tile_kernel(prec, M, N, K, monkeypatch):
-    """gemm_nt_pt_kernel (round 3): a block walks 2 or 3 (4 at M = 13120) consecutive 160 x 256 tiles, the next tile's first
-    stages in flight during the epilogue (ring slot 2 is the transposition space); every epilogue, ragged last row panel,
-    2 .. 16 contraction steps"""
-    monkeypatch.setenv("TIMHIP_GEMM_DG", "0")
-    monkeypatch.setenv("TIMHIP_GEMM_PT", "1")
+def test_gemm_persistent_tile_kernel(prec, M, N, K, knobs):
+    """gemm_nt_pt_kernel (round 3; TUNING=1 builds only - measured equal to one tile per block): a block walks 2 or 3 (4 at
+    M = 13120) consecutive 160 x 256 tiles, the next tile's first stages in flight during the epilogue (ring slot 2 is the
+    transposition space); every epilogue, ragged last row panel, 2 .. 16 contraction steps"""
+    knobs(TIMHIP_GEMM_DG="0", TIMHIP_GEMM_PT="1")
     _check_layer_gemm_epilogues(prec, M, N, K)
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("M,N,K,offset", [(9920, 1024, 1024, 9), (9920, 2048, 1024, 9), (9920, 3072, 1024, 9), (9920, 1024, 2048, 9),
                                           (9920, 1024, 3072, 3), (8000, 1024, 128, 1), (13120, 1024, 192, 21)])
-def test_gemm_dual_group_kernel(prec, M, N, K, offset, monkeypatch):
-    """gemm_nt_dg_kernel (round 3: two wave groups on different 160 x 128 tiles a few steps apart, persistent over tile pairs,
-    2-slot rings): every epilogue the encoder layers use, 1 / 2 / 3 pairs per block, 2 .. 48 contraction steps, several group
-    offsets (the offset only changes WHEN things happen - results must not depend on it), against fp64"""
-    monkeypatch.setenv("TIMHIP_GEMM_DG", "1")
-    monkeypatch.setenv("TIMHIP_GEMM_DG_OFFSET", str(offset))
+def test_gemm_dual_group_kernel(prec, M, N, K, offset, knobs):
+    """gemm_nt_dg_kernel (round 3; TUNING=1 builds only - measured 13 % slower): two wave groups on different 160 x 128 tiles a
+    few steps apart, persistent over tile pairs, 2-slot rings: every epilogue the encoder layers use, 1 / 2 / 3 pairs per
+    block, 2 .. 48 contraction steps, several group offsets (the offset only changes WHEN things happen - results must not
+    depend on it), against fp64"""
+    knobs(TIMHIP_GEMM_DG="1", TIMHIP_GEMM_DG_OFFSET=str(offset))
     _check_layer_gemm_epilogues(prec, M, N, K)
 
 

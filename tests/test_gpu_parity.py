@@ -528,9 +528,11 @@ def test_c2a_production_batch_end_to_end(prec):
           % (prec, worst, sum(v.numel() for k, v in res["outs"].items() if k != "feats"), wg, wc, wr))
 
 
+@pytest.mark.tuning
 @pytest.mark.parametrize("train", [False, True])
-def test_c2a_fused_residual_layernorm_epilogue(train, monkeypatch):
-    """gemm_nt_ldln_kernel (TIMHIP_FUSE_LN=1, round 3): out-projection / linear2 with the LayerNorm that
+def test_c2a_fused_residual_layernorm_epilogue(train, knobs):
+    """TUNING=1 builds only (measured 64.2 us against 62.5 us for the two kernels: not in the product library).
+    gemm_nt_ldln_kernel (TIMHIP_FUSE_LN=1, round 3): out-projection / linear2 with the LayerNorm that
     follows inside the GEMM's epilogue - the four column tiles of a row panel exchange per-row (sum, sum of squares) through
     memory.  At the production batch (M = 9920: the only shapes it takes) the whole model, forward and backward, must (a) stay
     within the fp16 tolerance of the fp32 oracle (the two paths are two fp16 evaluations: the statistics are summed in another
@@ -546,8 +548,7 @@ def test_c2a_fused_residual_layernorm_epilogue(train, monkeypatch):
     runs = {}
     for name, env in (("two_kernels", {"TIMHIP_FUSE_LN": "0"}), ("fused", {"TIMHIP_FUSE_LN": "1", "TIMHIP_FUSE_LN_SPIN": "100000"}),
                       ("timed_out", {"TIMHIP_FUSE_LN": "1", "TIMHIP_FUSE_LN_SPIN": "0"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        knobs(**env)
         m.zero_grad(set_to_none=True)
         m.rt.step = 100          # the same dropout key (functional.Runtime.next_seed) for every run
         runs[name] = run_model(m, c["inp"], nv, na, True, c["R"])

@@ -142,6 +142,8 @@ _SIGS = {
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),
+    "timhip_reload_env": (None, []),
+    "timhip_build_flags": (C.c_int, []),
     "timhip_dp_reduce": (C.c_int, [i32, vp, i32, C.c_longlong, f32, vp, vp]),
     "timhip_split3_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "timhip_label_queries": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
@@ -170,6 +172,16 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def reload_env():
+    """the launchers read their TIMHIP_* A/B knobs once; call this after changing one inside a process (tests, tools)"""
+    load().timhip_reload_env()
+
+
+def tuning_build():
+    """True when the loaded library is a TUNING=1 build (carries the measured-slower kernel variants)"""
+    return bool(load().timhip_build_flags() & 1)
 
 
 def exported_symbols():

@@ -1,6 +1,7 @@
 // extern "C" stage entry points: one post-norm encoder layer forward/backward
 // (transformers.py:92-111), plus small utilities.  Pure launch sequencing: no
 // allocation, no synchronisation, no retained state.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -148,9 +149,43 @@ int wgrad(int prec, const void* dY, int ldy, int Nout, const void* X, int ldx, i
 
 const unsigned long long* tim_salt_ptr = nullptr;
 
+// ---- environment knobs, cached (common.h: TimKnobs) ----------------------------------------------------------------
+namespace {
+TimKnobs g_knobs;
+std::atomic<int> g_knobs_state{0};   // 0: not read, 1: valid
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; }
+void read_knobs(TimKnobs& k) {
+  k.gemm_pp = env_int("TIMHIP_GEMM_PP", 1); k.gemm_ld = env_int("TIMHIP_GEMM_LD", 1); k.gemm_pf = env_int("TIMHIP_GEMM_PF", 4);
+  k.gemm_pf_mode = env_int("TIMHIP_GEMM_PF_MODE", 1); k.gemm_pf_mr = env_int("TIMHIP_GEMM_PF_MR", 0);
+  k.gemm_ldp = env_int("TIMHIP_GEMM_LDP", 1); k.gemm_ld1 = env_int("TIMHIP_GEMM_LD1", 0); k.gemm_pt = env_int("TIMHIP_GEMM_PT", 0);
+  k.gemm_dg = env_int("TIMHIP_GEMM_DG", 0); k.gemm_dg_offset = env_int("TIMHIP_GEMM_DG_OFFSET", 9);
+  k.fuse_ln = env_int("TIMHIP_FUSE_LN", 0); k.fuse_ln_spin = env_int("TIMHIP_FUSE_LN_SPIN", 100000);
+  k.wgrad_pp = env_int("TIMHIP_WGRAD_PP", 1); k.wgrad_ld = env_int("TIMHIP_WGRAD_LD", 1); k.wgrad_pf = env_int("TIMHIP_WGRAD_PF", 4);
+  k.attn_waves = env_int("TIMHIP_ATTN_WAVES", 0); k.attn_fused = env_int("TIMHIP_ATTN_FUSED", 1);
+  k.attn_pipe = env_int("TIMHIP_ATTN_PIPE", 1);
+}
+}  // namespace
+const TimKnobs& tim_knobs() {
+  if (g_knobs_state.load(std::memory_order_acquire) == 0) {   // (a benign race reads the same environment twice)
+    TimKnobs k;
+    read_knobs(k);
+    g_knobs = k;
+    g_knobs_state.store(1, std::memory_order_release);
+  }
+  return g_knobs;
+}
+
 extern "C" {
 
 int timhip_version(void) { return TIMHIP_VERSION; }
+void timhip_reload_env(void) { g_knobs_state.store(0, std::memory_order_release); (void)tim_knobs(); }
+int timhip_build_flags(void) {
+#ifdef TIMHIP_TUNING
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int timhip_dropout_salt(const unsigned long long* dev_salt) {
   tim_salt_ptr = dev_salt;
@@ -259,8 +294,7 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
   // TIMHIP_FUSE_LN=1 (round 3, opt-in): the LayerNorm that follows the out-projection / linear2 inside the GEMM's epilogue
   // (gemm_nt_ldln_kernel: the column tiles of a row panel exchange row statistics); the stand-alone LayerNorm stays behind it as
   // a launch that exits at once unless a tile's wait timed out.  Falls back to the two kernels wherever the shape does not fit.
-  const char* fuse_v = getenv("TIMHIP_FUSE_LN");   // (read per call: tests switch it inside one process)
-  const bool fuse_ln = fuse_v && fuse_v[0] == '1';
+  const bool fuse_ln = tim_knobs().fuse_ln == 1;
   const uint32_t* ln_run_if = nullptr;
   bool fused1 = false;
   if (fuse_ln && h16_storage(prec) && !split(TIMHIP_DESC_OUTPROJ_SPLIT)) {
@@ -394,16 +428,25 @@ static int layer_bwd_data_impl(const TimDesc& d, const TimLayerParams* w, const 
   TimEpi e = epi0();
   e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;   // u = dropmask * gelu'(pre-activation), written by the forward
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_MULAUX_T, df, E, w->l2_wt, E, M, FF, E, e, 1, s))) return rc;
-  // the FFN branch's input gradient du W1 as a 16-bit product; norm1 backward adds it to dy2 (the residual branch) as it reads
+  // the FFN branch's input gradient du W1 as an operand-dtype product; norm1 backward adds it to dy2 (the residual branch) as it
+  // reads.  fp16 (11 bits under the gradient scale) and the fp32-storage modes (nothing is rounded) take this form; plain bf16
+  // would round the branch to 8 bits per layer, so there the product joins the fp32 stream directly (dy2 += du W1, fp32)
+  const bool branch_split = prec != TIMHIP_PREC_BF16;
   e = epi0();
-  e.out0 = Tb; e.ld0 = E;
-  if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
+  if (branch_split) {
+    e.out0 = Tb; e.ld0 = E;
+    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
+  } else {
+    e.out0 = f32b; e.ld0 = E; e.res = f32a; e.ldres = E;
+    if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_ADD_F32, du, FF, w->l1_wt, FF, M, E, FF, e, 1, s))) return rc;
+  }
+  const float* ln1_in = branch_split ? f32a : f32b;
   // norm1 backward -> dy1 (fp32) and da = dropout1-mask * dy1 (T)
-  float* dy1 = dx_in_add ? dx_in : f32b;
-  if ((rc = tim_layernorm_bwd(prec, f32a, E, y1, E, st1, M, E, 0, w->n1_w, dy1, E, da, E, d.p_drop, d.seed,
+  float* dy1 = dx_in_add ? dx_in : (branch_split ? f32b : f32a);
+  if ((rc = tim_layernorm_bwd(prec, ln1_in, E, y1, E, st1, M, E, 0, w->n1_w, dy1, E, da, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b,
                               g->ln_partials ? g->ln_partials + tim_layernorm_bwd_ws(M, E) / sizeof(float) : (float*)(ws + W.lnp), s,
-                              g->ln_partials != nullptr, gs_in, Tb, E, gs_out))) return rc;
+                              g->ln_partials != nullptr, gs_in, branch_split ? Tb : nullptr, E, gs_out))) return rc;
   // do = da Wo
   e = epi0();
   e.out0 = Tc; e.ld0 = E;

@@ -461,17 +461,14 @@ AttnArgsM make_args2(const TimDesc& d) {
 static inline int rows_waves(int S) {
   int n = (S + 31) / 32;
   n = n < 1 ? 1 : (n > 8 ? 8 : n);
-  if (const char* v = getenv("TIMHIP_ATTN_WAVES")) {   // (A/B knob, as in attention_mfma.hip)
-    const int w = atoi(v);
-    if (w >= 1 && w <= 8) n = w;
-  }
+  const int w = tim_knobs().attn_waves;   // (A/B knob, as in attention_mfma.hip)
+  if (w >= 1 && w <= 8) n = w;
   return n;
 }
 
 // fused form: DH = 128, 97..128 feature keys, K / V / dS / P~ within the 160 KB of LDS (S <= 192)
 static inline bool fused_fits(const TimDesc& d) {
-  const char* v = getenv("TIMHIP_ATTN_FUSED");
-  if (v && v[0] == '0') return false;
+  if (tim_knobs().attn_fused == 0) return false;
   const int SP = (d.S + 31) & ~31;
   return d.E / d.H == 128 && (d.F + 31) / 32 == 4 && (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 <= 160 * 1024;
 }

@@ -474,10 +474,8 @@ AttnArgsM make_args(const TimDesc& d) {
 static inline int attn_waves(int S) {
   int n = (S + 31) / 32;
   n = n < 1 ? 1 : (n > 4 ? 4 : n);
-  if (const char* v = getenv("TIMHIP_ATTN_WAVES")) {   // (A/B knob: fewer waves than row blocks - a wave then walks several)
-    const int w = atoi(v);
-    if (w >= 1 && w <= 8) n = w;
-  }
+  const int w = tim_knobs().attn_waves;   // (A/B knob: fewer waves than row blocks - a wave then walks several)
+  if (w >= 1 && w <= 8) n = w;
   return n;
 }
 

@@ -269,6 +269,31 @@ __device__ __forceinline__ void gelu_both_f(float x, float& gl, float& dg) {
   dg = fmaf(x * kInvSqrt2Pi, e, ph);
 }
 
+// A/B knobs of the launchers, read from the environment ONCE (first launch) instead of per launch - the step issues 144
+// launches and the host is within 36 % of being the bottleneck.  timhip_reload_env() (test hook, include/timhip.h) re-reads
+// them; the knobs marked (T) select kernels that exist only in a TUNING=1 build of the library and are ignored otherwise.
+struct TimKnobs {
+  int gemm_pp;        // TIMHIP_GEMM_PP      0: no one-block-per-CU NT kernels at all (the two-blocks-per-CU kernels of gemm.hip)
+  int gemm_ld;        // TIMHIP_GEMM_LD      0: the 8-wave ping-pong kernel instead of loader waves + L2 prefetch
+  int gemm_pf;        // TIMHIP_GEMM_PF      L2 prefetch distance in stages (default 4, 0: off)
+  int gemm_pf_mode;   // TIMHIP_GEMM_PF_MODE 1: a tile touches its share of the XCD's lines, 2: all its lines
+  int gemm_pf_mr;     // TIMHIP_GEMM_PF_MR   prefetch distance of multi-round shapes run one tile per block (default 0)
+  int gemm_ldp;       // TIMHIP_GEMM_LDP     0: one tile per block where the default walks 2-4
+  int gemm_ld1;       // TIMHIP_GEMM_LD1 (T) 1: one barrier per contraction step
+  int gemm_pt;        // TIMHIP_GEMM_PT  (T) 1: 8-wave persistent-tile kernel
+  int gemm_dg;        // TIMHIP_GEMM_DG  (T) 1: dual-group persistent kernel;  gemm_dg_offset: TIMHIP_GEMM_DG_OFFSET
+  int gemm_dg_offset;
+  int fuse_ln;        // TIMHIP_FUSE_LN  (T) 1: residual + LayerNorm inside the out-projection / linear2 epilogue
+  int fuse_ln_spin;   // TIMHIP_FUSE_LN_SPIN
+  int wgrad_pp;       // TIMHIP_WGRAD_PP     0: no one-block-per-CU weight-gradient grid
+  int wgrad_ld;       // TIMHIP_WGRAD_LD     0: its 8-wave merged-phase form
+  int wgrad_pf;       // TIMHIP_WGRAD_PF     its L2 prefetch distance (default 4)
+  int attn_waves;     // TIMHIP_ATTN_WAVES   waves per attention block (0: by shape)
+  int attn_fused;     // TIMHIP_ATTN_FUSED   0: two-kernel attention backward
+  int attn_pipe;      // TIMHIP_ATTN_PIPE    0: one (window, head) per attention-forward block (no persistent pipeline)
+};
+const TimKnobs& tim_knobs();
+
 // Non-finite watch of the fp16 gradient path.  `out_scale` (where a kernel takes one) points at word 1 of the block
 // timhip_grad_scale writes: {S, 1/S, scratch, scratch, FLAG, 0, 0, 0}.  Every kernel that writes FINAL fp32 gradients
 // through out_scale folds what it writes into `chk` (0 * v stays 0 unless v is inf / nan, then chk is nan for good) and ORs

@@ -809,8 +809,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
   const int Kp = round_up(K, 64);
   TimGemmScope timing(2.0 * M * N * K / (te.reserved > 1 ? te.reserved : 1), s);   // te.reserved: operand replication (split GEMM)
   // production-batch layer shapes: the one-block-per-CU ping-pong kernel (TIMHIP_GEMM_PP=0 turns it off: A/B switch)
-  static const bool pp_on = [] { const char* v = getenv("TIMHIP_GEMM_PP"); return !(v && v[0] == '0'); }();
-  if (pp_on && h16_storage(precision) && tim_gemm_pp_wins(M, N, Kp, splitk)) {
+  if (tim_knobs().gemm_pp != 0 && h16_storage(precision) && tim_gemm_pp_wins(M, N, Kp, splitk)) {
     const int rc = tim_gemm_nt_pp(precision, epi, A, lda, B, ldb, M, N, Kp, &e, s);
     if (rc != TIMHIP_EUNSUPPORTED) return rc;
   }

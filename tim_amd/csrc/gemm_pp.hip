@@ -26,6 +26,7 @@
 //   WAR  stage (t+2) % 3 = (t-1) % 3 is refilled from G0's MFMA phase of step t on; the last fragment reads of step t-1
 //        (G1's LOAD phase) were waited for (lgkmcnt) BEFORE a barrier G0 has to pass to get there.
 #include <stdlib.h>
+#include <mutex>
 
 #include "gemm_epi.h"
 
@@ -1106,6 +1107,7 @@ __global__ __launch_bounds__(512) void gemm_nt_dg_kernel(const HT* __restrict__ 
   }
 }
 
+#ifdef TIMHIP_TUNING   // (measured 13 % slower than one tile per block, DESIGN.md section 5c: tuning builds only)
 template <typename HT, int EPI>
 void launch_dg(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, int offset_phases, hipStream_t s) {
   const size_t shmem = 2 * (size_t)DG_RING;
@@ -1117,6 +1119,8 @@ void launch_dg(const void* A, int lda, const void* B, int ldb, int M, int N, int
   hipLaunchKernelGGL((gemm_nt_dg_kernel<HT, EPI>), dim3(npairs / ppb), dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N,
                      K, e, ppb, offset_phases);
 }
+
+#endif
 
 template <typename HT, int EPI>
 void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, hipStream_t s) {
@@ -1151,15 +1155,15 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   }
+  const TimKnobs& kn = tim_knobs();
   const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
+#ifdef TIMHIP_TUNING
   if constexpr (EPI != TIMHIP_EPI_DROP_RES_F32) {   // (that epilogue's residual prefetch leaves no registers for the tile loop's state)
-    // two or three full rounds of tiles: the persistent-tile kernel - TIMHIP_GEMM_PT=1 only (a tested A/B switch, not the default:
-    // measured equal to one tile per block within the run-to-run spread, in_proj forward 71.8 vs 71.5 us, linear1 61.8 vs 60.3,
-    // linear2 input gradient 50.7 vs 50.5 - the hardware already overlaps the next round's block launches and prologues with the
-    // current round's tail; what a round costs beyond its main loop is the epilogue's own drain)
+    // two or three full rounds of tiles: the 8-wave persistent-tile kernel - TIMHIP_GEMM_PT=1, tuning builds only (measured equal
+    // to one tile per block within the run-to-run spread, in_proj forward 71.8 vs 71.5 us, linear1 61.8 vs 60.3, linear2 input
+    // gradient 50.7 vs 50.5 - profiles/r03_nt_kernel_variants_ab.txt)
     const int tiles = (int)grid.x, tpb = (tiles + 255) / 256;
-    const char* ptv = getenv("TIMHIP_GEMM_PT");
-    if (tpb >= 2 && tpb <= 4 && tiles % tpb == 0 && ((N + PP_BN - 1) / PP_BN) % tpb == 0 && K >= 128 && ptv && ptv[0] == '1' && e.a_wrap == 0) {
+    if (tpb >= 2 && tpb <= 4 && tiles % tpb == 0 && ((N + PP_BN - 1) / PP_BN) % tpb == 0 && K >= 128 && kn.gemm_pt == 1 && e.a_wrap == 0) {
       static PerDeviceOnce pt_attr;
       if (pt_attr.first())
         (void)hipFuncSetAttribute((const void*)gemm_nt_pt_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -1168,17 +1172,14 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
       return;
     }
   }
+#endif
   // Default: the loader-wave kernel with the L2 prefetch (round 3: in the step 5.66 ms with the 8-wave kernel, 5.60-5.65 with
   // loader waves, 5.41-5.44 with loader waves + prefetch 4 stages ahead, NT GEMMs 763 -> 816 TFLOP/s; prefetch distance 2 / 3 / 5
   // / 6 / 8: +1.0 / +0.5 / +0.2 / +0.7 / +0.8 % of the step; every tile prefetching ALL its lines: 5.83-5.89 ms, the
-  // prefetch loads then take the vector-memory path's time themselves).  TIMHIP_GEMM_LD=0: the 8-wave kernels.
-  const char* ldv = getenv("TIMHIP_GEMM_LD");
-  if (!(ldv && ldv[0] == '0') && e.a_wrap == 0) {
-    const char* pfv = getenv("TIMHIP_GEMM_PF");   // L2 prefetch distance in stages (0: off)
-    const char* pfm = getenv("TIMHIP_GEMM_PF_MODE");
+  // prefetch loads then take the vector-memory path's time themselves).  TIMHIP_GEMM_LD=0: the 8-wave kernel (fallback).
+  if (kn.gemm_ld != 0 && e.a_wrap == 0) {
     // multi-round shapes (more than 256 tiles; TIMHIP_GEMM_PF_MR): no prefetch - their tiles drift apart after the first round and
     // a share covers a twelfth of a panel; in the step distance 0 / 2 / 4 / 6 / 8 / 12 for them: 5.29 / 5.32 / 5.32 / 5.34 / 5.34 / 5.34 ms
-    const char* pfmr = getenv("TIMHIP_GEMM_PF_MR");
     // Two to four full rounds of tiles run as ONE round of blocks that walk tpb column tiles each (gemm_nt_ldp_kernel;
     // TIMHIP_GEMM_LDP=0: one tile per block) - the tiles of an XCD stay in step, so the prefetch shares apply to them.  In the
     // step 5.343 -> 5.314 ms (four interleaved runs per arm, every run of the walk below every run of the one-tile kernel).
@@ -1186,34 +1187,34 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     // spilled; against the restored spill-free one-tile kernel the walk first LOST 1.3 % - it spilled 9-21 registers itself,
     // the epilogue's loop-invariant lane arithmetic having been hoisted in front of the tile loop and held across the main
     // loop; with the lane id laundered once per tile (8 / 5 / 1 spills on the three epilogues that use it) it wins 0.5 %.
-    const char* ldpv = getenv("TIMHIP_GEMM_LDP");
     const int tiles_ = (int)grid.x, tiles_n_ = (N + PP_BN - 1) / PP_BN;
     int tpb = 1;
-    if (!(ldpv && ldpv[0] == '0') && tiles_ > 256) {
+    if (kn.gemm_ldp != 0 && tiles_ > 256) {
       const int want = (tiles_ + 255) / 256;
       if (want <= 4 && tiles_n_ % want == 0 && tiles_ % want == 0 && K >= 128) tpb = want;
     }
-    const int pf_d_ = (grid.x > 256 && tpb == 1) ? (pfmr ? atoi(pfmr) : 0) : (pfv ? atoi(pfv) : 4);
+    const int pf_d_ = (grid.x > 256 && tpb == 1) ? kn.gemm_pf_mr : kn.gemm_pf;
     const dim3 grid_(tiles_ / tpb);
-    const char* l1v = getenv("TIMHIP_GEMM_LD1");   // 1: one barrier per contraction step
-    if (l1v && l1v[0] == '1') {
+#ifdef TIMHIP_TUNING
+    if (kn.gemm_ld1 == 1) {   // one barrier per contraction step (measured: +4.6 % isolated, +0.5 % in the step)
       static PerDeviceOnce attr_l1;
       if (attr_l1.first())
         (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW, true>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
-                         grid.x > 256 ? (pfmr ? atoi(pfmr) : 0) : (pfv ? atoi(pfv) : 4), pfm ? atoi(pfm) : 1);
+                         grid.x > 256 ? kn.gemm_pf_mr : kn.gemm_pf, kn.gemm_pf_mode);
       return;
     }
+#endif
     if (tpb > 1) {
       static PerDeviceOnce attr_p;
       if (attr_p.first())
         (void)hipFuncSetAttribute((const void*)gemm_nt_ldp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL((gemm_nt_ldp_kernel<HT, EPI, TMW>), grid_, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N,
-                         K, e, pf_d_, pfm ? atoi(pfm) : 1, tpb);
+                         K, e, pf_d_, kn.gemm_pf_mode, tpb);
       return;
     }
     hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
-                       pf_d_, pfm ? atoi(pfm) : 1);
+                       pf_d_, kn.gemm_pf_mode);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
@@ -1225,8 +1226,16 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
 // `fail` (out): the device word the stand-alone LayerNorm behind this launch takes as run_if (see the kernel's header).
 int tim_gemm_nt_pp_ln(int precision, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
                       const TimLnFuse& lf, const uint32_t** fail, hipStream_t s) {
+#ifndef TIMHIP_TUNING
+  // Product builds do not carry the fused kernel: measured 64.2 us (fused GEMM 59.5 + the stand-by LayerNorm launch 4.7) against
+  // 62.5 us for the two kernels, it stays a tuning-build experiment; the layer runs its two-kernel path.
+  (void)precision; (void)A; (void)lda; (void)B; (void)ldb; (void)M; (void)N; (void)K; (void)epi_dev; (void)lf; (void)fail; (void)s;
+  return TIMHIP_EUNSUPPORTED;
+#else
   const EpiDev& e = *reinterpret_cast<const EpiDev*>(epi_dev);
   constexpr int TMW = 5, BM = 32 * TMW;
+  // (N: the widths the stand-by LayerNorm behind this launch supports - the same predicate, so the pair is all-or-nothing)
+  if (N != 512 && N != 1024 && N != 2048) return TIMHIP_EUNSUPPORTED;
   if (!h16_storage(precision) || M % BM || N % PP_BN || K % 64 || K < 128 || !e.vec || e.a_wrap != 0 || !e.res || !lf.xt || !lf.stats ||
       !lf.g || !lf.b)
     return TIMHIP_EUNSUPPORTED;
@@ -1234,12 +1243,16 @@ int tim_gemm_nt_pp_ln(int precision, const void* A, int lda, const void* B, int 
   if (tiles > 256 || tiles < 128 || N / PP_BN > 8 || (lf.ldt % 4) || (lf.xf && lf.ldx % 4)) return TIMHIP_EUNSUPPORTED;   // one co-resident round
   if (lf.mask_out && (lf.mask_cols % (32 * (N / PP_BN)) || ((uintptr_t)lf.mask_out & 3))) return TIMHIP_EUNSUPPORTED;
   // per-device scratch: partial sums, flags, {epoch, done, fail}
+  // (one scratch block per device, allocated under a lock at first use - which must not be inside a graph capture; concurrent
+  //  fused launches on one device from several streams would share it: the tuning experiment runs one stream)
   struct Scratch { float2* part; uint32_t* flags; uint32_t* ctl; };
   static Scratch scr[32] = {};
+  static std::mutex scr_lock;
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = dev < 0 ? 0 : (dev > 31 ? 31 : dev);
-  if (!scr[dev].part) {   // (first use: not inside a graph capture)
+  std::lock_guard<std::mutex> hold(scr_lock);
+  if (!scr[dev].part) {
     char* p = nullptr;
     const size_t bytes = 256 * (size_t)BM * sizeof(float2) + 256 * 4 + 64;
     if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) return TIMHIP_EUNSUPPORTED;
@@ -1250,18 +1263,17 @@ int tim_gemm_nt_pp_ln(int precision, const void* A, int lda, const void* B, int 
   f.mbits = (lf.mask_out && lf.mask_p > 0.f) ? (uint32_t*)lf.mask_out : nullptr;
   f.mwords = lf.mask_cols / 32; f.mthr = lf.mask_p > 0.f ? drop_threshold(lf.mask_p) : 0u; f.mseed = TimSeed(lf.mask_seed); f.msite = lf.mask_site;
   f.part = scr[dev].part; f.flags = scr[dev].flags; f.ctl = scr[dev].ctl;
-  const char* sl = getenv("TIMHIP_FUSE_LN_SPIN");   // polls (~0.3 us each) before a tile gives up: default ~30 ms
-  f.spin_limit = sl ? (uint32_t)atoi(sl) : 100000u;
+  f.spin_limit = (uint32_t)tim_knobs().fuse_ln_spin;   // polls (~0.3 us each) before a tile gives up: default ~30 ms
   const size_t shmem = (size_t)PP_NST * (BM + PP_BN) * PP_ROWB;
-  const char* pfv = getenv("TIMHIP_GEMM_PF");
   static PerDeviceOnce attr_set[2];
   const int hi = precision == TIMHIP_PREC_F16 ? 1 : 0;
   if (attr_set[hi].first())
     DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)gemm_nt_ldln_kernel<HT, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   DISPATCH_H16(precision, hipLaunchKernelGGL((gemm_nt_ldln_kernel<HT, TMW>), dim3(tiles), dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B,
-                                            ldb, M, N, K, e, f, pfv ? atoi(pfv) : 4));
+                                            ldb, M, N, K, e, f, tim_knobs().gemm_pf));
   if (fail) *fail = scr[dev].ctl;   // (run_if convention of tim_layernorm_fwd: see the kernel's header)
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+#endif
 }
 
 // Is this problem one for the ping-pong kernel?  It needs enough 160 x 256 tiles to fill the 256 CUs about evenly: the
@@ -1275,6 +1287,7 @@ bool tim_gemm_pp_wins(int M, int N, int K, int splitk) {
 
 // Shapes for the dual-group persistent kernel: whole 160 x 256 tile pairs, at least two contraction steps, an even spread of the
 // pairs over the blocks, vectorised epilogue operands.
+#ifdef TIMHIP_TUNING
 static bool tim_gemm_dg_ok(int M, int N, int K, const EpiDev& e) {
   if (M % DG_BM || N % (2 * DG_BN) || K % 64 || K < 128 || !e.vec || !e.vec8) return false;
   const int npairs = (M / DG_BM) * (N / (2 * DG_BN));
@@ -1282,19 +1295,19 @@ static bool tim_gemm_dg_ok(int M, int N, int K, const EpiDev& e) {
   return npairs >= 192 && npairs % ppb == 0;
 }
 
+#endif
+
 int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
                    hipStream_t s) {
   const EpiDev& e = *reinterpret_cast<const EpiDev*>(epi_dev);
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
-  // TIMHIP_GEMM_DG=1: the dual-group persistent kernel where the shape allows (an A/B switch and a tested alternative, NOT the
-  // default: measured 13 % slower over the layer's eight shapes than the one-tile-per-block kernel - its 160 x 128 group tiles
-  // stage 72 KiB per step pair where the 160 x 256 tile stages 52, and the global -> LDS path (~30 B/clk/CU), not the matrix
-  // pipe, is what bounds these loops; the hidden epilogues do not pay for that - DESIGN.md section 5c);
-  // TIMHIP_GEMM_DG_OFFSET: barriers group 1 runs behind group 0 (odd)
-  const char* dgv = getenv("TIMHIP_GEMM_DG");
-  if (dgv && dgv[0] == '1' && tim_gemm_dg_ok(M, N, K, e) && e.a_wrap == 0) {
-    const char* ov = getenv("TIMHIP_GEMM_DG_OFFSET");
-    int off = ov ? atoi(ov) : 9;
+#ifdef TIMHIP_TUNING
+  // TIMHIP_GEMM_DG=1 (tuning builds): the dual-group persistent kernel where the shape allows - measured 13 % slower over the
+  // layer's eight shapes than the one-tile-per-block kernel: its 160 x 128 group tiles stage 72 KiB per step pair where the
+  // 160 x 256 tile stages 52, and the global -> LDS path (~30 B/clk/CU), not the matrix pipe, is what bounds these loops; the hidden
+  // epilogues do not pay for that - DESIGN.md section 5c; TIMHIP_GEMM_DG_OFFSET: barriers group 1 runs behind group 0 (odd)
+  if (tim_knobs().gemm_dg == 1 && tim_gemm_dg_ok(M, N, K, e) && e.a_wrap == 0) {
+    int off = tim_knobs().gemm_dg_offset;
     if (off < 1) off = 1;
     off |= 1;
     switch (epi) {
@@ -1310,6 +1323,7 @@ int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B
     return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
   }
 plain:
+#endif
   switch (epi) {
 #define CASE(X) case X: DISPATCH_H16(precision, (launch_pp<HT, X>(A, lda, B, ldb, M, N, K, e, s))); break;
     CASE(TIMHIP_EPI_STORE_T)

@@ -434,8 +434,7 @@ int tim_wgrad_group_h16(int precision, const TimWgradItem* it, int n, int M, int
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
   if (!it || n < 1 || n > WG_MAX || M <= 0) return TIMHIP_EINVAL;
   // an encoder layer of a production batch: the one-block-per-CU ping-pong grid (wgrad_pp.hip; TIMHIP_WGRAD_PP=0: A/B switch)
-  static const bool pp_on = [] { const char* v = getenv("TIMHIP_WGRAD_PP"); return !(v && v[0] == '0'); }();
-  if (pp_on && tim_wgrad_pp_wins(it, n, M)) {
+  if (tim_knobs().wgrad_pp != 0 && tim_wgrad_pp_wins(it, n, M)) {
     double fl = 0.0;
     for (int i = 0; i < n; ++i) fl += 2.0 * M * it[i].Nout * it[i].Kout;
     TimGemmScope timing(fl, s);

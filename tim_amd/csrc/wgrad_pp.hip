@@ -763,7 +763,7 @@ int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int 
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
   WpGroup g;
   g.n = n; g.M = M; g.accumulate = accumulate ? 1 : 0; g.out_scale = out_scale;
-  { const char* v = getenv("TIMHIP_WGRAD_PF"); g.pf_dist = v ? atoi(v) : 4; }
+  g.pf_dist = tim_knobs().wgrad_pf;
   g.tile0[0] = 0;
   for (int i = 0; i < WP_MAX; ++i) {
     if (i >= n) {
@@ -785,8 +785,7 @@ int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int 
     DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_ld_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   }
   // the 12-wave loader form is the default; TIMHIP_WGRAD_LD=0 selects the 8-wave merged-phase kernel (A/B switch)
-  const char* ldv = getenv("TIMHIP_WGRAD_LD");   // (read per call: tests switch it inside one process)
-  const bool ld_on = !(ldv && ldv[0] == '0');
+  const bool ld_on = tim_knobs().wgrad_ld != 0;
 #ifdef TIMHIP_TUNING
   if (const char* v = getenv("TIMHIP_WGPP_ABL")) {
     const int abl = atoi(v);

@@ -261,8 +261,8 @@ class Runtime:
             return None
         gs = torch.zeros(8, dtype=torch.float32, device=dev)   # {S, 1/S, scratch, scratch, non-finite flag, 0, 0, 0}
         self._gs_blocks.append(gs)
-        if len(self._gs_blocks) > 16:    # (many backward passes without a reader: fold on the device, no sync)
-            self._fold_flags()
+        if len(self._gs_blocks) > 16 and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self._fold_flags()               # (many backward passes without a reader: fold on the device, no sync)
         cots = [c for c in cotangents if c is not None and c.numel() > 0]
         if not cots:
             gs[:2] = 1.0
@@ -864,7 +864,9 @@ class EncoderFn(torch.autograd.Function):
         dx2 = torch.empty_like(dx)
         # between layers the gradient travels split: fp32 part (what LayerNorm-backward wrote) + operand-dtype part (the
         # in-projection's input-gradient product, added by the next LayerNorm-backward as it reads): timhip_layer_bwd_split
-        dxa = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(2)] if Lyr > 1 else [None, None]
+        # (plain bf16 would round that part to 8 bits per layer: there the layer returns one complete fp32 gradient instead)
+        split_stream = Lyr > 1 and rt.prec != L.PREC_BF16
+        dxa = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(2)] if split_stream else [None, None]
         add_in = None     # 16-bit part of the gradient entering the current layer (None at the top of the stack)
         stack = model._stack_prefix
         main = torch.cuda.current_stream()

@@ -30,7 +30,7 @@ for name, N, K, epi in shapes:
             [("dg%d" % o, {"TIMHIP_GEMM_DG": "1", "TIMHIP_GEMM_DG_OFFSET": str(o), "TIMHIP_GEMM_PT": "0"}) for o in offsets]:
         best = 1e9
         for rep in range(3):
-            os.environ.update(env)
+            os.environ.update(env); L.reload_env()
             for _ in range(3): run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

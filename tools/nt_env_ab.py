@@ -35,7 +35,7 @@ for name, N, K, epi in shapes:
     best = {}
     for rep in range(4):
         for vname, env in variants:
-            os.environ.update(env)
+            os.environ.update(env); L.reload_env()
             for _ in range(3): run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -17,7 +17,7 @@ for (M, N, K) in ((9920, 1024, 3072), (9920, 3072, 1024), (9920, 1024, 1024), (9
         line = "M%d N%d K%d %s:" % (M, N, K, epi)
         for rep in range(3):
             for ld in ("0", "1"):
-                os.environ["TIMHIP_GEMM_LD"] = ld
+                os.environ["TIMHIP_GEMM_LD"] = ld; L.reload_env()
                 for _ in range(3): run(epi)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
