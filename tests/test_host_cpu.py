@@ -188,3 +188,30 @@ def test_build_model_takes_the_reference_parsers_namespaces():
     assert type(m) is DetTIM and hasattr(m, "reg_head")
     rec.variant = "recognition"      # an explicit attribute still wins
     assert type(build_model(rec)[0]) is RecTIM
+
+
+def test_layer_split_mode_is_validated(monkeypatch):
+    """Runtime.layer_split (opt-in fp16 margin mode): unknown names and unknown TIM_AMD_SPLIT_LAYER_WEIGHTS values raise, widths
+    the wrapped-operand product cannot take (E or FF not a multiple of 64) fall back to plain weights with a warning, and
+    `split_outproj` follows an assignment made after construction."""
+    import warnings
+    from tim_amd.functional import Runtime
+    rt = Runtime("fp16")
+    assert rt.layer_split == () and not rt.split_outproj
+    rt.layer_split = ("out",)
+    assert rt.split_outproj and rt.layer_split_for(1024, 2048) == ("out",)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert rt.layer_split_for(96, 192) == () and rt.layer_split_flags(96, 192) == 0
+        assert rt.layer_split_for(160, 320) == ()
+    assert len(w) == 1 and "plain" in str(w[0].message)          # warned once
+    with pytest.raises(ValueError):
+        rt.layer_split = ("out", "ffn")
+    with pytest.raises(ValueError):
+        Runtime("bf16").layer_split = ("out",)
+    monkeypatch.setenv("TIM_AMD_SPLIT_LAYER_WEIGHTS", "everything")
+    with pytest.raises(ValueError):
+        Runtime("fp16")
+    monkeypatch.setenv("TIM_AMD_SPLIT_LAYER_WEIGHTS", "all")
+    assert Runtime("fp16").layer_split == ("in", "out", "l1", "l2")
+    assert Runtime("bf16").layer_split == ()                     # (the switch is an fp16-mode option)

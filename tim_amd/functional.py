@@ -73,8 +73,12 @@ class Runtime:
         # (DESIGN.md section 6): none 8.1e-4 max logit error; "out" (the out-projection: largest single term, smallest GEMM)
         # 7.2e-4 at +2 % of the step; "all" 5.3e-4 at +15 %.
         sel = os.environ.get("TIM_AMD_SPLIT_LAYER_WEIGHTS", "none") if self.split else "none"
-        self.layer_split = {"none": (), "out": ("out",), "all": ("in", "out", "l1", "l2")}.get(sel, ())
-        self.split_outproj = "out" in self.layer_split
+        modes = {"none": (), "out": ("out",), "all": ("in", "out", "l1", "l2")}
+        if sel not in modes:
+            raise ValueError("TIM_AMD_SPLIT_LAYER_WEIGHTS=%r: expected one of %s" % (sel, sorted(modes)))
+        self._layer_split = ()
+        self._split_warned = False
+        self.layer_split = modes[sel]
         self._wsplit = {}
         self._wsparams = {}  # id(param) -> weakref: every weight this runtime has split
         # fp16 backward: gradient operands are stored times a power of two chosen per backward pass from the incoming
@@ -175,9 +179,41 @@ class Runtime:
             call("timhip_cast_weights", self.prec, C.cast(arr, C.c_void_p), len(items), _stream())
             self._wcache.update(fresh)
 
-    def layer_split_flags(self):
+    # ---- opt-in weight-split mode of the encoder layers' forward GEMMs -----------------------------------------
+    @property
+    def layer_split(self):
+        return self._layer_split
+
+    @layer_split.setter
+    def layer_split(self, keys):
+        keys = tuple(keys)
+        bad = [k for k in keys if k not in ("in", "out", "l1", "l2")]
+        if bad:
+            raise ValueError("layer_split: unknown Linear %r (expected a subset of in / out / l1 / l2)" % (bad,))
+        if keys and not self.split:
+            raise ValueError("layer_split is a margin mode of precision='fp16' only")
+        self._layer_split = keys
+
+    @property
+    def split_outproj(self):          # (derived: never stale when layer_split is assigned after construction)
+        return "out" in self._layer_split
+
+    def layer_split_for(self, E, FF):
+        """the split set this model can run: the wrapped-operand product (TimEpi.a_wrap_k) needs contraction lengths that are
+        multiples of 64, i.e. E % 64 == 0 and FF % 64 == 0 (the model itself only asks for d_model % 32 == 0); otherwise plain
+        weights, with one warning - not a TIMHIP_EUNSUPPORTED at the first layer"""
+        if self._layer_split and (E % 64 or FF % 64):
+            if not self._split_warned:
+                import warnings
+                warnings.warn("tim_amd: layer_split %r needs E %% 64 == 0 and FF %% 64 == 0 (E = %d, FF = %d): running with plain "
+                              "16-bit layer weights" % (self._layer_split, E, FF))
+                self._split_warned = True
+            return ()
+        return self._layer_split
+
+    def layer_split_flags(self, E, FF):
         f = {"in": L.DESC_INPROJ_SPLIT, "out": L.DESC_OUTPROJ_SPLIT, "l1": L.DESC_L1_SPLIT, "l2": L.DESC_L2_SPLIT}
-        return sum(f[k] for k in self.layer_split)
+        return sum(f[k] for k in self.layer_split_for(E, FF))
 
     def weight_split(self, p, mode=1):
         """split copy of an fp32 weight [N, K] as [N, 3 ru(K)] 16-bit column blocks: mode 1 = [hi | hi | lo] (the weight side
@@ -655,7 +691,7 @@ class EncoderFn(torch.autograd.Function):
              ptr(te_c), T, ptr(mod), p_seq, seed, L.SITE_SEQ, ptr(xs_f[0]), ptr(xs_t[0]), st)
 
         # ---- L post-norm encoder layers (transformers.py:44-45,92-111)
-        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, rt.layer_split_flags(), None)
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, rt.layer_split_flags(E, FF), None)
         saved_bytes = L.load().timhip_layer_saved_bytes(C.byref(desc))
         ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
         ws = model._workspace(ws_bytes, dev)

@@ -353,8 +353,10 @@ class TIM(nn.Module):
     @staticmethod
     def _layer_params(rt, P, pre):
         from .functional import _f32c
+        lsplit = rt.layer_split_for(P[pre + "linear1.weight"].shape[1], P[pre + "linear1.weight"].shape[0])
+
         def fwd_w(key, name):   # the forward operand of a Linear: plain 16-bit copy, or its split copy (Runtime.layer_split)
-            return rt.weight_split(P[pre + name], mode=0) if key in rt.layer_split else rt.weight(P[pre + name])
+            return rt.weight_split(P[pre + name], mode=0) if key in lsplit else rt.weight(P[pre + name])
         keep = [fwd_w("in", "self_attn.in_proj_weight"), rt.weight(P[pre + "self_attn.in_proj_weight"], True),
                 fwd_w("out", "self_attn.out_proj.weight"), rt.weight(P[pre + "self_attn.out_proj.weight"], True),
                 fwd_w("l1", "linear1.weight"), rt.weight(P[pre + "linear1.weight"], True),
