@@ -142,8 +142,10 @@ def test_backward_of_a_stale_forward_is_refused(salt_off):
 def test_c2a_production_batch_replay_is_the_eager_step_fp16(salt_off):
     """WHERE THE `graph_replay` NUMBERS OF THE BENCH LINE ARE QUOTED: C2a, B = 64 windows, fp16, .train() with the reference's
     dropout rates - the production kernels (loader-wave / tile-walk NT GEMMs, grouped weight gradients, chained layers, fused
-    attention backward).  A replay and an eager step under the same dropout salt: identical logits, every gradient equal up
-    to the order of a few fp32 atomics."""
+    attention backward).  A replay and an eager step under the same dropout salt: the same masks at every site, logits and
+    every gradient equal up to the order of fp32 atomic adds (at these shapes the heads' split products and the bias /
+    LayerNorm column sums accumulate with atomics, so two EAGER runs are not bit-identical either: 1e-5 relative; a single
+    differing keep-bit would move logits by 1e-2)."""
     from tests.test_gpu_parity import build
     from tim_amd.config import named_config
     cfg = named_config("C2a")
@@ -159,14 +161,14 @@ def test_c2a_production_batch_replay_is_the_eager_step_fp16(salt_off):
     rep = _snap(model, gs())
     word.fill_(_i64(5 * K2 - F._SALT_STEP))
     eager = _snap(model, fn())
-    _same(rep, eager, 0)
+    _same(rep, eager, 1e-5)
     assert len(rep[1]) == len(list(model.parameters())) - sum(1 for n, _ in model.named_parameters() if n.startswith("drloc_mlp"))
     assert model.rt.grads_finite()
     # the next replay draws other masks (the salt advanced on the device) and is again reproducible eagerly
     rep2 = _snap(model, gs())
     assert not torch.equal(rep2[0][0], rep[0][0])
     word.fill_(_i64(5 * K2))                     # (where the word stood before that replay's own increment)
-    _same(rep2, _snap(model, fn()), 0)
+    _same(rep2, _snap(model, fn()), 1e-5)
 
 
 def test_detection_training_step_replay_is_the_eager_step(salt_off, monkeypatch):
@@ -231,8 +233,8 @@ def test_detection_training_step_replay_is_the_eager_step(salt_off, monkeypatch)
         for a, b in zip(eg["labels"][0], rep["lab"]):
             assert torch.equal(a, b)
         for a, b in zip([t for t in eg["output"][0] if t is not None], rep["cls"]):
-            assert torch.equal(a.detach(), b)
-        assert torch.equal(eg["output"][1][0].detach(), rep["reg"])
+            assert torch.allclose(a.detach(), b, rtol=1e-5, atol=1e-5)      # (fp32 atomics reorder between any two runs)
+        assert torch.allclose(eg["output"][1][0].detach(), rep["reg"], rtol=1e-5, atol=1e-6)
         assert abs(eg["loss"].item() - rep["loss"].item()) <= 1e-5 * max(1.0, abs(rep["loss"].item()))
         assert abs(norm.item() - norm_after.item()) <= 1e-4
         for n, p in model.named_parameters():

@@ -379,6 +379,15 @@ def test_attention_structured(prec, B, S, F, H, Dh):
     _attn_case(prec, B, S, F, H, Dh)
 
 
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("B,S,F,H,Dh,p", [(2, 499, 100, 8, 128, 0.1), (1, 499, 100, 2, 128, 0.0), (3, 260, 50, 2, 64, 0.1)])
+def test_attention_long_sequence_row_split(prec, B, S, F, H, Dh, p):
+    """detection's sequence (S = 499: 100 feature tokens + 399 queries, 16 row blocks) with few (window, head) pairs: the row
+    blocks of a pair are spread over several workgroups (attention_mfma.hip: attn_row_split) in the forward and in the row kernel
+    of the backward - 4 parts of 4 row blocks at S = 499, ragged last part at S = 260 (9 row blocks); with attention dropout"""
+    _attn_case(prec, B, S, F, H, Dh, p=p)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_attention_dropout(prec):
     _attn_case(prec, 2, 40, 24, 2, 64, p=0.25)

@@ -20,6 +20,7 @@ struct AttnArgsM {
   float scale;
   uint32_t thr; float dscale; TimSeed seed; uint32_t site;
   int abl;  // tuning builds only (TimDesc.reserved >> 8): 1 no scratch stores, 2 no dqkv stores, 4 operand rows alias row 0
+  int rsplit, rper;   // two-kernel form: the row blocks of a (window, head) over rsplit workgroups of rper row blocks (attention_mfma.hip)
 };
 #ifdef TIMHIP_TUNING
 #define ATT_ABL(a, bit) (((a).abl & (bit)) != 0)
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
   char* sV = sK + FP * DH * 2;
   char* sS = sV + FP * DH * 2;                          // FUSED: dS  [SP][FP]
   char* sP = sS + ((a.S + 31) & ~31) * FP * 2;          // FUSED: P~  [SP][FP]
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int rsplit = FUSED ? 1 : a.rsplit;
+  const int bh = blockIdx.x / rsplit, part = blockIdx.x - bh * rsplit;
+  const int b = bh / a.H, h = bh % a.H;
   const int S = a.S, F = a.F, E = a.E;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,18 +83,18 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
   const HT* dobase = d_o + (size_t)b * S * E + (size_t)h * DH;
   const HT* obase = o + (size_t)b * S * E + (size_t)h * DH;
   const float* lsebase = lse + ((size_t)b * a.H + h) * S;
-  HT* dSs = dS_scr + (size_t)blockIdx.x * S * FP;
-  HT* Pts = Pt_scr + (size_t)blockIdx.x * S * FP;
+  HT* dSs = dS_scr + (size_t)bh * S * FP;
+  HT* Pts = Pt_scr + (size_t)bh * S * FP;
   stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
   stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
 
   const int li = lane & 31, g = lane >> 5;
-  const int nrb = (S + 31) >> 5;
+  const int nrb = FUSED ? ((S + 31) >> 5) : min((S + 31) >> 5, (part + 1) * a.rper);
 
   // ---------------- phase 1 ----------------
   const int nwaves = blockDim.x >> 6;
-  for (int rb = wave; rb < nrb; rb += nwaves) {
+  for (int rb = (FUSED ? 0 : part * a.rper) + wave; rb < nrb; rb += nwaves) {
     const int row = rb * 32 + li;
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
@@ -455,6 +458,7 @@ AttnArgsM make_args2(const TimDesc& d) {
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
   a.abl = d.reserved >> 8;
+  a.rsplit = 1; a.rper = (d.S + 31) / 32;
   return a;
 }
 
@@ -491,8 +495,20 @@ int launch_bwd2(const TimDesc& d, const void* qkv, const void* o, const float* l
   HT* Pt = dS + (size_t)d.B * d.H * d.S * FP;
   const size_t lds1 = (size_t)2 * FP * DH * 2;
   (void)hipFuncSetAttribute((const void*)attn_bwd_rows<HT, DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-  hipLaunchKernelGGL((attn_bwd_rows<HT, DH, NJB>), dim3(d.B * d.H), dim3(64 * rows_waves(d.S)), lds1, s, (const HT*)qkv,
-                     (const HT*)o, lse, (const HT*)d_o, (HT*)dqkv, dS, Pt, make_args2(d));
+  // long sequences with few (window, head) pairs (detection: B * H = 128, 16 row blocks): the row blocks of a pair over several
+  // workgroups of four waves, two workgroups per CU (the kernel takes 256 VGPRs: eight wave slots per CU)
+  AttnArgsM a = make_args2(d);
+  {
+    const int nrb = (d.S + 31) / 32, bh = d.B * d.H;
+    int want = bh >= 512 ? 1 : (512 + bh - 1) / bh;
+    if (want > nrb / 4) want = nrb / 4;
+    if (want < 1) want = 1;
+    a.rper = (nrb + want - 1) / want;
+    a.rsplit = (nrb + a.rper - 1) / a.rper;
+  }
+  const int waves = a.rsplit > 1 ? rows_waves(32 * (a.rper < 4 ? a.rper : 4)) : rows_waves(d.S);
+  hipLaunchKernelGGL((attn_bwd_rows<HT, DH, NJB>), dim3(d.B * d.H * a.rsplit), dim3(64 * waves), lds1, s, (const HT*)qkv,
+                     (const HT*)o, lse, (const HT*)d_o, (HT*)dqkv, dS, Pt, a);
   if (hipGetLastError() != hipSuccess) return TIMHIP_ELAUNCH;
   const size_t lds2 = 2 * 2 * 64 * 128 * 2;
   hipLaunchKernelGGL(attn_bwd_keys<HT>, dim3((d.F + 127) / 128, 2, d.B * d.H), dim3(256), lds2, s, dS, Pt, (const HT*)qkv,

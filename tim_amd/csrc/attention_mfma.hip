@@ -26,6 +26,7 @@ struct AttnArgsM {
   int S, F, E, H, LP;
   float scale;
   uint32_t thr; float dscale; TimSeed seed; uint32_t site;
+  int rsplit, rper;   // the 32-row blocks of a (window, head) are spread over rsplit workgroups of rper row blocks each (1: one workgroup)
 };
 
 __device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + FP * DH * 2;
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  // (window, head) = blockIdx.x / rsplit; a long sequence (detection: S = 499, B * H = 128) spreads its row blocks over rsplit
+  // workgroups that each stage the K / V tile themselves (51 KB from L2) - 128 workgroups would leave half of the 256 CUs idle
+  const int bh = blockIdx.x / a.rsplit, part = blockIdx.x - bh * a.rsplit;
+  const int b = bh / a.H, h = bh % a.H;
   const int S = a.S, F = a.F, E = a.E;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,9 +88,9 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
   __syncthreads();
 
   const int li = lane & 31, g = lane >> 5;
-  const int nrb = (S + 31) >> 5;
+  const int nrb = min((S + 31) >> 5, (part + 1) * a.rper);
   const int nwaves = blockDim.x >> 6;
-  for (int rb = wave; rb < nrb; rb += nwaves) {
+  for (int rb = part * a.rper + wave; rb < nrb; rb += nwaves) {
     const int row = rb * 32 + li;
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
@@ -463,7 +467,20 @@ AttnArgsM make_args(const TimDesc& d) {
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
+  a.rsplit = 1; a.rper = (d.S + 31) / 32;
   return a;
+}
+
+// Row split of a (window, head): enough workgroups for two per CU (512) when B * H alone does not provide them, each with at
+// least `waves_min` row blocks (one per wave).  C4 training (B = 16, H = 8, S = 499: 16 row blocks): 4 parts of 4 row blocks.
+static inline void attn_row_split(const TimDesc& d, int waves_min, int& rsplit, int& rper) {
+  const int nrb = (d.S + 31) / 32, bh = d.B * d.H;
+  int want = bh >= 512 ? 1 : (512 + bh - 1) / bh;
+  const int most = nrb / (waves_min < 1 ? 1 : waves_min);
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  rper = (nrb + want - 1) / want;
+  rsplit = (nrb + rper - 1) / rper;
 }
 
 // one wave per 32-row block of queries, at most 8 waves (2 per SIMD keeps the 256-VGPR budget)
@@ -483,8 +500,10 @@ template <typename HT, int DH, int NJB>
 int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
   const size_t lds = (size_t)2 * NJB * 32 * DH * 2;
   (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HT, DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_mfma<HT, DH, NJB>), dim3(d.B * d.H), dim3(64 * attn_waves(d.S)), lds, s, (const HT*)qkv, (HT*)o, lse,
-                     make_args(d));
+  AttnArgsM a = make_args(d);
+  attn_row_split(d, 4, a.rsplit, a.rper);
+  hipLaunchKernelGGL((attn_fwd_mfma<HT, DH, NJB>), dim3(d.B * d.H * a.rsplit), dim3(64 * attn_waves(32 * a.rper)), lds, s,
+                     (const HT*)qkv, (HT*)o, lse, a);
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 template <typename HT, int DH, int NJB>

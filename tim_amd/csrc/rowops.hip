@@ -676,47 +676,60 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __re
                                                            const float* __restrict__ dx, int n_e_rows, uint32_t thr,
                                                            float scale, TimSeed seed, uint32_t site,
                                                            float* __restrict__ d_e0, float* __restrict__ d_e1,
-                                                           float* __restrict__ d_cls, float* __restrict__ d_mod) {
+                                                           float* __restrict__ d_cls, float* __restrict__ d_mod, int G) {
+  // A block walks G consecutive token rows and carries the modality / cls sums across rows that add into the same vector
+  // (detection: 399 query rows share one cls vector and one modality vector - one atomic per row and column took 75 us at
+  // S = 499, the adds being resolved one at a time at the memory side); the atomics go out when the target changes.
   __shared__ float4 red[4][64];
-  const int s = blockIdx.x;
-  const TimSeqRow r = rows[s];
   const int E = 2 * d;
   const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int s_lo = blockIdx.x * G, s_hi = min(S, s_lo + G);
   for (int c0 = blockIdx.y * 256; c0 < E; c0 += gridDim.y * 256) {
     const int c = c0 + q * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < E) {
+    float4 msum = make_float4(0.f, 0.f, 0.f, 0.f), csum = msum;
+    int mtgt = -1, ctgt = -1;
+    auto flush = [&](float* base, int tgt, int width, float4& v) {
+      if (tgt >= 0 && base) {
+        float* p = base + (size_t)tgt * width + c;
+        atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+      }
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    for (int s = s_lo; s < s_hi; ++s) {
+      const TimSeqRow r = rows[s];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < E) {
 #pragma unroll 4
-      for (int b = rl; b < B; b += 4) {
-        const size_t bs = (size_t)b * S + s;
-        float4 g = *reinterpret_cast<const float4*>(dx + bs * E + c);
-        if (thr != 0u) {
-          float k0, k1, k2, k3;
-          drop_mask4(seed, site, (bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
-          g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+        for (int b = rl; b < B; b += 4) {
+          const size_t bs = (size_t)b * S + s;
+          float4 g = *reinterpret_cast<const float4*>(dx + bs * E + c);
+          if (thr != 0u) {
+            float k0, k1, k2, k3;
+            drop_mask4(seed, site, (bs * E + c) >> 2, thr, scale, k0, k1, k2, k3);
+            g.x *= k0; g.y *= k1; g.z *= k2; g.w *= k3;
+          }
+          acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+          if (c < d && r.kind != 1) {
+            float* d_e = r.kind == 0 ? d_e0 : d_e1;
+            if (d_e) store4<float>(d_e + ((size_t)b * n_e_rows + r.src) * d + c, g.x, g.y, g.z, g.w);
+          }
         }
-        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-        if (c < d && r.kind != 1) {
-          float* d_e = r.kind == 0 ? d_e0 : d_e1;
-          if (d_e) store4<float>(d_e + ((size_t)b * n_e_rows + r.src) * d + c, g.x, g.y, g.z, g.w);
-        }
       }
+      red[rl][q] = acc;
+      __syncthreads();
+      if (rl == 0 && c < E) {
+        const float4 a1 = red[1][q], a2 = red[2][q], a3 = red[3][q];
+        acc.x += a1.x + a2.x + a3.x; acc.y += a1.y + a2.y + a3.y; acc.z += a1.z + a2.z + a3.z; acc.w += a1.w + a2.w + a3.w;
+        const int mt = (r.mod >= 0 && d_mod) ? r.mod : -1;
+        if (mt != mtgt) { flush(d_mod, mtgt, E, msum); mtgt = mt; }
+        if (mt >= 0) { msum.x += acc.x; msum.y += acc.y; msum.z += acc.z; msum.w += acc.w; }
+        const int ct = (c < d && r.kind == 1 && d_cls) ? r.src : -1;
+        if (ct != ctgt) { flush(d_cls, ctgt, d, csum); ctgt = ct; }
+        if (ct >= 0) { csum.x += acc.x; csum.y += acc.y; csum.z += acc.z; csum.w += acc.w; }
+      }
+      __syncthreads();
     }
-    red[rl][q] = acc;
-    __syncthreads();
-    if (rl == 0 && c < E) {
-      const float4 a1 = red[1][q], a2 = red[2][q], a3 = red[3][q];
-      acc.x += a1.x + a2.x + a3.x; acc.y += a1.y + a2.y + a3.y; acc.z += a1.z + a2.z + a3.z; acc.w += a1.w + a2.w + a3.w;
-      if (r.mod >= 0 && d_mod) {
-        float* p = d_mod + (size_t)r.mod * E + c;
-        atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
-      }
-      if (c < d && r.kind == 1 && d_cls) {
-        float* p = d_cls + (size_t)r.src * d + c;
-        atomicAdd(p, acc.x); atomicAdd(p + 1, acc.y); atomicAdd(p + 2, acc.z); atomicAdd(p + 3, acc.w);
-      }
-    }
-    __syncthreads();
+    if (rl == 0 && c < E) { flush(d_mod, mtgt, E, msum); flush(d_cls, ctgt, d, csum); }
   }
 }
 
@@ -1255,8 +1268,9 @@ int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float*
   if (!rows || !dx || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
   const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
   const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
-  hipLaunchKernelGGL(assemble_bwd_kernel, dim3(S, (2 * d + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx, n_e_rows, thr,
-                     scale, seed, site, d_e0, d_e1, d_cls, d_mod);
+  const int G = S >= 256 ? (S + 127) / 128 : 1;   // token rows per block: about 128 row groups, one atomic per group, vector and column
+  hipLaunchKernelGGL(assemble_bwd_kernel, dim3((S + G - 1) / G, (2 * d + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx,
+                     n_e_rows, thr, scale, seed, site, d_e0, d_e1, d_cls, d_mod, G);
   TIM_CHECK_LAUNCH();
   if (d_te) {
     hipLaunchKernelGGL(assemble_bwd_te_kernel, dim3(T_, B >= 32 ? 16 : (B >= 8 ? 4 : 1)), dim3(128), 0, (hipStream_t)stream, rows, B, S, d, dx, T_,
