@@ -85,8 +85,8 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
   const float* lsebase = lse + ((size_t)b * a.H + h) * S;
   HT* dSs = dS_scr + (size_t)bh * S * FP;
   HT* Pts = Pt_scr + (size_t)bh * S * FP;
-  stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
-  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
+  // (K and V staged as a pair: every load of both tiles ahead of the first LDS write - one memory latency, not two)
+  stage_tile_pair<DH>(sK, base + E, sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
   __syncthreads();
 
   const int li = lane & 31, g = lane >> 5;
@@ -216,8 +216,12 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
           if (st) {
             if (isq) {
               const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(qp + E + dh);
-              const vec8<HT> qf8 = *reinterpret_cast<const vec8<HT>*>(qp + dh);
-              const vec8<HT> d8 = *reinterpret_cast<const vec8<HT>*>(dop + dh);
+              // fp16: the q / dO chunks are the fragments the products above used (columns 16 kk + 8 g = dh) - no second read;
+              // bf16: read again (kept live as operands AND as values to convert, the fragments cost this kernel 200 spilled
+              // registers with this compiler)
+              constexpr bool REUSE = sizeof(HT) == 2 && __is_same(HT, f16_t);
+              const vec8<HT> qf8 = REUSE ? qf[2 * db + p2] : *reinterpret_cast<const vec8<HT>*>(qp + dh);
+              const vec8<HT> d8 = REUSE ? df[2 * db + p2] : *reinterpret_cast<const vec8<HT>*>(dop + dh);
               float kself[8], vself[8];
 #pragma unroll
               for (int u = 0; u < 8; ++u) {

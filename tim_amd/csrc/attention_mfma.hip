@@ -83,24 +83,34 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t ld = (size_t)3 * E;
   const HT* base = qkv + (size_t)b * S * ld + (size_t)h * DH;
-  stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
-  stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
-  __syncthreads();
-
   const int li = lane & 31, g = lane >> 5;
   const int nrb = min((S + 31) >> 5, (part + 1) * a.rper);
   const int nwaves = blockDim.x >> 6;
-  for (int rb = part * a.rper + wave; rb < nrb; rb += nwaves) {
+  // (five key blocks - F > 128 - hold 80 score registers per lane: no room for operands in flight, the requests stay where
+  //  they are consumed)
+  constexpr bool PRE = NJB <= 4;
+  // Operand prefetch (round 4).  The block used to run a chain of dependent memory latencies - K tile, V tile, then per row
+  // block its q / self-k rows, its self-v rows at the store - with two workgroups per CU to hide them: 31.5 us for 82 MB.  Now
+  // every load is issued as early as its registers allow: the first row block's q / self-k rows BEFORE the K / V staging
+  // loads (one latency for all three), K and V staged as a pair, the self-v rows and the NEXT row block's q / self-k rows
+  // right after the S^T products (under the softmax and the P V products).
+  auto load_rows = [&](int rbx, vec8<HT> (&qf)[NKK], vec8<HT> (&kself)[NKK]) {
+    const int rowx = min(rbx * 32 + li, S - 1);
+    const HT* qx = base + (size_t)rowx * ld;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const vec8<HT>*>(qx + kk * 16 + g * 8);
+    if (!PRE || rowx >= F) {   // (feature tokens have no self term; without operand prefetch the plain unconditional form)
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) kself[kk] = *reinterpret_cast<const vec8<HT>*>(qx + E + kk * 16 + g * 8);
+    }
+  };
+  // one 32-row block of queries; qf / kself: its q rows and (query tokens) own-key rows, already requested
+  auto row_block = [&](int rb, vec8<HT> (&qf)[NKK], vec8<HT> (&kself)[NKK]) {
     const int row = rb * 32 + li;
     const bool valid = row < S;
     const int rowc = valid ? row : S - 1;
     const bool isq = rowc >= F;
     const HT* qp = base + (size_t)rowc * ld;
-    vec8<HT> qf[NKK], kself[NKK];
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const vec8<HT>*>(qp + kk * 16 + g * 8);
-#pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) kself[kk] = *reinterpret_cast<const vec8<HT>*>(qp + E + kk * 16 + g * 8);
 
     // S^T = K Q^T : lane owns query row `row`, registers hold keys 32jb + (r&3) + 8(r>>2) + 4g
     f32x16_t sc[NJB];
@@ -182,6 +192,12 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
       pf[jb][0] = pack8<HT>(sc[jb], 0);
       pf[jb][1] = pack8<HT>(sc[jb], 1);
     }
+    // the self-v rows of this block (used at the store) go out now - the score registers are free - under the P V products
+    vec8<HT> vself[NKK];
+    if (PRE && isq) {
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) vself[kk] = *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + kk * 16 + g * 8);
+    }
     constexpr int NH = NDB >= 2 ? 2 : 1, DBH = NDB / NH;
     HT* op = o + ((size_t)b * S + rowc) * E + (size_t)h * DH;
 #pragma unroll
@@ -213,7 +229,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
           const int dh = 32 * (hh * DBH + d2) + 16 * p2 + 8 * g;
           if (valid) {
             if (isq) {
-              const vec8<HT> sv = *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + dh);
+              // columns dh .. dh + 7 = 16 (dh / 16) + 8 g: the chunk requested above (PRE), or read here
+              const vec8<HT> sv = PRE ? vself[2 * (hh * DBH + d2) + p2] : *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + dh);
 #pragma unroll
               for (int u = 0; u < 8; ++u) v[u] = fmaf(pself, (float)sv[u], v[u]);
             }
@@ -221,6 +238,39 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
           }
         }
     }
+  };
+
+  // The wave's first row block is peeled out of the loop: its operands were requested before the K / V staging, and keeping
+  // them in registers of their own (not loop-carried) is what lets the compiler fit the kernel without spills.
+  int rb = part * a.rper + wave;
+  if constexpr (!PRE) {   // the plain loop: operands requested where they are consumed
+    stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
+    stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
+    __syncthreads();
+    for (; rb < nrb; rb += nwaves) {
+      vec8<HT> q1[NKK], k1[NKK];
+      load_rows(rb, q1, k1);
+      row_block(rb, q1, k1);
+    }
+    return;
+  }
+  {
+    vec8<HT> q0[NKK], k0[NKK];
+    if (PRE && rb < nrb) load_rows(rb, q0, k0);
+    if constexpr (PRE) {
+      stage_tile_pair<DH>(sK, base + E, sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
+    } else {
+      stage_tile<DH>(sK, base + E, ld, FP, F, tid, blockDim.x);
+      stage_tile<DH>(sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
+    }
+    __syncthreads();
+    if (!PRE && rb < nrb) load_rows(rb, q0, k0);
+    if (rb < nrb) row_block(rb, q0, k0);
+  }
+  for (rb += nwaves; rb < nrb; rb += nwaves) {
+    vec8<HT> q1[NKK], k1[NKK];
+    load_rows(rb, q1, k1);
+    row_block(rb, q1, k1);
   }
 }
 

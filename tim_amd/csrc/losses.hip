@@ -230,6 +230,12 @@ __global__ void diou_kernel(const float* __restrict__ pred, const float* __restr
 
 }  // namespace
 
+namespace {
+// (a kernel, not hipMemsetAsync: a 4-byte memset node inside a captured HIP graph left the word unset on replay - the
+//  detection training step's replayed loss read 1e32 while its logits and labels were right; tests/test_gpu_graph.py)
+__global__ void zero_word_kernel(float* p) { *p = 0.f; }
+}  // namespace
+
 extern "C" {
 
 int timhip_focal_loss_fwd(const float* logits, const float* targets, int rows, int C, const float* row_weights,
@@ -237,7 +243,7 @@ int timhip_focal_loss_fwd(const float* logits, const float* targets, int rows, i
                           void* stream) {
   if (!logits || !targets || !loss_sum || rows < 0 || C <= 0) return TIMHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return TIMHIP_ELAUNCH;
+  hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, s, loss_sum);
   if (rows == 0) return TIMHIP_OK;
   const long long n = (long long)rows * C;
   const int blocks = (int)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256);   // one atomic per block on a single address
@@ -264,7 +270,7 @@ int timhip_diou_1d(const float* pred_offsets, const float* target_offsets, int n
                    const float* grad_out, float* loss_sum, float* dpred, void* stream) {
   if (!pred_offsets || !target_offsets || n < 0 || (!loss_sum && !dpred)) return TIMHIP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (loss_sum && hipMemsetAsync(loss_sum, 0, sizeof(float), s) != hipSuccess) return TIMHIP_ELAUNCH;
+  if (loss_sum) hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, s, loss_sum);
   if (n == 0) return TIMHIP_OK;
   hipLaunchKernelGGL(diou_kernel, dim3((n + 255) / 256 > 256 ? 256 : (n + 255) / 256), dim3(256), 0, s, pred_offsets,
                      target_offsets, n, row_valid, eps, grad_out, loss_sum, dpred);

@@ -76,6 +76,50 @@ __device__ __forceinline__ void stage_tile(char* tile, const HT* src, size_t ld,
   }
 }
 
+// Two tiles (K and V of one head) staged together: every global load of BOTH tiles is issued before the first LDS write, so
+// the block pays one memory latency for the pair instead of one per tile (the attention kernels are latency-bound at two
+// workgroups per CU: every load issued earlier is time off the block's critical path).
+template <int DH, typename HT>
+__device__ __forceinline__ void stage_tile_pair(char* tile0, const HT* src0, char* tile1, const HT* src1, size_t ld, int nrows,
+                                                int nvalid, int tid, int nthreads) {
+  constexpr int NC = DH / 8, UN = 8;
+  for (int i0 = tid; i0 < nrows * NC; i0 += nthreads * UN) {
+    vec8<HT> v0[UN], v1[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = i0 + u * nthreads;
+      const int row = idx / NC, c = idx % NC;
+      if (idx < nrows * NC && row < nvalid) {
+        v0[u] = *reinterpret_cast<const vec8<HT>*>(src0 + (size_t)row * ld + c * 8);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v0[u][e] = (HT)0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = i0 + u * nthreads;
+      const int row = idx / NC, c = idx % NC;
+      if (idx < nrows * NC && row < nvalid) {
+        v1[u] = *reinterpret_cast<const vec8<HT>*>(src1 + (size_t)row * ld + c * 8);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v1[u][e] = (HT)0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = i0 + u * nthreads;
+      if (idx < nrows * NC) *reinterpret_cast<vec8<HT>*>(tile0 + tile_off<DH>(idx / NC, idx % NC)) = v0[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int idx = i0 + u * nthreads;
+      if (idx < nrows * NC) *reinterpret_cast<vec8<HT>*>(tile1 + tile_off<DH>(idx / NC, idx % NC)) = v1[u];
+    }
+  }
+}
+
 // V^T / K^T fragment for the PV-style MFMA: lane (i = lane & 31 -> dh 32*db + i, g = lane >> 5)
 // gets the 8 values tile[key(u)][dh], key(u) = kb + 8*(u>>2) + 4*g + (u&3)   (kb = 32*jb + 16*a)
 template <int DH, typename HT>
