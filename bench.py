@@ -638,20 +638,23 @@ def main():
         traffic = None  # HBM-side bytes per launch of the GEMM kernels, from the committed rocprofv3 PMC passes
         tnote = "no PMC summary committed for this configuration"
         try:
-            tfile = [f for f in ("r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            tfile = [f for f in ("r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
             if args.precision in ("bf16", "fp16") and args.workload == "C2a" and B == 64:
                 ntk, tnk = tj.get("gemm_nt_ld_kernel", tj.get("gemm_nt_pp_kernel")), tj.get("wgrad_ld_kernel", tj.get("wgrad_pp_kernel"))   # 8 NT + 1 grouped TN launch per layer
                 if "gemm_nt_ldp_kernel" in tj:   # three of a layer's eight NT launches (in-proj forward, linear1, linear2 dgrad) walk their tiles
                     ntk = dict(ntk, bytes_per_launch=(5 * ntk["bytes_per_launch"] + 3 * tj["gemm_nt_ldp_kernel"]["bytes_per_launch"]) / 8.0)
                 traffic = round((8 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 9.0)
-                tnote = ("average HBM-side bytes per GEMM launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
-                         "profiles/%s, tools/pmc_traffic.py): NT %.0f MB, grouped TN %.0f MB per launch"
+                tnote = ("CITED, not measured in this run: average fabric-side bytes per GEMM launch from the committed rocprofv3 PMC "
+                         "passes of this command on the builder's box (FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
+                         "profiles/%s, tools/pmc_traffic.py; the x2 and the write counter calibrated on known byte counts, "
+                         "profiles/r04_pmc_calibration_notes.txt: both count Infinity-Cache hits, i.e. L2 <-> fabric traffic, an upper "
+                         "bound of the HBM bytes): NT %.0f MB, grouped TN %.0f MB per launch"
                          % (tfile, ntk["bytes_per_launch"] / 1e6, tnk["bytes_per_launch"] / 1e6))
         except Exception:
             traffic = None
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic,
+                           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": "cited" if traffic else None,
                            "algorithmic_bytes_per_launch": round(alg_avg),
                            "traffic_note": tnote + "; algorithmic bytes average %.0f MB per launch (NT %.0f MB on average, grouped "
                                            "TN %.1f MB)" % (alg_avg / 1e6, sum(alg_nt) / 8e6, alg_tn / 1e6),

@@ -2,7 +2,7 @@
 # Evidence of one round, run on the GPU box through gpurun:  bash tools/collect_evidence.sh r03_a
 # -> gpurun_out/<tag>/: bench_default.json, kernel stats of a 35-step profiled run, PMC passes (FETCH_SIZE / WRITE_SIZE / SQ
 # counters, each in its own run with --kernel-trace only), the library calibration table.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
@@ -19,4 +19,15 @@ python tools/rocpd_stats.py $OUT/prof/c2a_results.db > $OUT/kernel_stats.csv 2> 
 python tools/pmc_traffic.py $OUT/traffic $OUT/pmc_traffic.json > /dev/null 2> $OUT/pmc_traffic.err
 python tools/pmc_summary.py $OUT/sq gemm_nt_ldp gemm_nt_ld gemm_nt_pp wgrad_ld attn_fwd attn_bwd_rows ln_bwd ln_fwd8 gemm_nt_h16 > $OUT/pmc_sq_summary.txt 2>&1
 rm -rf $OUT/prof $OUT/traffic $OUT/sq
+ls -la $OUT
+# secondary configurations: kernel stats of the C4 training step and of C1
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_c4 -o c4 -- python /root/repo/tools/prof_secondary.py C4 16 30 --det-train > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_c1 -o c1 -- python /root/repo/tools/prof_secondary.py C1 64 30 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $OUT/sq_c4/a -o p --output-format csv -- python /root/repo/tools/prof_secondary.py C4 16 8 --det-train > /dev/null 2>&1
+cd /root/repo
+python tools/rocpd_stats.py $(find $OUT/prof_c4 -name "*.db" | head -1) > $OUT/c4_train_kernel_stats.csv 2> $OUT/c4.err
+python tools/rocpd_stats.py $(find $OUT/prof_c1 -name "*.db" | head -1) > $OUT/c1_kernel_stats.csv 2> $OUT/c1.err
+python tools/pmc_summary.py $OUT/sq_c4 gemm_nt_ldp gemm_nt_ld wgrad_ld attn_fwd attn_bwd_rows attn_bwd_keys ln_bwd ln_fwd8 focal assemble_bwd > $OUT/c4_pmc_sq_summary.txt 2>&1
+rm -rf $OUT/prof_c4 $OUT/prof_c1 $OUT/sq_c4
 ls -la $OUT
