@@ -432,7 +432,11 @@ def main():
     ap.add_argument("--no-extra-step", action="store_true",
                     help="skip the untimed extras - the step in the other stream configuration and the forward-only loop "
                          "(profiling runs: the summary then holds only steps like the timed ones)")
-    ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay measurement")
+    ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay measurement (implies --step-mode eager)")
+    ap.add_argument("--step-mode", default="auto", choices=["auto", "graph", "eager"],
+                    help="how the K timed steps are issued: 'graph' = the whole step (weight refresh, forward, backward) captured once "
+                         "in a HIP graph and replayed K times (tim_amd/graph.py: one host call per step); 'eager' = K eager steps of "
+                         "~144 launches each; 'auto' (default) = graph on one GPU, eager when the step contains collectives (--gpus > 1)")
     ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--det-train", action="store_true",
                     help="detection workloads (C4): the true training step (train-mode query draw, labelling, focal + DIoU) instead of the inference form")
@@ -508,22 +512,66 @@ def main():
             res = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         print(json.dumps(res), flush=True)
         os._exit(0)   # skip interpreter teardown of a process that may hold a half-built capture
+    # ---- how the timed steps are issued.  The eager step is ~144 launches that a free host issues in ~3.4 ms - under the 5.3 ms
+    # the GPU needs, but not by much: on a box whose host cores were busy with other tenants (load average 10-24, round 4) the
+    # same build measured 9.25 ms per eager step with 8.2 ms of it host issue, and 5.27 ms as a replayed HIP graph.  The headline
+    # therefore times the step the way the framework runs it in production (tim_amd/graph.py): captured once,
+    # replayed - every kernel of the eager step, fresh dropout masks per replay (device-side salt), the weight refresh included;
+    # parity of a replay with the eager step: tests/test_gpu_graph.py (C2a B = 64 fp16, detection training).  The eager figures
+    # stay in the line (`eager`), and with collectives in the step (--gpus > 1) the timed steps are eager.
+    mode = args.step_mode
+    if args.no_graph and mode == "auto":
+        mode = "eager"
+    if mode == "auto":
+        mode = "graph" if world == 1 else "eager"
+    if mode == "graph" and world > 1:
+        raise SystemExit("--step-mode graph is a single-GPU mode (the data-parallel step issues RCCL collectives on a side stream)")
+    gstep = None
+    graph_note = None
+    if mode == "graph":
+        try:
+            from tim_amd.graph import GraphedStep
+            gstep = GraphedStep(model, lambda: step_fn(run_model, batch, nv, na, R))
+        except Exception as e:  # noqa: BLE001  (a runtime that refuses the capture: the eager steps are timed, and the line says so)
+            gstep, mode = None, "eager"
+            graph_note = "HIP-graph capture failed (%s: %s): eager steps timed" % (type(e).__name__, str(e)[:160])
+    run_step = gstep if gstep is not None else (lambda: step_fn(run_model, batch, nv, na, R))
     for _ in range(args.warmup):
-        step_fn(run_model, batch, nv, na, R)
+        run_step()
     barrier()
     live = None
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - 1 and rank == 0 and not args.no_roofline:
+        if gstep is None and i == args.steps - 1 and rank == 0 and not args.no_roofline:
             # roofline: HIP events around every encoder-layer GEMM launch (>= 1e10 FLOPs: excludes heads / embedders) of the
             # LAST timed step, recorded on the streams the kernels are launched on (timhip_gemm_timing_*)
             from tim_amd import _lib as L
             L.call("timhip_gemm_timing_start", 256, 1.0e10)
             live = True
-        step_fn(run_model, batch, nv, na, R)
+        run_step()
     t_enqueue = time.perf_counter() - t0   # host time to ISSUE the K steps (the GPU may still be running them)
     barrier()
     dt = time.perf_counter() - t0
+    eager = None
+    if gstep is not None:
+        # the same step issued eagerly, right behind the timed region: its wall-clock rate and host issue time (the robustness
+        # margin the replay buys), and - in its last step - the per-launch HIP events of the roofline: a replayed graph cannot
+        # carry events around individual launches; the kernels, their launch parameters and the stream are the eager step's
+        ne = max(5, min(args.steps, 20))
+        for _ in range(5):   # (the first eager steps behind a capture re-warm the allocator: tools/eager_after_graph.py)
+            step_fn(run_model, batch, nv, na, R)
+        torch.cuda.synchronize()
+        te0 = time.perf_counter()
+        for i in range(ne):
+            if i == ne - 1 and rank == 0 and not args.no_roofline:
+                from tim_amd import _lib as L
+                L.call("timhip_gemm_timing_start", 256, 1.0e10)
+                live = True
+            step_fn(run_model, batch, nv, na, R)
+        te_issue = time.perf_counter() - te0
+        torch.cuda.synchronize()
+        eager = {"ms_per_step": round((time.perf_counter() - te0) / ne * 1e3, 3), "host_issue_ms_per_step": round(te_issue / ne * 1e3, 3),
+                 "steps": ne, "launches_per_step": 144 if args.workload == "C2a" else None}
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -605,6 +653,8 @@ def main():
         "host_issue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16"}.get(args.precision, "f32"),
         "data": "synthetic",
+        "step_mode": ("hip_graph_replay: the whole step (weight refresh, forward, backward) captured once by tim_amd.graph.GraphedStep, "
+                      "K replays timed" if gstep is not None else "eager: K eager steps timed") + ("; " + graph_note if graph_note else ""),
         "config": {"workload": "%s: EPIC-100 A+V recognition, d_model 512 (E 1024), 6 layers, 8 heads, 50+50 "
                                "feature tokens, 15+10 interval queries, train-mode dropout" % args.workload
                    if args.workload == "C2a" else args.workload,
@@ -612,6 +662,8 @@ def main():
                    "global_batch": world * B, "parallelism": "dp%d" % world, "precision": args.precision},
     }
     out["windows_per_s"] = round(world * B * args.steps / dt, 1)
+    if eager is not None:
+        out["eager"] = eager
     if comm is not None:
         out["comm"] = comm
     if fwd_ms:
@@ -667,6 +719,9 @@ def main():
                                      "extra step after the timed region in the other of the two stream configurations; "
                                      "`achieved_isolated` / `per_shape_isolated` = the same shapes timed back to back on an "
                                      "otherwise idle GPU" % ("h16" if args.precision in ("bf16", "fp16") else "f32"),
+                           "events_from": ("the last of %d eager steps issued right behind the timed region (a replayed graph cannot carry "
+                                           "per-launch events; same kernels, launch parameters and stream)" % eager["steps"]) if eager
+                                          else "the last timed step",
                            "backward_streams": 2 if model.rt.overlap_wgrad else 1,
                            "launches_timed": live[2] if live else 0,
                            "achieved_other_streams": round(live_serial, 1) if live and live_serial else None,
@@ -675,7 +730,7 @@ def main():
     # `value`, which stays the eager number so that the roofline events above sit inside the timed region.  Measured in a CHILD
     # process (`--graph-child`): whatever a runtime does with a capture it dislikes - an exception, or a crash - the bench
     # line of this process is not at stake.
-    if rank == 0 and world == 1 and not args.no_graph:
+    if rank == 0 and world == 1 and not args.no_graph and gstep is None:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--workload", args.workload, "--batch", str(B),
                "--precision", args.precision, "--steps", str(args.steps), "--warmup", str(args.warmup)]

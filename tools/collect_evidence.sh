@@ -9,7 +9,7 @@ cd /root/repo
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 300 python tools/blas_ref.py > $OUT/blas_ref.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-B="python /root/repo/bench.py --no-cpu-baseline --no-extra-step --no-graph --no-per-shape --no-secondary"
+B="python /root/repo/bench.py --no-cpu-baseline --no-extra-step --no-per-shape --no-secondary"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof -o c2a -- $B --steps 35 --warmup 5 > $OUT/bench_profiled_run.json 2> /dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/traffic/f -o p --output-format csv -- $B --steps 9 --warmup 2 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/traffic/w -o p --output-format csv -- $B --steps 9 --warmup 2 > /dev/null 2>&1

@@ -5,7 +5,7 @@ import torch
 import bench
 from tim_amd.config import named_config
 cfg = named_config("C2a"); dev = torch.device("cuda", 0)
-model, _ = bench.build_model(cfg, "bf16", dev); model.train()
+model, _ = bench.build_model(cfg, "fp16", dev); model.train()
 batch = bench.make_batch(cfg, 64, 15, 10, 100, dev); R = [None]
 for _ in range(5): bench.step_fn(model, batch, 15, 10, R)
 torch.cuda.synchronize()
@@ -20,4 +20,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): bench.step_fn(model, batch, 15, 10, R)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
