@@ -432,6 +432,10 @@ int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, in
  * cast of several cotangent matrices (dst[i] is [rows[i], ld[i]], zero padded beyond cols[i]) in one launch. */
 int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, int count, const int* s0, const int* n,
                          void* const* rows_T, void* stream);
+/* dx[B,S,E] (fp32, the gradient entering the last encoder layer) written in one pass: rows s < F <- feats_cot[b,s,:] (NULL: 0),
+ * rows of the count <= 6 DISJOINT token ranges [s0[i], s0[i] + n[i]) (s0[i] >= F) <- d_rows[i][b*n[i] + j,:], every other row 0. */
+int timhip_dx_init(int B, int S, int F, int E, const float* feats_cot, int count, const int* s0, const int* n,
+                   const float* const* d_rows, float* dx, void* stream);
 int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, const int* n,
                               const float* const* d_rows, float* dx, void* stream);
 int timhip_cast_rows_many(int precision, int count, const float* const* src, const int* rows, const int* cols,

@@ -140,6 +140,7 @@ _SIGS = {
     "timhip_ln_partials_reduce": (C.c_int, [vp, i32, i32, i32, vp, vp, vp]),
     "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "timhip_dx_init": (C.c_int, [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]),
     "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),
     "timhip_reload_env": (None, []),

@@ -805,14 +805,8 @@ class EncoderFn(torch.autograd.Function):
 
         # gradient stream of the last layer's output: the feature rows start as the incoming `feats` cotangent (a copy, not a
         # zero fill + add: 66 instead of 118 MB at C2a), the query rows as zeros for the heads' row scatters to add into
-        dx = torch.empty((M, E), dtype=torch.float32, device=dev)
+        dx = torch.empty((M, E), dtype=torch.float32, device=dev)   # (written below, behind the heads' input-gradient products)
         dx3 = dx.view(B, S, E)
-        if g["feats"] is not None:
-            dx3[:, :F].copy_(g["feats"])
-        else:
-            dx3[:, :F].zero_()
-        if S > F:
-            dx3[:, F:].zero_()
         xL_t = ctx.xs_t[Lyr]
         # fp16: scale of the gradient operands for this pass, from the cotangents that enter it (device side, no sync).  The
         # fp32 stream dx and every parameter gradient stay true-scale; only fp16 tensors carry the factor.
@@ -857,10 +851,18 @@ class EncoderFn(torch.autograd.Function):
         rt.gemm_many(L.EPI_ADD_F32, head_dgrads, acc_scale=gs_out)
         spans = sorted((h[1], h[1] + h[2]) for h in head_scatter)
         disjoint = all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))   # detection: several heads read one row
-        if 2 <= len(head_scatter) <= 6 and disjoint:
-            call("timhip_scatter_ranges_add", B, S, E, len(head_scatter), _iarr([h[1] for h in head_scatter]),
+        gfeats = _f32c(g["feats"]) if g["feats"] is not None else None
+        if len(head_scatter) <= 6 and disjoint:
+            # one pass writes the whole stream: feature rows <- the `feats` cotangent, query rows <- their head's rows, rest 0
+            call("timhip_dx_init", B, S, F, E, ptr(gfeats), len(head_scatter), _iarr([h[1] for h in head_scatter]),
                  _iarr([h[2] for h in head_scatter]), _parr([h[0] for h in head_scatter]), ptr(dx), st)
         else:
+            if gfeats is not None:
+                dx3[:, :F].copy_(gfeats)
+            else:
+                dx3[:, :F].zero_()
+            if S > F:
+                dx3[:, F:].zero_()
             for d_rows, s0, n in head_scatter:
                 call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
         del head_dgrads, head_scatter, head_casts

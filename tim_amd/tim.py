@@ -199,13 +199,17 @@ class _GradBuckets:
         for b in self.order:
             n = (sizes[b] + 63) // 64 * 64                 # 256-byte aligned bucket starts (the tail padding is exchanged too)
             self.flat[b] = self.base[pos:pos + n]
+            pos += n
+        # zero fills: whole buckets the kernels accumulate into (heads, front end), and of the overwritten layer buckets only
+        # the pieces nobody writes (alignment tails) or that are accumulated into (LayerNorm slices) - ONE multi-tensor launch
+        # for all the small pieces (they used to be a fill launch per layer)
+        accumulated = []
+        for b in self.order:
             if not (layer_overwrite and b.startswith("layer")):
                 self.flat[b].zero_()
-            else:
-                self.flat[b][sizes[b]:].zero_()
-            pos += n
+            elif self.flat[b].numel() > sizes[b]:
+                accumulated.append(self.flat[b][sizes[b]:])
         off = {b: 0 for b in sizes}
-        accumulated = []
         for n, p in zip(names, params):
             b = bucket_of(n)
             self.views[n] = self.flat[b][off[b]:off[b] + p.numel()].view(p.shape)
