@@ -99,7 +99,9 @@ def main(argv=None):
         # non-finite guard (what GradScaler.step does in the reference loop, train.py:355-363): the fp16 mode's device-side
         # gradient scale never skips a step by itself, so the loop does - the clip already computes the norm
         gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-        if torch.isfinite(gnorm):
+        inner = model.module if hasattr(model, "module") else model
+        # (two equivalent tests: the norm the clip computed, and the word the weight-gradient kernels OR when they write inf / nan)
+        if torch.isfinite(gnorm) and inner.rt.grads_finite():
             opt.step()
         hist.append(loss.item())
         if rank == 0 and (step % 5 == 0 or step == args.steps - 1):
