@@ -162,7 +162,7 @@ void read_knobs(TimKnobs& k) {
   k.fuse_ln = env_int("TIMHIP_FUSE_LN", 0); k.fuse_ln_spin = env_int("TIMHIP_FUSE_LN_SPIN", 100000);
   k.wgrad_pp = env_int("TIMHIP_WGRAD_PP", 1); k.wgrad_ld = env_int("TIMHIP_WGRAD_LD", 1); k.wgrad_pf = env_int("TIMHIP_WGRAD_PF", 4);
   k.attn_waves = env_int("TIMHIP_ATTN_WAVES", 0); k.attn_fused = env_int("TIMHIP_ATTN_FUSED", 1);
-  k.attn_pipe = env_int("TIMHIP_ATTN_PIPE", 1);
+  k.ln_rpb = env_int("TIMHIP_LN_RPB", 0);
 }
 }  // namespace
 const TimKnobs& tim_knobs() {

@@ -290,7 +290,7 @@ struct TimKnobs {
   int wgrad_pf;       // TIMHIP_WGRAD_PF     its L2 prefetch distance (default 4)
   int attn_waves;     // TIMHIP_ATTN_WAVES   waves per attention block (0: by shape)
   int attn_fused;     // TIMHIP_ATTN_FUSED   0: two-kernel attention backward
-  int attn_pipe;      // TIMHIP_ATTN_PIPE    0: one (window, head) per attention-forward block (no persistent pipeline)
+  int ln_rpb;         // TIMHIP_LN_RPB       rows per LayerNorm-backward block (0: by shape)
 };
 const TimKnobs& tim_knobs();
 

@@ -1117,6 +1117,7 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
 // 16 rows per block, more when that would exceed the 768 co-resident blocks (3 per CU at the 154 VGPRs of the encoder's
 // act == 0 kernel): one balanced round
 static int ln_bwd_rows_per_block(int rows) {
+  if (tim_knobs().ln_rpb >= 4) return tim_knobs().ln_rpb / 4 * 4;   // (A/B knob)
   int rpb = 16;
   if (rows > 16 * 768) rpb = (((rows + 767) / 768) + 3) / 4 * 4;
   return rpb;
