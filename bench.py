@@ -114,7 +114,10 @@ def step_fn(model, batch, nv, na, R):
     inner = model.module if hasattr(model, "module") else model
     if isinstance(R, dict):          # detection as true training: R carries {"target": ..., state}
         return det_train_step(model, batch, R["target"], R)
-    for p in inner.parameters():
+    plist = inner.__dict__.get("_bench_plist")
+    if plist is None:
+        plist = inner.__dict__["_bench_plist"] = list(inner.parameters())   # (walking the module tree costs ~0.25 ms per step)
+    for p in plist:
         p.grad = None
     inner.rt.invalidate_weights()  # weights changed (optimizer step): redo the operand copies
     if hasattr(inner, "reg_head"):   # detection in inference form with gradients: dense query pyramid generated by the model

@@ -328,8 +328,24 @@ class TIM(nn.Module):
 
     # ---- helpers used by tim_amd.functional --------------------------------------------------------
     def _encoder_param_list(self):
-        sd = dict(self.named_parameters())
-        return [sd[n] for n in self._encoder_param_names]
+        """the parameters the encoder Function takes, in `_encoder_param_names` order.  Walking the module tree costs the host
+        ~0.3 ms per call (a tenth of an eager step's issue time), so the list is kept; `nn.Module._apply` (.to / .cuda / .half
+        keep the Parameter objects when torch's default `__future__` flags are in force, but may not) drops it, and so does
+        `invalidate_param_cache()` - call that after REPLACING a parameter object inside the model (in-place updates,
+        `load_state_dict`, optimizers need nothing)."""
+        lst = self.__dict__.get("_enc_params")
+        if lst is None:
+            sd = dict(self.named_parameters())
+            lst = [sd[n] for n in self._encoder_param_names]
+            self.__dict__["_enc_params"] = lst
+        return lst
+
+    def invalidate_param_cache(self):
+        self.__dict__.pop("_enc_params", None)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_enc_params", None)
+        return super()._apply(fn, *args, **kwargs)
 
     def _plan(self, T, nv, na):
         key = (T, nv, na)
