@@ -243,3 +243,30 @@ def test_detection_training_step_replay_is_the_eager_step(salt_off, monkeypatch)
             s = rep["grads"][n].abs().max().item() + 1e-12
             assert (p.grad - rep["grads"][n]).abs().max().item() <= 1e-4 * s, n
     assert not torch.equal(seen[0], seen[1])                                 # a fresh draw per replay
+
+
+def test_nonfinite_watch_follows_the_replays(salt_off):
+    """`rt.grads_finite()` under HIP-graph replay: the flag words of the captured backward passes are rewritten by every
+    replay - a replay whose cotangents overflow reads False (and its gradients really are non-finite), the next healthy replay
+    True again, also after earlier reads; eager passes in between are folded in."""
+    cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+    B, nv, na = 4, 4, 2
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=3, dtype=torch.float32)
+    model = _model(cfg, sd, "fp16", 0.0)
+    static = {k: v.to(DEV).clone() for k, v in inp.items()}
+    R = []
+    fn = _step(model, static, nv, na, R)
+    gs = GraphedStep(model, fn)
+    gs()
+    assert model.rt.grads_finite() and model.rt.grads_finite()
+    good = [r.clone() for r in R]
+    R[0].fill_(float("inf"))                       # the captured backward reads the cotangents from these static tensors
+    gs()
+    finite = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    assert not finite and not model.rt.grads_finite()
+    for r, g in zip(R, good):
+        r.copy_(g)
+    gs()
+    assert model.rt.grads_finite()
+    fn()                                           # an eager pass in between
+    assert model.rt.grads_finite()

@@ -87,6 +87,7 @@ class Runtime:
         # cotangent before values go subnormal
         self.grad_scale_target = 16.0
         self._gs_blocks = []   # this runtime's timhip_grad_scale blocks since the last grads_finite() (word 4 = non-finite flag)
+        self._gs_captured = []  # ... and the blocks of captured (HIP-graph) backward passes
         self._nf_acc = None
         self._wcache = {}
         self._wparams = {}  # id(param) -> weakref: every weight this runtime has cast
@@ -296,9 +297,13 @@ class Runtime:
         if self.prec != L.PREC_F16:
             return None
         gs = torch.zeros(8, dtype=torch.float32, device=dev)   # {S, 1/S, scratch, scratch, non-finite flag, 0, 0, 0}
-        self._gs_blocks.append(gs)
-        if len(self._gs_blocks) > 16 and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            self._fold_flags()               # (many backward passes without a reader: fold on the device, no sync)
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a block of a captured step lives as long as the graph and is rewritten by every replay: watched for good
+            self._gs_captured.append(gs)
+        else:
+            self._gs_blocks.append(gs)
+            if len(self._gs_blocks) > 16:
+                self._fold_flags()           # (many backward passes without a reader: fold on the device, no sync)
         cots = [c for c in cotangents if c is not None and c.numel() > 0]
         if not cots:
             gs[:2] = 1.0
@@ -314,13 +319,17 @@ class Runtime:
             f = torch.stack([g[4] for g in self._gs_blocks]).view(torch.int32).ne(0).any()
             self._nf_acc = f if self._nf_acc is None else (self._nf_acc | f)
             self._gs_blocks = []
+        if self._gs_captured:   # (not consumed: the next replay zeroes and rewrites them)
+            f = torch.stack([g[4] for g in self._gs_captured]).view(torch.int32).ne(0).any()
+            self._nf_acc = f if self._nf_acc is None else (self._nf_acc | f)
 
     def grads_finite(self, reset=True):
         """False iff a weight / bias gradient written since the last call (by this runtime's backward passes) was inf or nan -
         the fp16 mode's counterpart of GradScaler's inf check (reference scripts/train.py:351,357-363: skip the optimizer
         step).  The kernels that write the gradients OR one device word (include/timhip.h: timhip_grad_scale); nothing is
         synchronised until this call reads it.  Always True in the fp32 / bf16 modes (8 exponent bits: no overflow to watch).
-        Under HIP-graph replay the word belongs to the captured backward: it describes the latest replay."""
+        Under HIP-graph replay the words belong to the captured backward passes: every replay zeroes and rewrites them, so
+        they describe the LATEST replay (reading does not clear them; eager passes in between are folded in as usual)."""
         self._fold_flags()
         if self._nf_acc is None:
             return True
