@@ -469,7 +469,10 @@ def test_fp16_scaled_gradient_operands():
     assert ref_dx.abs().max().item() > 0 and float(g.cpu().to(torch.float16).abs().max()) < 2e-6
 
 
-_PP_SHAPES = [(9920, 1024, 1024), (9920, 3072, 1024), (9920, 1024, 2048), (9925, 1000, 192), (3000, 2056, 64)]
+_PP_SHAPES = [(9920, 1024, 1024), (9920, 3072, 1024), (9920, 1024, 2048), (9925, 1000, 192), (3000, 2056, 64),
+              # M = 7984 / 8000 (detection B = 16 x 499 tokens, Perception Test): 50 panels of 160 rows would leave a fifth of
+              # the CUs idle - these run the 128-row tile (63 panels: 252 tiles per 1024 columns), one tile per block and walked
+              (7984, 1024, 1024), (7984, 3072, 1024), (8000, 2048, 192)]
 
 
 def _pp_knobs(knobs, loaders):

@@ -163,6 +163,7 @@ void read_knobs(TimKnobs& k) {
   k.wgrad_pp = env_int("TIMHIP_WGRAD_PP", 1); k.wgrad_ld = env_int("TIMHIP_WGRAD_LD", 1); k.wgrad_pf = env_int("TIMHIP_WGRAD_PF", 4);
   k.attn_waves = env_int("TIMHIP_ATTN_WAVES", 0); k.attn_fused = env_int("TIMHIP_ATTN_FUSED", 1);
   k.ln_rpb = env_int("TIMHIP_LN_RPB", 0);
+  k.gemm_tmw = env_int("TIMHIP_GEMM_TMW", 0);
 }
 }  // namespace
 const TimKnobs& tim_knobs() {

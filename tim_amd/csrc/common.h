@@ -291,6 +291,7 @@ struct TimKnobs {
   int attn_waves;     // TIMHIP_ATTN_WAVES   waves per attention block (0: by shape)
   int attn_fused;     // TIMHIP_ATTN_FUSED   0: two-kernel attention backward
   int ln_rpb;         // TIMHIP_LN_RPB       rows per LayerNorm-backward block (0: by shape)
+  int gemm_tmw;       // TIMHIP_GEMM_TMW     5 / 4: force the 160- / 128-row tile of the loader-wave NT kernels (0: by shape)
 };
 const TimKnobs& tim_knobs();
 

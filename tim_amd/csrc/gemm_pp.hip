@@ -558,8 +558,9 @@ __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const
                                         int nk, uint32_t lds0, int lw, int lane) {
   constexpr int BM = 32 * TMW, A_GROUPS = BM / 32;
   constexpr int ST_BYTES = (BM + PP_BN) * PP_ROWB;
-  static_assert(A_GROUPS == 5, "group table written for the 160 x 256 tile");
-  const int g0 = lw == 0 ? 0 : 1 + 3 * lw, ng = lw == 0 ? 4 : 3;   // groups 0-3 | 4-6 | 7-9 | 10-12
+  static_assert(A_GROUPS == 5 || A_GROUPS == 4, "group tables: the 160 x 256 tile (13 groups of 32 rows) and the 128 x 256 tile (12)");
+  // 160 x 256: groups 0-3 | 4-6 | 7-9 | 10-12;  128 x 256: three groups per loader wave
+  const int g0 = A_GROUPS == 5 ? (lw == 0 ? 0 : 1 + 3 * lw) : 3 * lw, ng = (A_GROUPS == 5 && lw == 0) ? 4 : 3;
   const int lrow = lane >> 3, lchunk = lane & 7;
   uint32_t off[16];
 #pragma unroll
@@ -579,7 +580,7 @@ __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const
   group(0, 0, 0); group(0, 0, 1); group(0, 0, 2); group(0, 0, 3);
   if (nk > 1) {
     group(1, 1, 0); group(1, 1, 1); group(1, 1, 2); group(1, 1, 3);
-    if (lw == 0) glds_wait<16>(); else glds_wait<12>();
+    if (ng == 4) glds_wait<16>(); else glds_wait<12>();
   } else {
     glds_wait<0>();
   }
@@ -590,7 +591,7 @@ __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const
       const int nslot = slot >= 1 ? slot - 1 : PP_NST - 1;
       if (t + 2 < nk) {
         group(t + 2, nslot, 0); group(t + 2, nslot, 1); group(t + 2, nslot, 2); group(t + 2, nslot, 3);
-        if (lw == 0) glds_wait<16>(); else glds_wait<12>();   // stage t + 1 (issued one interval earlier) has landed
+        if (ng == 4) glds_wait<16>(); else glds_wait<12>();   // stage t + 1 (issued one interval earlier) has landed
       } else {
         glds_wait<0>();
       }
@@ -1122,12 +1123,15 @@ void launch_dg(const void* A, int lda, const void* B, int ldb, int M, int N, int
 
 #endif
 
-template <typename HT, int EPI>
+template <typename HT, int EPI, int TMW = 5>
 void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, hipStream_t s) {
-  constexpr int TMW = 5, BM = 32 * TMW;
+  constexpr int BM = 32 * TMW;
   const size_t shmem = (size_t)PP_NST * (BM + PP_BN) * PP_ROWB;
+  if constexpr (TMW != 5) {   // the 128-row tile exists for the loader-wave kernels only
+    if (tim_knobs().gemm_ld == 0 || e.a_wrap != 0) return launch_pp<HT, EPI, 5>(A, lda, B, ldb, M, N, K, e, s);
+  }
 #ifdef TIMHIP_TUNING   // per-phase cycle counters (tools/pp_phase.py)
-  if constexpr (EPI == TIMHIP_EPI_STORE_T) {
+  if constexpr (EPI == TIMHIP_EPI_STORE_T && TMW == 5) {
     if (getenv("TIMHIP_PP_PROF")) {
       const char* ab = getenv("TIMHIP_PP_ABL");   // 1 no DMA, 2 no MFMAs, 3 DMA only, L the late wait (two-barrier loop)
       const dim3 g_(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
@@ -1152,13 +1156,14 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
 #endif
   static PerDeviceOnce attr_set;   // idempotent; a benign race sets it twice at worst
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if constexpr (TMW == 5)
+      (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   }
   const TimKnobs& kn = tim_knobs();
   const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
 #ifdef TIMHIP_TUNING
-  if constexpr (EPI != TIMHIP_EPI_DROP_RES_F32) {   // (that epilogue's residual prefetch leaves no registers for the tile loop's state)
+  if constexpr (EPI != TIMHIP_EPI_DROP_RES_F32 && TMW == 5) {   // (that epilogue's residual prefetch leaves no registers for the tile loop's state)
     // two or three full rounds of tiles: the 8-wave persistent-tile kernel - TIMHIP_GEMM_PT=1, tuning builds only (measured equal
     // to one tile per block within the run-to-run spread, in_proj forward 71.8 vs 71.5 us, linear1 61.8 vs 60.3, linear2 input
     // gradient 50.7 vs 50.5 - profiles/r03_nt_kernel_variants_ab.txt)
@@ -1196,7 +1201,7 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
     const int pf_d_ = (grid.x > 256 && tpb == 1) ? kn.gemm_pf_mr : kn.gemm_pf;
     const dim3 grid_(tiles_ / tpb);
 #ifdef TIMHIP_TUNING
-    if (kn.gemm_ld1 == 1) {   // one barrier per contraction step (measured: +4.6 % isolated, +0.5 % in the step)
+    if constexpr (TMW == 5) if (kn.gemm_ld1 == 1) {   // one barrier per contraction step (measured: +4.6 % isolated, +0.5 % in the step)
       static PerDeviceOnce attr_l1;
       if (attr_l1.first())
         (void)hipFuncSetAttribute((const void*)gemm_nt_ld_kernel<HT, EPI, TMW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -1217,7 +1222,27 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
                        pf_d_, kn.gemm_pf_mode);
     return;
   }
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+  if constexpr (TMW == 5)
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<HT, EPI, TMW>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+}
+
+// Which row-panel height: 160 (the default: 98 FLOP per staged byte) or 128 (85)?  What a launch costs is (rounds of co-resident
+// blocks) x (tiles a block walks) x (bytes a tile stages per step); M = 7984 (detection, B = 16 x 499 tokens) and M = 8000
+// (Perception Test) give 50 panels of 160 rows - 200 tiles per 1024 columns on 256 CUs - but 63 panels of 128: 252.
+static int pp_cost(int M, int N, int K, int bm) {
+  const int tiles_n = (N + PP_BN - 1) / PP_BN, tiles = ((M + bm - 1) / bm) * tiles_n;
+  int tpb = 1;
+  if (tiles > 256) {
+    const int want = (tiles + 255) / 256;
+    if (want <= 4 && tiles_n % want == 0 && tiles % want == 0 && K >= 128) tpb = want;
+  }
+  const int blocks = tiles / tpb, rounds = (blocks + 255) / 256;
+  return rounds * tpb * (bm + PP_BN);
+}
+static int pp_tmw(int M, int N, int K) {
+  const int force = tim_knobs().gemm_tmw;   // (A/B knob)
+  if (force == 4 || force == 5) return force;
+  return pp_cost(M, N, K, 128) * 100 < pp_cost(M, N, K, 160) * 97 ? 4 : 5;
 }
 
 }  // namespace
@@ -1301,6 +1326,7 @@ int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B
                    hipStream_t s) {
   const EpiDev& e = *reinterpret_cast<const EpiDev*>(epi_dev);
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
+  const bool tall = pp_tmw(M, N, K) == 5;
 #ifdef TIMHIP_TUNING
   // TIMHIP_GEMM_DG=1 (tuning builds): the dual-group persistent kernel where the shape allows - measured 13 % slower over the
   // layer's eight shapes than the one-tile-per-block kernel: its 160 x 128 group tiles stage 72 KiB per step pair where the
@@ -1325,7 +1351,7 @@ int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B
 plain:
 #endif
   switch (epi) {
-#define CASE(X) case X: DISPATCH_H16(precision, (launch_pp<HT, X>(A, lda, B, ldb, M, N, K, e, s))); break;
+#define CASE(X) case X: DISPATCH_H16(precision, (tall ? launch_pp<HT, X, 5>(A, lda, B, ldb, M, N, K, e, s) : launch_pp<HT, X, 4>(A, lda, B, ldb, M, N, K, e, s))); break;
     CASE(TIMHIP_EPI_STORE_T)
     CASE(TIMHIP_EPI_RELU_T)
     CASE(TIMHIP_EPI_STORE_F32)
