@@ -296,6 +296,7 @@ class Runtime:
         from the largest |cotangent| - no host synchronisation."""
         if self.prec != L.PREC_F16:
             return None
+        dev = torch.device(dev)
         gs = torch.zeros(8, dtype=torch.float32, device=dev)   # {S, 1/S, scratch, scratch, non-finite flag, 0, 0, 0}
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             # a block of a captured step lives as long as the graph and is rewritten by every replay: watched for good
