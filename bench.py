@@ -771,9 +771,9 @@ def main():
         if args.workload == "C2a":
             sec_steps = max(5, args.steps // 2)
             for key, wl, b_, kw, desc in (
-                    ("c2b", "C2b", B, {}, "C2b: 75+75 feature tokens, 15+10 queries (S = 205), train-mode dropout"),
+                    ("c2b", "C2b", B, {"graph": True}, "C2b: 75+75 feature tokens, 15+10 queries (S = 205), train-mode dropout"),
                     ("c1", "C1", B, {"graph": True}, "C1: visual-only, d_model 256, 2 layers, 4 heads, 50 tokens + 3 x 10 queries (S = 80), train-mode dropout"),
-                    ("c3", "C3", B, {}, "C3: Perception Test A+V recognition, 50+50 tokens, 15+10 queries, dropouts 0.1"),
+                    ("c3", "C3", B, {"graph": True}, "C3: Perception Test A+V recognition, 50+50 tokens, 15+10 queries, dropouts 0.1"),
                     ("c4_train", "C4", 16, {"det_train": True, "graph": True},
                      "C4: EPIC-100 detection TRAINING step (det scripts/train.py:212-349): model.train(), 399 queries drawn from the "
                      "training pyramid, IoU labelling on the device, encoder forward, sigmoid focal loss with IoU row weights + 1-D "
