@@ -529,6 +529,34 @@ def main():
         mode = "graph" if world == 1 else "eager"
     if mode == "graph" and world > 1:
         raise SystemExit("--step-mode graph is a single-GPU mode (the data-parallel step issues RCCL collectives on a side stream)")
+    eager = None
+    live = None
+    if mode == "graph":
+        # the same step issued eagerly, right BEFORE the capture and the timed region: its wall-clock rate and host issue time (the
+        # robustness margin the replay buys), and - in its last step - the per-launch HIP events of the roofline: a replayed graph
+        # cannot carry events around individual launches; the kernels, their launch parameters and the stream are the eager
+        # step's.  (Before, not behind: eager steps issued in a process that holds an instantiated graph of the same step cost
+        # the host 4 - 11 ms instead of 3.5, tools/eager_after_graph.py and profiles/r04_c_bench_default.json.)
+        ne = max(5, min(args.steps, 20))
+        for _ in range(max(30, args.warmup)):   # (a process needs ~30 eager steps before its host side is in steady state: lazily
+            step_fn(run_model, batch, nv, na, R)   # loaded code objects, allocator growth - tools/eager_after_graph.py: 6.1 -> 3.5 ms of issue time)
+        torch.cuda.synchronize()
+        te0 = time.perf_counter()
+        for i in range(ne):
+            if i == ne - 1 and rank == 0 and not args.no_roofline:
+                from tim_amd import _lib as L
+                L.call("timhip_gemm_timing_start", 256, 1.0e10)
+                live = True
+            step_fn(run_model, batch, nv, na, R)
+        te_issue = time.perf_counter() - te0
+        torch.cuda.synchronize()
+        eager = {"ms_per_step": round((time.perf_counter() - te0) / ne * 1e3, 3), "host_issue_ms_per_step": round(te_issue / ne * 1e3, 3),
+                 "steps": ne, "launches_per_step": 144 if args.workload == "C2a" else None}
+        if live:
+            import ctypes as C
+            ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int(0)
+            L.call("timhip_gemm_timing_stop", C.byref(ms_), C.byref(fl_), C.byref(n_))
+            live = (ms_.value, fl_.value, n_.value)
     gstep = None
     graph_note = None
     if mode == "graph":
@@ -542,10 +570,9 @@ def main():
     for _ in range(args.warmup):
         run_step()
     barrier()
-    live = None
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if gstep is None and i == args.steps - 1 and rank == 0 and not args.no_roofline:
+        if gstep is None and live is None and i == args.steps - 1 and rank == 0 and not args.no_roofline:
             # roofline: HIP events around every encoder-layer GEMM launch (>= 1e10 FLOPs: excludes heads / embedders) of the
             # LAST timed step, recorded on the streams the kernels are launched on (timhip_gemm_timing_*)
             from tim_amd import _lib as L
@@ -555,35 +582,15 @@ def main():
     t_enqueue = time.perf_counter() - t0   # host time to ISSUE the K steps (the GPU may still be running them)
     barrier()
     dt = time.perf_counter() - t0
-    eager = None
-    if gstep is not None:
-        # the same step issued eagerly, right behind the timed region: its wall-clock rate and host issue time (the robustness
-        # margin the replay buys), and - in its last step - the per-launch HIP events of the roofline: a replayed graph cannot
-        # carry events around individual launches; the kernels, their launch parameters and the stream are the eager step's
-        ne = max(5, min(args.steps, 20))
-        for _ in range(5):   # (the first eager steps behind a capture re-warm the allocator: tools/eager_after_graph.py)
-            step_fn(run_model, batch, nv, na, R)
-        torch.cuda.synchronize()
-        te0 = time.perf_counter()
-        for i in range(ne):
-            if i == ne - 1 and rank == 0 and not args.no_roofline:
-                from tim_amd import _lib as L
-                L.call("timhip_gemm_timing_start", 256, 1.0e10)
-                live = True
-            step_fn(run_model, batch, nv, na, R)
-        te_issue = time.perf_counter() - te0
-        torch.cuda.synchronize()
-        eager = {"ms_per_step": round((time.perf_counter() - te0) / ne * 1e3, 3), "host_issue_ms_per_step": round(te_issue / ne * 1e3, 3),
-                 "steps": ne, "launches_per_step": 144 if args.workload == "C2a" else None}
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    if live:
-        import ctypes as C
-        from tim_amd import _lib as L
-        ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int(0)
+    import ctypes as C
+    from tim_amd import _lib as L
+    ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int(0)
+    if live is True:
         L.call("timhip_gemm_timing_stop", C.byref(ms_), C.byref(fl_), C.byref(n_))
         live = (ms_.value, fl_.value, n_.value)
     comm = None
@@ -722,7 +729,7 @@ def main():
                                      "extra step after the timed region in the other of the two stream configurations; "
                                      "`achieved_isolated` / `per_shape_isolated` = the same shapes timed back to back on an "
                                      "otherwise idle GPU" % ("h16" if args.precision in ("bf16", "fp16") else "f32"),
-                           "events_from": ("the last of %d eager steps issued right behind the timed region (a replayed graph cannot carry "
+                           "events_from": ("the last of %d eager steps issued right before the capture and the timed region (a replayed graph cannot carry "
                                            "per-launch events; same kernels, launch parameters and stream)" % eager["steps"]) if eager
                                           else "the last timed step",
                            "backward_streams": 2 if model.rt.overlap_wgrad else 1,
