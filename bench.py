@@ -764,7 +764,8 @@ def main():
             try:
                 m2, _ = build_model(cfg, "bf16", dev, seed=0)
                 m2.train()
-                ms2 = timed_steps(m2, batch, nv, na, max(5, args.steps // 2), 3)
+                R2 = [None]   # (median of per-step event intervals after 30 warm-ups: a fresh model's first eager steps are host-bound)
+                ms2 = robust_step_ms(lambda: step_fn(m2, batch, nv, na, R2), max(5, args.steps // 2), 30)[0]
                 err2, _ = logit_parity(m2, cfg, sd_np, nv, na, dev)
                 out["bf16_mode"] = {"ms_per_step": round(ms2, 3), "interval_queries_per_s": round(B * (nv + na) / ms2 * 1e3, 1),
                                     "max_abs_logit_err": float("%.3g" % err2),
