@@ -658,3 +658,33 @@ def test_gemm_weight_split_with_wrapped_a_operand(prec, M, N, K):
     rt.gemm(L.EPI_DROP_RES_F32, A, W3, M, N, 2 * K, out, N, res=res, ldres=N, rep=2, a_wrap_k=K)
     torch.cuda.synchronize()
     assert (out.double() - (ref + res.double())).abs().max().item() <= lim * 2
+
+
+def test_dx_init_writes_the_whole_stream():
+    """timhip_dx_init (round 4): the gradient stream entering the encoder stack in one pass - feature rows <- the `feats`
+    cotangent (zeros without one), the rows of up to six DISJOINT token ranges <- their heads' rows, every other row zero;
+    overlapping ranges and ranges that reach into the feature rows are refused (the caller adds those instead)."""
+    B, S, F, E = 3, 23, 9, 64
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(B, F, E, generator=g).to(DEV)
+    ranges = [(11, 4), (18, 5), (9, 2)]           # [9,11) [11,15) [18,23): rows 15..17 belong to nobody
+    rows = [torch.randn(B * n, E, generator=g).to(DEV) for _, n in ranges]
+    want = torch.zeros(B, S, E, device=DEV)
+    want[:, :F] = feats
+    for (s0, n), r in zip(ranges, rows):
+        want[:, s0:s0 + n] = r.view(B, n, E)
+    dx = torch.full((B * S, E), float("nan"), device=DEV)
+    ia = lambda v: (C.c_int * len(v))(*v)
+    pa = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    L.call("timhip_dx_init", B, S, F, E, L.ptr(feats), 3, ia([r[0] for r in ranges]), ia([r[1] for r in ranges]), pa(rows), L.ptr(dx), st())
+    torch.cuda.synchronize()
+    assert torch.equal(dx.view(B, S, E), want)
+    dx.fill_(float("nan"))
+    L.call("timhip_dx_init", B, S, F, E, None, 0, None, None, None, L.ptr(dx), st())      # nothing to copy: all zeros
+    torch.cuda.synchronize()
+    assert bool((dx == 0).all())
+    lib = L.load()
+    bad = lib.timhip_dx_init(B, S, F, E, L.ptr(feats), 2, ia([11, 13]), ia([4, 4]), pa(rows[:2]), L.ptr(dx), st())   # overlap
+    assert bad != 0
+    bad = lib.timhip_dx_init(B, S, F, E, L.ptr(feats), 1, ia([F - 1]), ia([4]), pa(rows[:1]), L.ptr(dx), st())       # into the feature rows
+    assert bad != 0
