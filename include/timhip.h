@@ -114,6 +114,15 @@ typedef struct TimDesc {
 #define TIMHIP_DESC_INPROJ_SPLIT 32    /* the same for in_w ([3E, ld >= 2E]), l1_w ([FF, ld >= 2E]) and l2_w ([E, ld >= 2FF]): with all four */
 #define TIMHIP_DESC_L1_SPLIT 64        /* set every forward GEMM of the layer carries its weight to ~22 bits at twice the matrix */
 #define TIMHIP_DESC_L2_SPLIT 128       /* work (an opt-in margin mode, tim_amd: TIM_AMD_SPLIT_LAYER_WEIGHTS=all); default: out only */
+/* Backward of TIMHIP_PREC_F16 (grad_scale set), timhip_layer_bwd_split / _data_split: the RESIDUAL part of the gradient stream in
+ * the operand dtype, times the gradient scale - like its branch parts (dx_*_add) and the gradient operands - instead of fp32.
+ *   STREAM16      inside the layer (between the two LayerNorm-backward launches);
+ *   STREAM16_IN   dx_out points at a T [M, E] matrix (what the layer above wrote under STREAM16_OUT), not at floats;
+ *   STREAM16_OUT  dx_in is written as such a T matrix (requires dx_in_add: the layer below adds the two as it reads).
+ * 120 instead of 160 MB per LayerNorm-backward launch at C2a; parameter gradients move by <= 1.5e-3 of their largest element. */
+#define TIMHIP_DESC_STREAM16 0x10000
+#define TIMHIP_DESC_STREAM16_IN 0x20000
+#define TIMHIP_DESC_STREAM16_OUT 0x40000
 
 /* One encoder layer.  *_op are operand-dtype working copies made by timhip_prepare_weights:
  * w (as stored, [N,K]) and wt (transposed, [K,N]).  Biases and LayerNorm parameters are the

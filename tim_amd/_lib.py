@@ -51,6 +51,7 @@ class TimLayerGrads(C.Structure):
 
 DESC_ATTN_FP32, DESC_ATTN_BWD_ONE_KERNEL, DESC_WGRAD_OVERWRITE, DESC_WGRAD_SEPARATE, DESC_OUTPROJ_SPLIT = 1, 2, 4, 8, 16
 DESC_INPROJ_SPLIT, DESC_L1_SPLIT, DESC_L2_SPLIT = 32, 64, 128   # TimDesc.reserved flags
+DESC_STREAM16, DESC_STREAM16_IN, DESC_STREAM16_OUT = 0x10000, 0x20000, 0x40000   # 16-bit residual gradient stream (fp16 backward)
 
 
 class TimCastItem(C.Structure):

@@ -420,11 +420,16 @@ static int layer_bwd_data_impl(const TimDesc& d, const TimLayerParams* w, const 
   const float* gs_in = (prec == TIMHIP_PREC_F16 && d.grad_scale) ? d.grad_scale : nullptr;
   const float* gs_out = gs_in ? gs_in + 1 : nullptr;
 
-  // norm2 backward -> dy2 (fp32) and df = dropout2-mask * dy2 (T)
+  // the residual part of the stream as 16-bit (TIMHIP_DESC_STREAM16*, fp16 mode only: same scale as the gradient operands)
+  const bool s16 = gs_in != nullptr && (d.reserved & TIMHIP_DESC_STREAM16) != 0;
+  const bool s16_in = s16 && (d.reserved & TIMHIP_DESC_STREAM16_IN) != 0;
+  const bool s16_out = s16 && (d.reserved & TIMHIP_DESC_STREAM16_OUT) != 0;
+  if (((d.reserved & (TIMHIP_DESC_STREAM16_IN | TIMHIP_DESC_STREAM16_OUT)) != 0 && !s16) || (s16_out && !dx_in_add)) return TIMHIP_EINVAL;
+  // norm2 backward -> dy2 (fp32; STREAM16: T times S, in f32a's space) and df = dropout2-mask * dy2 (T)
   if ((rc = tim_layernorm_bwd(prec, dx_out, E, y2, E, st2, M, E, 0, w->n2_w, f32a, E, df, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP2), g->n2_w, g->n2_b,
                               g->ln_partials ? g->ln_partials : (float*)(ws + W.lnp), s, g->ln_partials != nullptr, gs_in,
-                              dx_out_add, E, gs_out))) return rc;
+                              dx_out_add, E, gs_out, (s16_in ? 1 : 0) | (s16 ? 2 : 0)))) return rc;
   // du = (df W2) * [dropout-mask * gelu'(pre-activation)]
   TimEpi e = epi0();
   e.out0 = du; e.ld0 = FF; e.aux = u; e.ldaux = FF;   // u = dropmask * gelu'(pre-activation), written by the forward
@@ -447,7 +452,8 @@ static int layer_bwd_data_impl(const TimDesc& d, const TimLayerParams* w, const 
   if ((rc = tim_layernorm_bwd(prec, ln1_in, E, y1, E, st1, M, E, 0, w->n1_w, dy1, E, da, E, d.p_drop, d.seed,
                               layer_site(d.layer, SITE_L_DROP1), g->n1_w, g->n1_b,
                               g->ln_partials ? g->ln_partials + tim_layernorm_bwd_ws(M, E) / sizeof(float) : (float*)(ws + W.lnp), s,
-                              g->ln_partials != nullptr, gs_in, branch_split ? Tb : nullptr, E, gs_out))) return rc;
+                              g->ln_partials != nullptr, gs_in, branch_split ? Tb : nullptr, E, gs_out,
+                              (s16 ? 1 : 0) | (s16_out ? 2 : 0)))) return rc;
   // do = da Wo
   e = epi0();
   e.out0 = Tc; e.ld0 = E;

@@ -461,7 +461,7 @@ AttnArgsM make_args2(const TimDesc& d) {
   a.thr = d.p_drop > 0.f ? drop_threshold(d.p_drop) : 0u;
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
-  a.abl = d.reserved >> 8;
+  a.abl = (d.reserved >> 8) & 0xff;
   a.rsplit = 1; a.rper = (d.S + 31) / 32;
   return a;
 }

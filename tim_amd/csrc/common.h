@@ -444,7 +444,8 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
                       int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,
                       float* dgamma, float* dbeta, float* partial_ws, hipStream_t s, bool defer_colsum = false,
                       const float* t_scale = nullptr,   // t_scale: device scalar multiplied into the operand-dtype copy dy_T
-                      const void* add_T = nullptr, int ldadd = 0, const float* add_scale = nullptr);   // dx += add_scale * add_T
+                      const void* add_T = nullptr, int ldadd = 0, const float* add_scale = nullptr,   // dx += add_scale * add_T
+                      int stream16 = 0);   // bit 0: dx is a T matrix (times 1 / add_scale); bit 1: dy_f32 is written as a T matrix times t_scale
 size_t tim_layernorm_bwd_ws(int rows, int cols);
 int tim_layernorm_bwd_blocks(int rows);   // partial rows one backward launch over `rows` rows writes
 int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);

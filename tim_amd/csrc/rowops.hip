@@ -406,7 +406,12 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
 // reduces dgamma/dbeta over its rows in registers, then LDS across its 4 waves, then one atomic
 // per column per block.
 // ACT0: the LayerNorm input is not an activation (act == 0, the encoder layers): no gelu' / relu' factors and their registers
-template <typename T, int LN_MAXV, bool ACT0 = false>
+// S16 (round 4, fp16 mode inside the encoder stack): bit 0 - `dx` is a T matrix holding the gradient times the gradient scale
+// (what the previous LayerNorm-backward wrote with bit 1), bit 1 - `dyf` is written as such a T matrix (unmasked, times
+// t_scale) instead of fp32: the residual part of the gradient stream travels 16-bit like its branch parts do - 120 instead
+// of 160 MB per launch at C2a.  Its rounding (11 bits under the same scale as the operand copies) moves the parameter
+// gradients by <= 1.5e-3 of their largest element (oracle with the stream rounded at every LayerNorm: cos 0.9999996).
+template <typename T, int LN_MAXV, bool ACT0 = false, int S16 = 0>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dx, int lddx,
                                                      const float* __restrict__ y, int ldy,
                                                      const float* __restrict__ stats, int rows, int cols, int act,
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   // optional second addend of the incoming gradient, in the operand dtype: dx_eff = dx + add_scale * addt.  The input-gradient
   // GEMM in front of this LayerNorm then stores its (scaled) 16-bit product instead of reading the fp32 stream and writing
   // the sum back (20 MB instead of 80 per launch at C2a)
-  const float as = (addt && add_scale) ? *add_scale : 1.f;
+  const float as = ((addt || (S16 & 1) != 0) && add_scale) ? *add_scale : 1.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = (cols + 255) >> 8;
   float4 ag[LN_MAXV], ab[LN_MAXV];
@@ -436,9 +441,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const int c = (i * 64 + lane) * 4;
     ww[i] = (i < nv && c < cols) ? *reinterpret_cast<const float4*>(w + c) : make_float4(0, 0, 0, 0);
   }
+  constexpr bool IN16 = (S16 & 1) != 0, OUT16 = (S16 & 2) != 0;
   float4 tn[LN_MAXV], dn[LN_MAXV];
   typedef T t4_t __attribute__((ext_vector_type(4)));
-  t4_t an[LN_MAXV];
+  t4_t an[LN_MAXV], dn16[LN_MAXV];
   float2 stn = make_float2(0.f, 0.f);
   auto fetch = [&](int row) {
     stn = *reinterpret_cast<const float2*>(stats + 2 * row);
@@ -452,7 +458,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           const f4_t q0_ = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(y + (size_t)row * ldy + c));
           tn[i] = make_float4(q0_[0], q0_[1], q0_[2], q0_[3]);
         }
-        dn[i] = *reinterpret_cast<const float4*>(dx + (size_t)row * lddx + c);
+        if constexpr (IN16) dn16[i] = *reinterpret_cast<const t4_t*>(reinterpret_cast<const T*>(dx) + (size_t)row * lddx + c);
+        else dn[i] = *reinterpret_cast<const float4*>(dx + (size_t)row * lddx + c);
         if (addt) an[i] = *reinterpret_cast<const t4_t*>(addt + (size_t)row * ldadd + c);
       }
     }
@@ -464,7 +471,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float4 xh[LN_MAXV], d[LN_MAXV], ga[LN_MAXV];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
-      xh[i] = tn[i]; d[i] = dn[i];
+      xh[i] = tn[i];
+      if constexpr (IN16) {
+        d[i] = make_float4(OpT<T>::to_f(dn16[i][0]) * as, OpT<T>::to_f(dn16[i][1]) * as, OpT<T>::to_f(dn16[i][2]) * as,
+                           OpT<T>::to_f(dn16[i][3]) * as);
+      } else {
+        d[i] = dn[i];
+      }
       if (addt) {
         d[i].x = fmaf(OpT<T>::to_f(an[i][0]), as, d[i].x); d[i].y = fmaf(OpT<T>::to_f(an[i][1]), as, d[i].y);
         d[i].z = fmaf(OpT<T>::to_f(an[i][2]), as, d[i].z); d[i].w = fmaf(OpT<T>::to_f(an[i][3]), as, d[i].w);
@@ -503,7 +516,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float o0 = rstd * (d[i].x - s1 - xh[i].x * s2), o1 = rstd * (d[i].y - s1 - xh[i].y * s2);
         float o2 = rstd * (d[i].z - s1 - xh[i].z * s2), o3 = rstd * (d[i].w - s1 - xh[i].w * s2);
         if (!ACT0 && act != 0) { o0 *= ga[i].x; o1 *= ga[i].y; o2 *= ga[i].z; o3 *= ga[i].w; }
-        if (dyf) store4<float>(dyf + (size_t)row * lddy + c, o0, o1, o2, o3);
+        if constexpr (OUT16) {
+          if (dyf) store4<T>(reinterpret_cast<T*>(dyf) + (size_t)row * lddy + c, o0 * ts, o1 * ts, o2 * ts, o3 * ts);
+        } else {
+          if (dyf) store4<float>(dyf + (size_t)row * lddy + c, o0, o1, o2, o3);
+        }
         if (dyt) {
           float k0 = ts, k1 = ts, k2 = ts, k3 = ts;
           if (thr != 0u) {
@@ -1129,8 +1146,9 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
                       float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, float* partial_ws,
                       hipStream_t s, bool defer_colsum, const float* t_scale, const void* addt, int ldadd,
-                      const float* add_scale) {
+                      const float* add_scale, int stream16) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
+  if (stream16 && (act != 0 || !h16_storage(precision) || !add_scale || !t_scale)) return TIMHIP_EUNSUPPORTED;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4) || (addt && ldadd % 4))
     return TIMHIP_EUNSUPPORTED;
   const int rpb = ln_bwd_rows_per_block(rows);
@@ -1145,11 +1163,19 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
 #define LN_BWD0(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, true>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
                                    (const T*)addt, ldadd, add_scale)
-  if (act == 0 && nv == 4) {
+#define LN_BWD16(NV, SV) hipLaunchKernelGGL((ln_bwd_kernel<HT, NV, true, SV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
+                                   cols, act, w, dyf, lddy, (HT*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
+                                   (const HT*)addt, ldadd, add_scale)
+#define LN_BWD16_NV(SV) do { if (nv <= 1) LN_BWD16(1, SV); else if (nv <= 2) LN_BWD16(2, SV); else if (nv <= 4) LN_BWD16(4, SV); else LN_BWD16(8, SV); } while (0)
+  if (stream16) {
+    DISPATCH_H16(precision, { if (stream16 == 1) LN_BWD16_NV(1); else if (stream16 == 2) LN_BWD16_NV(2); else LN_BWD16_NV(3); });
+  } else if (act == 0 && nv == 4) {
     DISPATCH_T(precision, LN_BWD0(4));
   } else {
     DISPATCH_T(precision, if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 4) LN_BWD(4); else LN_BWD(8));
   }
+#undef LN_BWD16_NV
+#undef LN_BWD16
 #undef LN_BWD0
 #undef LN_BWD
   TIM_CHECK_LAUNCH();

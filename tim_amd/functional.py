@@ -86,6 +86,12 @@ class Runtime:
         # the fp16 maximum for gradients that grow along the backward chain (LayerNorm's 1/std) and 2^-18 of the largest
         # cotangent before values go subnormal
         self.grad_scale_target = 16.0
+        # fp16: the residual part of the backward's gradient stream between LayerNorms as 16-bit under the gradient scale (default;
+        # TIM_AMD_GRAD_STREAM=fp32 keeps it fp32: +40 MB per LayerNorm-backward launch at C2a, gradients ~2x closer to the oracle's)
+        gsel = os.environ.get("TIM_AMD_GRAD_STREAM", "16")
+        if gsel not in ("16", "fp32"):
+            raise ValueError("TIM_AMD_GRAD_STREAM=%r: expected 16 or fp32" % gsel)
+        self.grad_stream16 = gsel == "16"
         self._gs_blocks = []   # this runtime's timhip_grad_scale blocks since the last grads_finite() (word 4 = non-finite flag)
         self._gs_captured = []  # ... and the blocks of captured (HIP-graph) backward passes
         self._nf_acc = None
@@ -915,6 +921,11 @@ class EncoderFn(torch.autograd.Function):
         # (plain bf16 would round that part to 8 bits per layer: there the layer returns one complete fp32 gradient instead)
         split_stream = Lyr > 1 and rt.prec != L.PREC_BF16
         dxa = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(2)] if split_stream else [None, None]
+        # fp16 (round 4): the residual part travels 16-bit as well, under the same gradient scale (TIMHIP_DESC_STREAM16*): the
+        # stack's entry (dx_init) and exit (layer 0 -> assemble_bwd) stay fp32.  TIM_AMD_GRAD_STREAM=fp32 keeps the fp32 stream.
+        stream16 = split_stream and rt.prec == L.PREC_F16 and gs is not None and rt.grad_stream16
+        dxh = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(2)] if stream16 else [None, None]
+        base_flags = desc.reserved
         add_in = None     # 16-bit part of the gradient entering the current layer (None at the top of the stack)
         stack = model._stack_prefix
         main = torch.cuda.current_stream()
@@ -938,6 +949,16 @@ class EncoderFn(torch.autograd.Function):
         defer_ln = rt.bucket_hook is None and os.environ.get("TIM_AMD_NO_DEFER_LN", "0") != "1"   # (env: A/B switch)
         ln_part_bytes = lib.timhip_layer_ln_partial_bytes(C.byref(desc)) if defer_ln else 0
         ln_part = torch.empty(Lyr * ln_part_bytes, dtype=torch.uint8, device=dev) if defer_ln else None
+        def _stream16_io(l):
+            """(gradient entering layer l, gradient leaving it) and the layer's stream flags: fp32 `dx` / `dx2` at the two ends of
+            the stack, the 16-bit ping-pong pair in between"""
+            if not stream16:
+                desc.reserved = base_flags
+                return dx, dx2
+            top, bottom = l == Lyr - 1, l == 0
+            desc.reserved = base_flags | L.DESC_STREAM16 | (0 if top else L.DESC_STREAM16_IN) | (0 if bottom else L.DESC_STREAM16_OUT)
+            return (dx if top else dxh[(l + 1) & 1]), (dx2 if bottom else dxh[l & 1])
+
         for l in reversed(range(Lyr)):
             pre = "%s.layers.%d." % (stack, l)
             lg = L.TimLayerGrads(*[ptr(G[pre + n]) for n in model._LAYER_GRAD_NAMES])
@@ -949,8 +970,9 @@ class EncoderFn(torch.autograd.Function):
                 if l + 2 in done:
                     main.wait_event(done[l + 2])  # the weight gradients of layer l+2 no longer read this dy
                 add_out = dxa[l & 1] if l > 0 else None
+                s_in, s_out = _stream16_io(l)
                 call("timhip_layer_bwd_data_split", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.layer_saved[l]),
-                     ptr(dx), ptr(add_in), ptr(dx2), ptr(add_out), ptr(dyb), C.byref(lg), ptr(ws), dws_bytes, main.cuda_stream)
+                     ptr(s_in), ptr(add_in), ptr(s_out), ptr(add_out), ptr(dyb), C.byref(lg), ptr(ws), dws_bytes, main.cuda_stream)
                 add_in = add_out
                 ev = torch.cuda.Event()
                 ev.record(main)
@@ -964,8 +986,9 @@ class EncoderFn(torch.autograd.Function):
                 grads.done("layer%d" % l, ready=dn)
             else:
                 add_out = dxa[l & 1] if l > 0 else None
+                s_in, s_out = _stream16_io(l)
                 call("timhip_layer_bwd_split", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.xs_t[l]),
-                     ptr(ctx.layer_saved[l]), ptr(dx), ptr(add_in), ptr(dx2), ptr(add_out), C.byref(lg), ptr(ws), ws_bytes, st)
+                     ptr(ctx.layer_saved[l]), ptr(s_in), ptr(add_in), ptr(s_out), ptr(add_out), C.byref(lg), ptr(ws), ws_bytes, st)
                 add_in = add_out
                 grads.done("layer%d" % l)
             dx, dx2 = dx2, dx
