@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 3
+#define TIMHIP_VERSION 4   /* 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
 
 enum {
   TIMHIP_OK = 0,

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TIM_AMD_LIB") or os.path.join(_HERE, "libtimhip.so")   # (TIM_AMD_LIB: an A/B build of the library, tools only)
 
+ABI_VERSION = 4   # include/timhip.h: TIMHIP_VERSION
 PREC_BF16, PREC_BF16X3, PREC_FP32, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32, "fp16": PREC_F16}
 H16 = (PREC_BF16, PREC_F16)   # 16-bit operand storage (the MFMA GEMM / attention / transposing weight-gradient kernels)
@@ -168,6 +169,10 @@ def load():
         raise TimHipError("libtimhip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (make -C tim_amd/csrc). There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.timhip_version.restype = C.c_int
+    if lib.timhip_version() != ABI_VERSION:   # (a stale A/B build would read this binding's buffers with yesterday's layout)
+        raise TimHipError("%s is ABI version %d, this binding speaks %d: rebuild it (make -C tim_amd/csrc%s)"
+                          % (LIB_PATH, lib.timhip_version(), ABI_VERSION, " TUNING=1" if "tuning" in LIB_PATH else ""))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
