@@ -297,13 +297,14 @@ class Runtime:
             return (self.seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
         return (self.seed * 0x9E3779B97F4A7C15 + self.step * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
-    def grad_scale(self, cotangents, dev):
+    def grad_scale(self, cotangents, dev, out=None):
         """fp16 only: device tensor {S, 1/S, 0, 0} for one backward pass (None in the other modes), S chosen on the device
         from the largest |cotangent| - no host synchronisation."""
         if self.prec != L.PREC_F16:
             return None
         dev = torch.device(dev)
-        gs = torch.zeros(8, dtype=torch.float32, device=dev)   # {S, 1/S, scratch, scratch, non-finite flag, 0, 0, 0}
+        # {S, 1/S, scratch, scratch, non-finite flag, 0, 0, 0}; `out`: a block the caller has already zero-filled
+        gs = out if out is not None else torch.zeros(8, dtype=torch.float32, device=dev)
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             # a block of a captured step lives as long as the graph and is rewritten by every replay: watched for good
             self._gs_captured.append(gs)
@@ -496,12 +497,13 @@ class TimeMlpFn(torch.autograd.Function):
         R, d = u3.shape
         ldd = _ru(d)
         g = _f32c(d_te).reshape(R, d)
-        gs = rt.grad_scale([g], dev)
-        gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
-        # the eight (accumulated-into) gradient tensors as views of ONE zero-filled buffer
+        # the eight (accumulated-into) gradient tensors as views of ONE zero-filled buffer; its last 8 words are the
+        # gradient-scale block of the fp16 mode (one fill launch for both)
         shapes = [(d, 2), (d,), (d, d), (d,), (d, d), (d,), (d,), (d,)]
         sizes = [(int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        flat = torch.zeros(sum(sizes) + 8, dtype=torch.float32, device=dev)
+        gs = rt.grad_scale([g], dev, out=flat[sum(sizes):])
+        gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
         views, off = [], 0
         for sh, n in zip(shapes, sizes):
             views.append(flat[off:off + int(torch.Size(sh).numel())].view(sh))
@@ -816,7 +818,13 @@ class EncoderFn(torch.autograd.Function):
         # gradient buckets: one flat fp32 buffer per bucket, parameters are views into it
         # bf16: the layers' Linear gradients are written, not accumulated -> their buckets are not zero-filled (nor read)
         overwrite = rt.h16
-        grads = model._alloc_grad_buckets(names, params, dev, layer_overwrite=overwrite)
+        # every buffer of this pass that has to start at zero goes out in ONE multi-tensor launch with the buckets' fills: the
+        # cls / modality gradient sums (atomics accumulate into them) and the gradient-scale block of the fp16 mode
+        ncls, nmod = len(plan.cls_names), len(plan.mod_names)
+        cm = torch.empty(max(ncls, 1) * d + max(nmod, 1) * E, dtype=torch.float32, device=dev)
+        gs_block = torch.empty(8, dtype=torch.float32, device=dev) if rt.prec == L.PREC_F16 else None
+        grads = model._alloc_grad_buckets(names, params, dev, layer_overwrite=overwrite,
+                                          extra_zero=[cm] + ([gs_block] if gs_block is not None else []))
         G = grads.views
 
         # gradient stream of the last layer's output: the feature rows start as the incoming `feats` cotangent (a copy, not a
@@ -826,7 +834,7 @@ class EncoderFn(torch.autograd.Function):
         xL_t = ctx.xs_t[Lyr]
         # fp16: scale of the gradient operands for this pass, from the cotangents that enter it (device side, no sync).  The
         # fp32 stream dx and every parameter gradient stay true-scale; only fp16 tensors carry the factor.
-        gs = rt.grad_scale([_f32c(v) for v in gouts if v is not None], dev)
+        gs = rt.grad_scale([_f32c(v) for v in gouts if v is not None], dev, out=gs_block)
         gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
         if rt.split:   # the forward fed the heads from the fp32 rows: gather their fp16 copies for the weight gradients
             hranges, hs2 = [], []
@@ -1006,11 +1014,10 @@ class EncoderFn(torch.autograd.Function):
         del ln_part
 
         # ---- sequence assembly backward
-        ncls, nmod = len(plan.cls_names), len(plan.mod_names)
         d_e = [None, None]
         for name, slot, *_ in ctx.emb_saved:
             d_e[slot] = torch.empty((B * nf, d), dtype=torch.float32, device=dev)
-        cm = torch.zeros(max(ncls, 1) * d + max(nmod, 1) * E, dtype=torch.float32, device=dev)   # atomics accumulate into both
+        # (cm: zero-filled with the gradient buckets at the top of the pass - atomics accumulate into both halves)
         d_cls = cm[:max(ncls, 1) * d].view(max(ncls, 1), d)
         d_mod = cm[max(ncls, 1) * d:].view(max(nmod, 1), E)
         d_te = torch.empty((B, T, d), dtype=torch.float32, device=dev)   # written in full by the kernel

@@ -175,7 +175,7 @@ class _AVGAParams(nn.Module):
 
 
 class _GradBuckets:
-    def __init__(self, rt, names, params, dev, bucket_of, layer_overwrite=False):
+    def __init__(self, rt, names, params, dev, bucket_of, layer_overwrite=False, extra_zero=()):
         """layer_overwrite: the encoder layers' Linear weight/bias gradients are written by the kernels
         (TIMHIP_DESC_WGRAD_OVERWRITE); their buckets are left uninitialised except the LayerNorm slices,
         which the kernels accumulate into."""
@@ -203,10 +203,11 @@ class _GradBuckets:
         # zero fills: whole buckets the kernels accumulate into (heads, front end), and of the overwritten layer buckets only
         # the pieces nobody writes (alignment tails) or that are accumulated into (LayerNorm slices) - ONE multi-tensor launch
         # for all the small pieces (they used to be a fill launch per layer)
-        accumulated = []
+        # (`extra_zero`: other small buffers of the same backward pass that must start at zero - they ride in the same launch)
+        accumulated = list(extra_zero)
         for b in self.order:
             if not (layer_overwrite and b.startswith("layer")):
-                self.flat[b].zero_()
+                accumulated.append(self.flat[b])
             elif self.flat[b].numel() > sizes[b]:
                 accumulated.append(self.flat[b][sizes[b]:])
         off = {b: 0 for b in sizes}
@@ -398,8 +399,8 @@ class TIM(nn.Module):
             return "front"
         return "heads"
 
-    def _alloc_grad_buckets(self, names, params, dev, layer_overwrite=False):
-        return _GradBuckets(self.rt, names, params, dev, self._bucket_of, layer_overwrite)
+    def _alloc_grad_buckets(self, names, params, dev, layer_overwrite=False, extra_zero=()):
+        return _GradBuckets(self.rt, names, params, dev, self._bucket_of, layer_overwrite, extra_zero)
 
     # ---- the reference's public interface ------------------------------------------------------------
     def forward_encoder(self, inputs, time_encodings, num_v_queries, num_a_queries):
