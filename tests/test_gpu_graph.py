@@ -270,3 +270,21 @@ def test_nonfinite_watch_follows_the_replays(salt_off):
     assert model.rt.grads_finite()
     fn()                                           # an eager pass in between
     assert model.rt.grads_finite()
+    # a graph whose LAST replay overflowed is dropped: its blocks must not keep reporting that overflow (round-4 advisor
+    # finding: `if rt.grads_finite(): opt.step()` would skip every step after a re-capture)
+    R[0].fill_(float("inf"))
+    gs()
+    assert not model.rt.grads_finite()
+    for r, g in zip(R, good):
+        r.copy_(g)
+    gs.reset()
+    del gs
+    assert model.rt.grads_finite()
+    fn()
+    assert model.rt.grads_finite()
+    gs2 = GraphedStep(model, fn)                   # a re-capture is watched again
+    gs2()
+    assert model.rt.grads_finite()
+    R[0].fill_(float("inf"))
+    gs2()
+    assert not model.rt.grads_finite()

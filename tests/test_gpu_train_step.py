@@ -129,3 +129,19 @@ def test_fp16_nonfinite_gradient_flag():
         for _ in range(12):
             assert step()
         assert not model.rt.grads_finite()
+        # ... and neither is the pass whose block TRIGGERS the fold (round-4 advisor finding: the fold used to read the new
+        # block's flag before that pass's kernels had been issued, and dropped it): each step appends two blocks (time MLP +
+        # encoder), so after 8 healthy steps the list holds 16 and the overflowing step's first append folds
+        assert step() and model.rt.grads_finite()
+        assert step()
+        per_step = len(model.rt._gs_blocks)       # blocks one step appends (one per backward pass: time MLP, encoder, ...)
+        assert 1 <= per_step <= 4
+        while len(model.rt._gs_blocks) < 16 - (per_step - 1):
+            assert step()
+        assert len(model.rt._gs_blocks) <= 16     # no fold yet: the next step's appends reach the limit
+        model.rt.grad_scale_target = 2.0 ** 60
+        assert not step()
+        model.rt.grad_scale_target = target
+        assert len(model.rt._gs_blocks) <= per_step   # the fold ran inside that step ...
+        assert not model.rt.grads_finite()        # ... and the step's own flag survived it
+        assert step() and model.rt.grads_finite()

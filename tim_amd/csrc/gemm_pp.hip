@@ -1307,7 +1307,8 @@ bool tim_gemm_pp_wins(int M, int N, int K, int splitk) {
   if (splitk != 1 || N < 512 || M < 1280) return false;
   const long long tiles = (long long)((M + 159) / 160) * ((N + PP_BN - 1) / PP_BN);
   const long long rounds = (tiles + 255) / 256;
-  return tiles >= 192 && tiles * 100 >= rounds * 256 * 75;   // the last round at least three quarters full on average
+  if (tiles < 256) return tiles >= tim_knobs().gemm_pp_min;   // (TIMHIP_GEMM_PP_MIN_TILES: half-batch chains run 124-tile launches side by side)
+  return tiles * 100 >= rounds * 256 * 75;   // the last round at least three quarters full on average
 }
 
 // Shapes for the dual-group persistent kernel: whole 160 x 256 tile pairs, at least two contraction steps, an even spread of the

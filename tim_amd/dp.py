@@ -175,24 +175,34 @@ class DataParallel(nn.Module):
         through the very code path the step uses; an exception or a wrong mean on any rank is ANDed again.  After that
         `_exchange` has no fallback: an error in a step's exchange propagates (out of memory included) - the job stops
         instead of diverging."""
+        W = self.world
+        n = 64 * W + 24                      # not a multiple of 8 W: the staged (padded) form; 64 W alone = the zero-copy form
         try:
             ok = bool(self._preflight())
+            if ok:
+                # everything the probe allocates is allocated HERE, before the first collective: a rank-local failure (out of
+                # memory included) is then ANDed across the group like any other refusal instead of leaving the peers inside
+                # a collective this rank never enters
+                self._staging(n, dev)
+                self._staging(64 * W, dev, recv_only=self.wire_dtype == torch.float32)
         except Exception as e:  # noqa: BLE001  (a preflight that raises is a refusal, with the reason kept for the warning)
             ok, self._why = False, "preflight: %s" % str(e)[:200]
         if not self._agree(ok, dev):
+            self._stage.clear()
             return "allreduce"
-        W = self.world
-        n = 64 * W + 24                      # not a multiple of 8 W: the staged (padded) form; 64 W alone = the zero-copy form
         ok = True
         try:
             for numel in (n, 64 * W):
-                probe = torch.arange(numel, dtype=torch.float32, device=dev) * (self.rank + 1)
+                # bounded values (at most 63 on every rank, whatever W): exact on a 16-bit wire too - an unbounded ramp
+                # overflowed fp16 from W = 32 on and sent the group to all_reduce with a misleading "wrong mean"
+                ramp = (torch.arange(numel, dtype=torch.float32, device=dev) % 64.0)
+                probe = ramp * ((self.rank + 1) / float(W))
                 self._exchange_a2a(probe, W, numel)
-                want = torch.arange(numel, dtype=torch.float32, device=dev) * ((W + 1) / 2.0)
+                want = ramp * ((W + 1) / (2.0 * W))
                 tol = 0.0 if self.wire_dtype == torch.float32 else 2.0 ** -7
-                if not bool(((probe - want).abs() <= tol * want.abs() + 1e-6).all()):
+                if not bool(((probe - want).abs() <= tol * want.abs() + 1e-4).all()):   # (fp32: a few ulps of 63 when W does not divide)
                     ok, self._why = False, "probe exchange returned a wrong mean"
-        except RuntimeError as e:            # raised on every rank alike (a backend without the collective)
+        except Exception as e:  # noqa: BLE001  (any failure of this rank's probe is a refusal the group hears about)
             ok, self._why = False, "probe exchange: %s" % str(e)[:200]
         self._stage.clear()
         self.bytes_on_wire = 0

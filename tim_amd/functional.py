@@ -93,7 +93,8 @@ class Runtime:
             raise ValueError("TIM_AMD_GRAD_STREAM=%r: expected 16 or fp32" % gsel)
         self.grad_stream16 = gsel == "16"
         self._gs_blocks = []   # this runtime's timhip_grad_scale blocks since the last grads_finite() (word 4 = non-finite flag)
-        self._gs_captured = []  # ... and the blocks of captured (HIP-graph) backward passes
+        self._gs_captured = []  # ... and the blocks of captured (HIP-graph) backward passes nobody owns yet (strong references)
+        self._gs_adopted = []   # ... weak references to the blocks a GraphedStep owns (adopt_captured)
         self._nf_acc = None
         self._wcache = {}
         self._wparams = {}  # id(param) -> weakref: every weight this runtime has cast
@@ -309,9 +310,11 @@ class Runtime:
             # a block of a captured step lives as long as the graph and is rewritten by every replay: watched for good
             self._gs_captured.append(gs)
         else:
+            # many backward passes without a reader: fold the OLDER blocks on the device (no sync) BEFORE this pass's block joins
+            # the list - its flag word is still zero here (its kernels are issued below), folding it would lose the pass's flag
+            if len(self._gs_blocks) >= 16:
+                self._fold_flags(captured=False)
             self._gs_blocks.append(gs)
-            if len(self._gs_blocks) > 16:
-                self._fold_flags()           # (many backward passes without a reader: fold on the device, no sync)
         cots = [c for c in cotangents if c is not None and c.numel() > 0]
         if not cots:
             gs[:2] = 1.0
@@ -322,14 +325,34 @@ class Runtime:
                  float(self.grad_scale_target), ptr(gs), _stream())
         return gs
 
-    def _fold_flags(self):
+    def _fold_flags(self, captured=True):
         if self._gs_blocks:
             f = torch.stack([g[4] for g in self._gs_blocks]).view(torch.int32).ne(0).any()
             self._nf_acc = f if self._nf_acc is None else (self._nf_acc | f)
             self._gs_blocks = []
-        if self._gs_captured:   # (not consumed: the next replay zeroes and rewrites them)
-            f = torch.stack([g[4] for g in self._gs_captured]).view(torch.int32).ne(0).any()
-            self._nf_acc = f if self._nf_acc is None else (self._nf_acc | f)
+        if captured:   # (not consumed: the next replay zeroes and rewrites them)
+            self._gs_adopted = [r for r in self._gs_adopted if r() is not None]   # blocks of dropped graphs: no longer watched
+            live = list(self._gs_captured) + [r() for r in self._gs_adopted]
+            live = [g for g in live if g is not None]
+            if live:
+                f = torch.stack([g[4] for g in live]).view(torch.int32).ne(0).any()
+                self._nf_acc = f if self._nf_acc is None else (self._nf_acc | f)
+
+    def adopt_captured(self, since=0):
+        """Hand the gradient-scale blocks of the backward passes captured so far (from list position `since`) to the caller (`GraphedStep` after its
+        capture): the runtime keeps WEAK references from here on, so the blocks - and the watch on their non-finite flags -
+        end with the object that owns the graph.  Blocks nobody adopts (a bare `torch.cuda.graph` capture) stay watched until
+        `forget_captured()`."""
+        blocks, self._gs_captured = self._gs_captured[since:], self._gs_captured[:since]
+        self._gs_adopted += [weakref.ref(b) for b in blocks]
+        return blocks
+
+    def forget_captured(self):
+        """Stop watching the blocks of every captured backward pass (a graph was dropped or is about to be re-captured: its
+        last replay may have left a flag set that nothing rewrites any more - watched for good it would make every later
+        grads_finite() False and a `if rt.grads_finite(): opt.step()` loop skip every step)."""
+        self._gs_captured = []
+        self._gs_adopted = []
 
     def grads_finite(self, reset=True):
         """False iff a weight / bias gradient written since the last call (by this runtime's backward passes) was inf or nan -

@@ -56,14 +56,24 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        n_before = len(self.rt._gs_captured)   # (blocks of an earlier bare capture stay with the runtime)
         self.graph = torch.cuda.CUDAGraph()
         self.rt.invalidate_weights()  # the cast of every weight is part of the captured step
         with torch.cuda.graph(self.graph):
             self.out = fn()
+        # the gradient-scale blocks (non-finite flags) of the captured backward passes live and die with this object
+        self._gs_blocks = self.rt.adopt_captured(since=n_before)
         # the gradient tensors the captured backward writes: re-attached on every replay, so eager steps in between (which
         # may re-allocate .grad) do not detach the parameters from the graph's results
         self._grads = [(p, p.grad) for p in inner.parameters() if p.grad is not None]
         self.replays = 0
+
+    def reset(self):
+        """Drop the captured graph (before a re-capture with new shapes, or when the loop goes back to eager steps): its
+        gradient-scale blocks are no longer watched by `Runtime.grads_finite()`."""
+        self._gs_blocks = []
+        self.graph = None
+        self._grads = []
 
     def __call__(self):
         self.graph.replay()
