@@ -341,10 +341,15 @@ def test_c2a_production_batch_train_mode_fp16():
     print("C2a B=64 fp16 TRAIN mode: worst |dlogit| %.3g over %d logits; gradients min cos %.6f, max rel err %.3g" % (worst, n, wc, wr))
 
 
-@pytest.mark.parametrize("key,step", [(1, 7), (20260930, 1234), (0x5EED5EED5EED, 99991)])
+_DRAWS = [(1, 7), (20260930, 1234), (0x5EED5EED5EED, 99991), (2, 1), (3, 100), (17, 4242), (99, 31337), (123456789, 5),
+          (0xC0FFEE, 77), (0xBADC0DE, 2025), (31415926, 8), (27182818, 65536)]
+_DRAW_ERRS = {}
+
+
+@pytest.mark.parametrize("key,step", _DRAWS)
 def test_c2a_production_batch_train_mode_fp16_other_draws(key, step):
     """the 1e-3 claim as a statement about the DISTRIBUTION of draws, not one pinned key: the same B = 64 training forward
-    under three unrelated (model key, step) pairs - different masks at every site - each against the fp32 oracle under ITS
+    under twelve unrelated (model key, step) pairs - different masks at every site - each against the fp32 oracle under ITS
     masks.  Forward only (the gradients' agreement does not depend on the draw: see the pinned case above)."""
     cfg = named_config("C2a")
     B, nv, na = 64, 15, 10
@@ -364,6 +369,11 @@ def test_c2a_production_batch_train_mode_fp16_other_draws(key, step):
     errs = {k: maxerr(outs[k], o[k]) for k in outs if k != "feats"}
     print("C2a B=64 fp16 TRAIN mode, key %d step %d (seed %d): worst |dlogit| %.3g  %s"
           % (key, step, seed, max(errs.values()), {k: "%.2e" % v for k, v in errs.items()}))
+    _DRAW_ERRS[(key, step)] = max(errs.values())
+    if len(_DRAW_ERRS) == len(_DRAWS):   # the tail of the distribution in one line (round-4 review: four draws say little)
+        v = sorted(_DRAW_ERRS.values())
+        print("C2a B=64 fp16 TRAIN mode, %d draws: max |dlogit| min %.3g median %.3g MAX %.3g (bound 1e-3)"
+              % (len(v), v[0], v[len(v) // 2], v[-1]))
     assert max(errs.values()) <= 1e-3, errs
 
 
