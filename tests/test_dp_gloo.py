@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, bpe=3):
+def _worker(rank, world, port, q, bpe=3, coll=None):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -35,7 +35,8 @@ def _worker(rank, world, port, q, bpe=3):
         cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
         m = TIM(cfg.num_class, visual_input_dim=24, audio_input_dim=40, d_model=32, nhead=2, num_layers=2, num_feats=6)
         before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
-        dp = DataParallel(m, buckets_per_exchange=bpe)
+        dp = DataParallel(m, buckets_per_exchange=bpe, collective=coll)
+        assert dp.collective == (coll or "a2a"), (dp.collective, dp._why)
         assert dp.wire_dtype == torch.float32          # the default is the reference's exact fp32 mean
         assert dp.world == world and dp.active and m.rt.bucket_hook is not None
         names = m._encoder_param_names
@@ -73,27 +74,30 @@ def _worker(rank, world, port, q, bpe=3):
         x = torch.randn(100003, generator=g) * 1e-3
         exact = x.clone()
         allreduce_buckets_reference([exact], world)
-        dp.wire_dtype = torch.bfloat16
+        dp.wire_dtype = torch.bfloat16 if coll is None else torch.float32   # (fp32 accumulation of a 16-bit wire: the a2a form only)
         dp._stage.clear()
         got = x.clone()
         dp._exchange(got)
         # two roundings to bf16 (each rank's contribution, then the mean): 2^-8 relative to the larger of the two
-        assert (got - exact).abs().max().item() <= 2.0 ** -8 * x.abs().max().item() * 1.01
-        assert (got - exact).abs().mean().item() <= 2.0 ** -9 * x.abs().mean().item()
+        if coll is None:
+            assert (got - exact).abs().max().item() <= 2.0 ** -8 * x.abs().max().item() * 1.01
+            assert (got - exact).abs().mean().item() <= 2.0 ** -9 * x.abs().mean().item()
+        else:
+            assert torch.allclose(got, exact, rtol=1e-6, atol=1e-9)
         both = got.clone()
         dist.broadcast(both, 0)
         assert torch.equal(both, got)          # every rank ends with the SAME gradients (all-gather of the reduced shards)
         assert dp.bytes_on_wire > 0
         # the plain fp32 all-reduce path (what the group falls back to TOGETHER, test_collective_choice_is_collective)
-        assert dp.collective == "a2a"
+        assert dp.collective == (coll or "a2a")
         dp.collective = "allreduce"       # (every rank of this test alike)
         z = x.clone()
         dp._exchange(z)
         assert torch.allclose(z, exact, rtol=1e-6, atol=1e-9)
-        dp.collective = "a2a"
+        dp.collective = coll or "a2a"
         # odd lengths that W does not divide, both wire formats, against the exact mean (staging path with padded chunks)
         for n_odd in (1, 7, 100003, 64 * 5):
-            for wd in (torch.float32, torch.bfloat16):
+            for wd in ((torch.float32, torch.bfloat16) if coll is None else (torch.float32,)):
                 dp.wire_dtype = wd
                 dp._stage.clear()
                 xo = torch.randn(n_odd, generator=g) * 1e-3
@@ -197,8 +201,11 @@ def _choice_worker(rank, world, port, q, mode):
             DP.dist.all_to_all_single = counted
         with warnings.catch_warnings(record=True) as wrn:
             warnings.simplefilter("always")
-            dp = DP.DataParallel(m)
-        want = "a2a" if mode == "step_error" else "allreduce"
+            # "rs_on_gloo": the reduce-scatter + all-gather form (the default over RCCL) asked for explicitly - gloo carries it too;
+            # "mixed": the ranks ask for different forms and land on all_reduce together
+            kw = {"collective": "rs_ag"} if mode == "rs_on_gloo" else ({"collective": ("a2a", "rs_ag")[rank]} if mode == "mixed" else {})
+            dp = DP.DataParallel(m, **kw)
+        want = "a2a" if mode == "step_error" else ("rs_ag" if mode == "rs_on_gloo" else "allreduce")
         assert dp.collective == want, dp.collective
         agreed = torch.tensor([1.0 if dp.collective == "allreduce" else 0.0])
         lo, hi = agreed.clone(), agreed.clone()
@@ -207,7 +214,7 @@ def _choice_worker(rank, world, port, q, mode):
         assert lo.item() == hi.item()                      # THE SAME decision on every rank
         if mode in ("preflight", "env"):
             assert not a2a_calls                           # nobody issued an all-to-all a peer would not join
-        if mode != "env" and mode != "step_error" and rank == 0:
+        if mode not in ("env", "step_error", "rs_on_gloo") and rank == 0:
             assert any("agreed on plain all_reduce" in str(w.message) for w in wrn)
         if mode == "wrong" and rank == 1:
             DP.DataParallel._reduce_chunks = orig
@@ -236,7 +243,7 @@ def _choice_worker(rank, world, port, q, mode):
         q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize("mode", ["preflight", "env", "raise", "wrong", "step_error"])
+@pytest.mark.parametrize("mode", ["preflight", "env", "raise", "wrong", "step_error", "rs_on_gloo", "mixed"])
 def test_collective_choice_is_collective(mode):
     """tim_amd/dp.py:_choose_collective - the all-to-all -> all-reduce fallback is decided once, by the whole group: a refusal,
     an exception or a wrong probe result on ONE rank moves EVERY rank to all_reduce before a step runs; after construction
@@ -255,13 +262,14 @@ def test_collective_choice_is_collective(mode):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
-@pytest.mark.parametrize("world,bpe", [(2, 3), (3, 1), (4, 4)])
-def test_gradient_buckets_gloo(world, bpe):
-    """world sizes 2, 3 (divides no bucket: padded chunks) and 4; one bucket per exchange, three, and all four as one range"""
+@pytest.mark.parametrize("world,bpe,coll", [(2, 3, None), (3, 1, None), (4, 4, None), (2, 2, "rs_ag"), (3, 4, "rs_ag")])
+def test_gradient_buckets_gloo(world, bpe, coll):
+    """world sizes 2, 3 (divides no bucket: padded chunks) and 4; one bucket per exchange, three, and all four as one range; the
+    all-to-all form (gloo's default here) and the reduce-scatter + all-gather form (the default over RCCL)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, bpe)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, bpe, coll)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

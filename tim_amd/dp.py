@@ -46,8 +46,13 @@ from torch import nn
 
 class DataParallel(nn.Module):
     def __init__(self, module, process_group=None, wire_dtype=torch.float32, broadcast_parameters=True, force=False,
-                 buckets_per_exchange=4):
-        """force: run the exchange even in a one-rank group (every collective is then a copy) - the single-GPU
+                 buckets_per_exchange=4, collective=None):
+        """collective: "rs_ag" (reduce-scatter + all-gather, RCCL sums in fp32 on the way: the default for an fp32 wire on the
+        nccl / RCCL backend, and the form a HIP graph can carry), "a2a" (all-to-all + local fp32 sum + all-gather: the only form
+        that accumulates a 16-bit wire in fp32; default for 16-bit wires and for backends without reduce_scatter_tensor),
+        "allreduce" (one fp32 all-reduce per range), or None = the environment's TIM_AMD_DP_COLLECTIVE, else the default.  The
+        group probes the preferred form together at construction and falls back to "allreduce" together.
+        force: run the exchange even in a one-rank group (every collective is then a copy) - the single-GPU
         test of how the side-stream work interferes with the backward uses it.
         buckets_per_exchange: consecutive gradient buckets (contiguous in memory, tim.py:_GradBuckets) travel as one range.
         Every exchange is ~5 enqueues on the comm stream and the host is close to being the bottleneck of the step (330
@@ -74,7 +79,8 @@ class DataParallel(nn.Module):
         self.buckets_per_exchange = max(1, int(buckets_per_exchange))
         self._pending = []         # buckets completed but not yet exchanged: (flat, ready)
         self._accumulating = False  # a backward pass ran under no_sync() since the last exchange
-        self.collective = "a2a"     # or "allreduce": agreed by the whole group in _choose_collective, never changed afterwards
+        self._want = collective     # None: environment, then the default for the wire dtype / backend (_preferred)
+        self.collective = "a2a"     # "rs_ag" | "a2a" | "allreduce": agreed by the whole group in _choose_collective, never changed afterwards
         self._why = ""
         rt = module.rt
         rt.bucket_hook = self._on_bucket
@@ -88,10 +94,10 @@ class DataParallel(nn.Module):
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._on_small_grad))
             dev = next(module.parameters()).device
             self.collective = self._choose_collective(dev)
-            if self.collective != "a2a" and self.rank == 0 and os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") != "allreduce":
+            if self.collective == "allreduce" and self.rank == 0 and self._preferred() != "allreduce":
                 import warnings
                 warnings.warn("tim_amd.dp: the group agreed on plain all_reduce for the gradient exchange (%s)"
-                              % (self._why or "a peer refused the all-to-all path"))
+                              % (self._why or "a peer refused the %s path" % self._preferred()))
             if broadcast_parameters:
                 self.broadcast_parameters()
 
@@ -121,8 +127,10 @@ class DataParallel(nn.Module):
             self.sync = old
 
     # ---- the exchange of one flat fp32 bucket -------------------------------------------------------
-    def _staging(self, n, dev, recv_only=False):
-        key = (n, dev, recv_only)
+    def _staging(self, n, dev, recv_only=False, rs=False):
+        """buffers of one range size, reused every step.  a2a: recv [W x per] (+ send, the padded / narrowed copy, unless the
+        collectives run on the bucket itself: recv_only), shard [per], acc [per];  rs: shard [per] (+ send unless recv_only)"""
+        key = (n, dev, recv_only, rs)
         st = self._stage.get(key)
         if st is None:
             W = self.world
@@ -130,9 +138,9 @@ class DataParallel(nn.Module):
             per = (per + 7) // 8 * 8                       # 16-byte chunks on the wire
             st = {"per": per,
                   "send": None if recv_only else torch.zeros(per * W, dtype=self.wire_dtype, device=dev),   # padding stays zero
-                  "recv": torch.empty(per * W, dtype=self.wire_dtype, device=dev),
+                  "recv": None if rs else torch.empty(per * W, dtype=self.wire_dtype, device=dev),
                   "shard": torch.empty(per, dtype=self.wire_dtype, device=dev),
-                  "acc": torch.empty(per, dtype=torch.float32, device=dev)}
+                  "acc": None if rs else torch.empty(per, dtype=torch.float32, device=dev)}
             self._stage[key] = st
         return st
 
@@ -148,13 +156,33 @@ class DataParallel(nn.Module):
             st["shard"].copy_(st["acc"])
 
     # ---- which collective: decided ONCE, by every rank together ------------------------------------
+    def _preferred(self):
+        """the exchange form this rank would like: constructor argument, else TIM_AMD_DP_COLLECTIVE, else by wire dtype and
+        backend (fp32 over RCCL: reduce-scatter + all-gather; a 16-bit wire, or a backend without reduce_scatter_tensor such as
+        gloo: all-to-all + local fp32 sum + all-gather)"""
+        want = self._want or os.environ.get("TIM_AMD_DP_COLLECTIVE")
+        if want:
+            if want not in ("rs_ag", "a2a", "allreduce"):
+                raise ValueError("collective / TIM_AMD_DP_COLLECTIVE = %r: expected rs_ag, a2a or allreduce" % (want,))
+            return want
+        try:
+            backend = str(dist.get_backend(self.pg))
+        except Exception:  # noqa: BLE001
+            backend = ""
+        return "rs_ag" if (self.wire_dtype == torch.float32 and "nccl" in backend) else "a2a"
+
     def _preflight(self):
-        """Everything about the all-to-all path that can fail on THIS rank without entering a collective: the A/B switch
-        in the environment, the two collectives' presence in this torch build, the wire dtype.  Raises or returns False for
+        """Everything about the preferred path that can fail on THIS rank without entering a collective: the A/B switch
+        in the environment, the collectives' presence in this torch build, the wire dtype.  Raises or returns False for
         'not here'; tests replace it on one rank to force a rank-asymmetric refusal."""
-        if os.environ.get("TIM_AMD_DP_COLLECTIVE", "a2a") == "allreduce":
+        want = self._preferred()
+        if want == "allreduce":
             return False
-        if not (hasattr(dist, "all_to_all_single") and hasattr(dist, "all_gather_into_tensor")):
+        if not hasattr(dist, "all_gather_into_tensor"):
+            return False
+        if want == "rs_ag":
+            return hasattr(dist, "reduce_scatter_tensor") and self.wire_dtype == torch.float32
+        if not hasattr(dist, "all_to_all_single"):
             return False
         return self.wire_dtype in (torch.float32, torch.bfloat16, torch.float16)
 
@@ -177,47 +205,93 @@ class DataParallel(nn.Module):
         instead of diverging."""
         W = self.world
         n = 64 * W + 24                      # not a multiple of 8 W: the staged (padded) form; 64 W alone = the zero-copy form
+        want = "allreduce"
         try:
+            want = self._preferred()
             ok = bool(self._preflight())
             if ok:
                 # everything the probe allocates is allocated HERE, before the first collective: a rank-local failure (out of
                 # memory included) is then ANDed across the group like any other refusal instead of leaving the peers inside
                 # a collective this rank never enters
-                self._staging(n, dev)
-                self._staging(64 * W, dev, recv_only=self.wire_dtype == torch.float32)
+                rs = want == "rs_ag"
+                self._staging(n, dev, rs=rs)
+                self._staging(64 * W, dev, recv_only=self.wire_dtype == torch.float32, rs=rs)
         except Exception as e:  # noqa: BLE001  (a preflight that raises is a refusal, with the reason kept for the warning)
             ok, self._why = False, "preflight: %s" % str(e)[:200]
-        if not self._agree(ok, dev):
+        # ranks that prefer DIFFERENT forms (an environment variable set on one of them) must not probe different collectives
+        # against each other: the group agrees on one code (MIN over ranks: allreduce 0 < a2a 1 < rs_ag 2), everybody who
+        # wanted something else counts as a refusal
+        code = {"allreduce": 0.0, "a2a": 1.0, "rs_ag": 2.0}[want if ok else "allreduce"]
+        flag = torch.tensor([code], dtype=torch.float32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        low = int(round(flag.item()))
+        if low == 0 or low != int(code):
+            # somebody refused, or the ranks want different forms: one more agreement so that EVERY rank leaves here (the
+            # ranks whose code equals the minimum cannot know whether all of them did)
+            self._agree(False, dev)
             self._stage.clear()
+            if not self._why and low != int(code):
+                self._why = "the ranks prefer different exchange forms"
+            return "allreduce"
+        if not self._agree(True, dev):
+            self._stage.clear()
+            if not self._why:
+                self._why = "the ranks prefer different exchange forms"
             return "allreduce"
         ok = True
+        self.collective = want               # (the probe runs through the very code path the step uses)
         try:
             for numel in (n, 64 * W):
                 # bounded values (at most 63 on every rank, whatever W): exact on a 16-bit wire too - an unbounded ramp
                 # overflowed fp16 from W = 32 on and sent the group to all_reduce with a misleading "wrong mean"
                 ramp = (torch.arange(numel, dtype=torch.float32, device=dev) % 64.0)
                 probe = ramp * ((self.rank + 1) / float(W))
-                self._exchange_a2a(probe, W, numel)
-                want = ramp * ((W + 1) / (2.0 * W))
+                self._exchange(probe)
+                want_v = ramp * ((W + 1) / (2.0 * W))
                 tol = 0.0 if self.wire_dtype == torch.float32 else 2.0 ** -7
-                if not bool(((probe - want).abs() <= tol * want.abs() + 1e-4).all()):   # (fp32: a few ulps of 63 when W does not divide)
+                if not bool(((probe - want_v).abs() <= tol * want_v.abs() + 1e-4).all()):   # (fp32: a few ulps of 63 when W does not divide)
                     ok, self._why = False, "probe exchange returned a wrong mean"
         except Exception as e:  # noqa: BLE001  (any failure of this rank's probe is a refusal the group hears about)
             ok, self._why = False, "probe exchange: %s" % str(e)[:200]
         self._stage.clear()
         self.bytes_on_wire = 0
-        return "a2a" if self._agree(ok, dev) else "allreduce"
+        return want if self._agree(ok, dev) else "allreduce"
 
     def _exchange(self, flat):
-        """flat (fp32, 1-D) <- mean over ranks: all-to-all + fp32 sum + all-gather on `wire_dtype`, or - when the group
-        agreed so at construction (`self.collective`) - one fp32 all-reduce.  No per-rank fallback (see _choose_collective)."""
+        """flat (fp32, 1-D) <- mean over ranks, by the form the group agreed on at construction (`self.collective`):
+        reduce-scatter + all-gather, all-to-all + fp32 sum + all-gather on `wire_dtype`, or one fp32 all-reduce.  No per-rank
+        fallback (see _choose_collective)."""
         W, n = self.world, flat.numel()
         if self.collective == "allreduce":
             dist.all_reduce(flat, group=self.pg)
             flat.mul_(1.0 / W)
             self.bytes_on_wire += 2 * 2 * (n // W) * (W - 1) * 4
             return
+        if self.collective == "rs_ag":
+            return self._exchange_rs(flat, W, n)
         return self._exchange_a2a(flat, W, n)
+
+    def _exchange_rs(self, flat, W, n):
+        """reduce-scatter (RCCL adds the W contributions of chunk r in fp32 on their way to rank r) + all-gather of the W
+        means: SURVEY 8e's pattern as two library collectives - no receive buffer, no local sum pass, and (unlike the
+        send / receive pairs behind all_to_all_single, which hang or crash hipStreamEndCapture on this stack:
+        profiles/r05_rccl_capture_probe.txt) capturable in a HIP graph."""
+        if self.wire_dtype == torch.float32 and n % (8 * W) == 0 and flat.is_contiguous():
+            per = n // W
+            st = self._staging(n, flat.device, recv_only=True, rs=True)
+            dist.reduce_scatter_tensor(st["shard"], flat, group=self.pg)
+            st["shard"].mul_(1.0 / W)
+            dist.all_gather_into_tensor(flat, st["shard"], group=self.pg)
+            self.bytes_on_wire += 2 * 2 * per * (W - 1) * 4
+            return
+        st = self._staging(n, flat.device, rs=True)
+        per = st["per"]
+        st["send"][:n].copy_(flat)
+        dist.reduce_scatter_tensor(st["shard"], st["send"], group=self.pg)
+        st["shard"].mul_(1.0 / W)
+        dist.all_gather_into_tensor(st["send"], st["shard"], group=self.pg)
+        flat.copy_(st["send"][:n])
+        self.bytes_on_wire += 2 * 2 * per * (W - 1) * st["send"].element_size()   # (a 16-bit wire is summed in 16 bits here: use a2a for that)
 
     def _exchange_a2a(self, flat, W, n):
         if self.wire_dtype == torch.float32 and n % (8 * W) == 0 and flat.is_contiguous():

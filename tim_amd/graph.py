@@ -7,7 +7,9 @@ module captures one full step (time MLP, encoder forward, loss, backward and opt
 
 What makes the HIP path capturable:
   * every `timhip_*` launch goes to torch's current stream (the capture stream); the weight-gradient side stream forks from
-    and joins back into it with events, which capture as graph edges;
+    and joins back into it with events, which capture as graph edges; so does the data-parallel wrapper's comm stream, whose
+    reduce-scatter / all-gather collectives RCCL records as graph nodes (tim_amd/dp.py, collective "rs_ag": tested on a
+    one-rank RCCL group, tools/dp_graph_check.py);
   * workspaces / saved activations come from torch's allocator, so they land in the graph's private pool;
   * dropout seeds are launch arguments, which a graph would freeze - `functional.graph_safe_dropout` moves the per-step part
     of the seed into a device word that a node of the graph advances (include/timhip.h: timhip_dropout_salt);
@@ -42,6 +44,12 @@ class GraphedStep:
 
     def __init__(self, model, fn, warmup=3):
         inner = model.module if hasattr(model, "module") else model
+        if getattr(model, "active", False) and getattr(model, "collective", None) == "a2a":
+            # all_to_all_single is send / receive pairs underneath; captured, they hang or crash hipStreamEndCapture on this
+            # stack (ROCm 7.0 / RCCL 2.26, profiles/r05_rccl_capture_probe.txt) - a segmentation fault, not an exception
+            raise RuntimeError("GraphedStep: the data-parallel wrapper exchanges its buckets with all_to_all_single, which cannot be "
+                               "captured in a HIP graph on this stack; construct tim_amd.dp.DataParallel with collective='rs_ag' "
+                               "(the default for an fp32 wire over RCCL) or run the step eagerly")
         self.rt = inner.rt
         inner._ws_pinned = True   # the graph keeps raw pointers into the model's workspaces: they are retired, never freed
         dev = next(inner.parameters()).device

@@ -1,7 +1,7 @@
 """The data-parallel step as a HIP graph, on what one GPU can show (round 5; VERDICT r4 "next" #3).
 
 A 1-rank RCCL group with the exchange forced on (`DataParallel(force=True)`): every gradient bucket goes through the comm-stream
-all-to-all -> fp32 sum -> all-gather sequence (copies on one rank).  This tool
+reduce-scatter -> all-gather sequence (copies on one rank).  This tool
   (a) captures that step - RCCL collectives on the comm stream included - with `tim_amd.graph.GraphedStep` and checks that a
       replay's gradients equal the eager data-parallel step's (same dropout salt);
   (b) measures what the wrapper costs on one GPU before a byte crosses a link, eager and replayed, for
@@ -53,7 +53,7 @@ def main():
     # ---- (a) replay == eager for the data-parallel step
     model = fresh()
     dp = DataParallel(model, force=True, buckets_per_exchange=2)
-    assert dp.active and dp.world == 1 and dp.collective == "a2a", (dp.active, dp.world, dp.collective, dp._why)
+    assert dp.active and dp.world == 1 and dp.collective == "rs_ag", (dp.active, dp.world, dp.collective, dp._why)
     R = [None]
     fn = lambda: bench.step_fn(dp, batch, nv, na, R)   # noqa: E731
     fn()
@@ -117,25 +117,28 @@ def main():
     g_plain, _ = median_ms(gp, warm=10)
     print("PLAIN   eager %.3f ms (host issue %.3f)   replay %.3f ms" % (e_plain, i_plain, g_plain), flush=True)
     del gp
-    for wire in (torch.float32, torch.bfloat16):
+    for coll, wire in (("rs_ag", torch.float32), ("a2a", torch.float32), ("a2a", torch.bfloat16), ("allreduce", torch.float32)):
         for bpe in (1, 2, 4, 99):
             m = fresh()
-            w = DataParallel(m, force=True, buckets_per_exchange=bpe, wire_dtype=wire)
+            w = DataParallel(m, force=True, buckets_per_exchange=bpe, wire_dtype=wire, collective=coll)
+            assert w.collective == coll, (w.collective, w._why)
             Rw = [None]
             fw = lambda: bench.step_fn(w, batch, nv, na, Rw)   # noqa: E731
             e_ms, i_ms = median_ms(fw)
             w.begin_step_timing()
             fw()
             comm_ms, nbytes = w.end_step_timing()
-            try:
-                gw = GraphedStep(w, fw)
-                g_ms, _ = median_ms(gw, warm=10)
-                del gw
-                g_txt = "replay %.3f ms (+%.3f)" % (g_ms, g_ms - g_plain)
-            except Exception as e:  # noqa: BLE001
-                g_txt = "replay: capture failed (%s)" % str(e).replace("\n", " | ")[:200]
-            print("DP wire=%s buckets_per_exchange=%s   eager %.3f ms (+%.3f; host issue %.3f)   %s   comm stream busy %.3f ms"
-                  % ("fp32" if wire == torch.float32 else "bf16", "all" if bpe == 99 else bpe, e_ms, e_ms - e_plain, i_ms, g_txt,
+            g_txt = "replay: not capturable (send / receive pairs)"
+            if coll != "a2a":
+                try:
+                    gw = GraphedStep(w, fw)
+                    g_ms, _ = median_ms(gw, warm=10)
+                    del gw
+                    g_txt = "replay %.3f ms (+%.3f)" % (g_ms, g_ms - g_plain)
+                except Exception as e:  # noqa: BLE001
+                    g_txt = "replay: capture failed (%s)" % str(e).replace("\n", " | ")[:200]
+            print("DP %-9s wire=%s buckets_per_exchange=%-3s  eager %.3f ms (+%.3f; host issue %.3f)   %s   comm stream busy %.3f ms"
+                  % (coll, "fp32" if wire == torch.float32 else "bf16", "all" if bpe == 99 else bpe, e_ms, e_ms - e_plain, i_ms, g_txt,
                      comm_ms), flush=True)
             m.rt.bucket_hook = None
             m.rt.finish_hook = None
