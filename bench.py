@@ -464,9 +464,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TIM_AMD_BENCH_FORCE_DP=1 (tests/test_gpu_bench_ranks.py): the data-parallel code path of this file on ONE rank - a one-rank
+    # RCCL group with the exchange forced on (every collective a copy).  Not a measurement mode either.
+    force_dp = world == 1 and os.environ.get("TIM_AMD_BENCH_FORCE_DP", "0") == "1"
+    dp_on = world > 1 or force_dp
+    if dp_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dp:
+            os.environ.setdefault("MASTER_PORT", "29517")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -481,17 +487,17 @@ def main():
     model, sd_np = build_model(cfg, args.precision, dev, seed=0)
     model.train(not detection or args.det_train)   # C4 without --det-train: inference form with gradients (no GT targets needed)
     run_model = model
-    if world > 1:
+    if dp_on:
         from tim_amd.dp import DataParallel
         # fp32 on the wire = the exact mean the reference's DistributedDataParallel computes (the default of tim_amd.dp);
-        # TIM_AMD_DP_WIRE=bf16 selects the half-traffic exchange (bf16 payload, fp32 accumulation)
+        # TIM_AMD_DP_WIRE=bf16 selects the half-traffic exchange (bf16 payload, fp32 accumulation, all-to-all form: eager only)
         wire = torch.bfloat16 if os.environ.get("TIM_AMD_DP_WIRE", "fp32") == "bf16" else torch.float32
-        run_model = DataParallel(model, wire_dtype=wire)
+        run_model = DataParallel(model, wire_dtype=wire, force=force_dp)
     batch = make_batch(cfg, B, 0 if detection else nv, na, seed=100 + rank, dev=dev)  # each rank its own shard of windows
     R = {"target": make_det_targets(cfg, B, 6, 5 + rank, dev)} if (detection and args.det_train) else [None]
 
     def barrier():
-        if world > 1:
+        if dp_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -525,10 +531,18 @@ def main():
     mode = args.step_mode
     if args.no_graph and mode == "auto":
         mode = "eager"
+    # The data-parallel step is captured too when its exchange is capturable: reduce-scatter + all-gather (or all-reduce) over RCCL
+    # (tim_amd/dp.py "rs_ag": the default for the fp32 wire; all_to_all_single's send / receive pairs hang or crash
+    # hipStreamEndCapture on this stack - profiles/r05_rccl_capture_probe.txt).  A capture is LOCAL (collectives are recorded, not
+    # run), so a rank whose capture fails cannot strand its peers; the ranks then agree (MIN over a flag) whether EVERYBODY
+    # replays or everybody issues eagerly.  TIM_AMD_BENCH_DP_GRAPH=0: eager data-parallel steps.
+    dp_capturable = dp_on and not share and getattr(run_model, "collective", "a2a") in ("rs_ag", "allreduce") \
+        and os.environ.get("TIM_AMD_BENCH_DP_GRAPH", "1") != "0"
     if mode == "auto":
-        mode = "graph" if world == 1 else "eager"
-    if mode == "graph" and world > 1:
-        raise SystemExit("--step-mode graph is a single-GPU mode (the data-parallel step issues RCCL collectives on a side stream)")
+        mode = "graph" if (not dp_on or dp_capturable) else "eager"
+    if mode == "graph" and dp_on and not dp_capturable:
+        raise SystemExit("--step-mode graph: this data-parallel exchange cannot be captured (collective %r over %s)"
+                         % (getattr(run_model, "collective", None), "gloo" if share else "RCCL"))
     eager = None
     live = None
     if mode == "graph":
@@ -562,10 +576,18 @@ def main():
     if mode == "graph":
         try:
             from tim_amd.graph import GraphedStep
-            gstep = GraphedStep(model, lambda: step_fn(run_model, batch, nv, na, R))
+            gstep = GraphedStep(run_model, lambda: step_fn(run_model, batch, nv, na, R))
         except Exception as e:  # noqa: BLE001  (a runtime that refuses the capture: the eager steps are timed, and the line says so)
             gstep, mode = None, "eager"
             graph_note = "HIP-graph capture failed (%s: %s): eager steps timed" % (type(e).__name__, str(e)[:160])
+        if dp_on:   # everybody replays, or nobody does
+            import torch.distributed as dist
+            okf = torch.tensor([1.0 if gstep is not None else 0.0], device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if okf.item() < 0.5 and gstep is not None:
+                gstep.reset()
+                gstep, mode = None, "eager"
+                graph_note = "HIP-graph capture failed on another rank: eager steps timed"
     run_step = gstep if gstep is not None else (lambda: step_fn(run_model, batch, nv, na, R))
     for _ in range(args.warmup):
         run_step()
@@ -582,7 +604,7 @@ def main():
     t_enqueue = time.perf_counter() - t0   # host time to ISSUE the K steps (the GPU may still be running them)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp_on:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -594,19 +616,36 @@ def main():
         L.call("timhip_gemm_timing_stop", C.byref(ms_), C.byref(fl_), C.byref(n_))
         live = (ms_.value, fl_.value, n_.value)
     comm = None
-    if world > 1:
+    if dp_on:
         # what the gradient exchange costs the step: (a) the same steps with the exchange switched off (every rank, same
-        # barriers) -> exposed time = difference; (b) one step with events on the comm stream -> its busy time and bus rate
+        # barriers; replays of a second captured graph when the timed steps were replays) -> exposed time = difference;
+        # (b) one eager step with events on the comm stream -> its busy time and bus rate
         import torch.distributed as dist
         nx = max(3, min(10, args.steps))
         with run_model.no_sync():
-            step_fn(run_model, batch, nv, na, R)
+            ns_step = lambda: step_fn(run_model, batch, nv, na, R)   # noqa: E731
+            if gstep is not None:
+                try:
+                    from tim_amd.graph import GraphedStep
+                    ns_step = GraphedStep(run_model, lambda: step_fn(run_model, batch, nv, na, R))
+                except Exception:  # noqa: BLE001
+                    pass
+                okf = torch.tensor([1.0 if not callable(getattr(ns_step, "reset", None)) else 2.0], device=dev)
+                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                if okf.item() < 1.5 and callable(getattr(ns_step, "reset", None)):   # (somebody's capture failed: eager everywhere)
+                    ns_step.reset()
+                    ns_step = lambda: step_fn(run_model, batch, nv, na, R)   # noqa: E731
+            ns_step()
             barrier()
             tx0 = time.perf_counter()
             for _ in range(nx):
-                step_fn(run_model, batch, nv, na, R)
+                ns_step()
             barrier()
             t = torch.tensor([time.perf_counter() - tx0], device=dev, dtype=torch.float64)
+            ns_graph = callable(getattr(ns_step, "reset", None))
+            if ns_graph:
+                ns_step.reset()
+            del ns_step
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_nosync = t.item() / nx * 1e3
         if not share:
@@ -616,17 +655,22 @@ def main():
         else:
             comm_ms, wire_bytes = None, None
         barrier()
-        comm = {"ms_per_step_without_exchange": round(ms_nosync, 3),
+        forms = {"rs_ag": "reduce-scatter + all-gather per range of gradient buckets (RCCL sums in fp32 on the way)",
+                 "a2a": "all-to-all + local fp32 sum + all-gather per range of gradient buckets",
+                 "allreduce": "one fp32 all-reduce per range of gradient buckets"}
+        comm = {"collective": run_model.collective,
+                "ms_per_step_without_exchange": round(ms_nosync, 3),
+                "without_exchange_timed_as": "hip_graph_replay" if ns_graph else "eager",
                 "exposed_comm_ms": round(dt / args.steps * 1e3 - ms_nosync, 3),
                 "comm_stream_busy_ms": None if comm_ms is None else round(comm_ms, 3),
                 "bytes_sent_plus_received_per_rank": wire_bytes,
                 "bus_GBps_per_rank": None if not comm_ms else round(wire_bytes / comm_ms / 1e6, 1),
                 "wire_dtype": str(run_model.wire_dtype).replace("torch.", ""),
-                "note": "all-to-all + local fp32 sum + all-gather per range of gradient buckets on a side stream (tim_amd/dp.py): "
-                        "fp32 payload by default (exact mean, collectives run on the bucket itself), TIM_AMD_DP_WIRE=bf16 halves "
-                        "the traffic; xGMI peak 7 links x ~153 GB/s per GPU"}
+                "note": forms.get(run_model.collective, run_model.collective) + ", on a side stream under the backward "
+                        "(tim_amd/dp.py); fp32 payload by default (the exact mean, collectives run on the bucket itself), "
+                        "TIM_AMD_DP_WIRE=bf16 halves the traffic (all-to-all form); xGMI peak 7 links x ~153 GB/s per GPU"}
     live_serial = None
-    if live and world == 1 and not args.no_extra_step:
+    if live and not dp_on and not args.no_extra_step:
         # the same measurement on one extra (untimed) step in the other stream configuration (weight gradients on a side
         # stream when the timed steps ran single-stream, and vice versa).  Single-GPU runs only: a step of the data-parallel
         # model contains collectives, and the other ranks are past their last step.
@@ -643,7 +687,7 @@ def main():
     value = queries_per_step * args.steps / dt
     # forward-only rate (SURVEY 8d asks for it beside the fwd+bwd metric): same batch, train-mode dropout, no autograd graph
     fwd_ms = None
-    if rank == 0 and world == 1 and not detection and not args.no_extra_step:
+    if rank == 0 and not dp_on and not detection and not args.no_extra_step:
         with torch.no_grad():
             for _ in range(3):
                 te_ = model(batch["times"], "time_mlp")
@@ -672,6 +716,8 @@ def main():
                    "global_batch": world * B, "parallelism": "dp%d" % world, "precision": args.precision},
     }
     out["windows_per_s"] = round(world * B * args.steps / dt, 1)
+    if force_dp:
+        out["forced_one_rank_dp"] = "TIM_AMD_BENCH_FORCE_DP=1: the data-parallel path on a one-rank RCCL group (every collective a copy) - a test mode, not a measurement"
     if eager is not None:
         out["eager"] = eager
     if comm is not None:
@@ -740,7 +786,7 @@ def main():
     # `value`, which stays the eager number so that the roofline events above sit inside the timed region.  Measured in a CHILD
     # process (`--graph-child`): whatever a runtime does with a capture it dislikes - an exception, or a crash - the bench
     # line of this process is not at stake.
-    if rank == 0 and world == 1 and not args.no_graph and gstep is None:
+    if rank == 0 and not dp_on and not args.no_graph and gstep is None:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--workload", args.workload, "--batch", str(B),
                "--precision", args.precision, "--steps", str(args.steps), "--warmup", str(args.warmup)]
@@ -750,7 +796,7 @@ def main():
             out["graph_replay"] = json.loads(line[-1]) if line else {"error": "child exited with %d" % r.returncode}
         except Exception as e:  # noqa: BLE001
             out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    if rank == 0 and world == 1 and not detection and not args.no_secondary:
+    if rank == 0 and not dp_on and not detection and not args.no_secondary:
         # (1) the accuracy the headline is bought with, measured here: the timed model against the fp32 CPU oracle
         try:
             err, nlog = logit_parity(model, cfg, sd_np, nv, na, dev)
@@ -792,11 +838,11 @@ def main():
                     out[key] = blk
                 except Exception as e:  # noqa: BLE001
                     out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not detection:
+    if rank == 0 and not dp_on and not args.no_cpu_baseline and not detection:
         out["cpu_baseline"] = cpu_baseline(cfg, sd_np, nv, na, args.workload)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dp_on:
         import torch.distributed as dist
         dist.barrier()       # rank 0 is the last to arrive (roofline loop): leave together
         dist.destroy_process_group()

@@ -7,26 +7,32 @@ backward produces one flat fp32 bucket per layer (plus a heads and a front-end b
 bucket is exchanged on a side stream the moment its layer's backward has been enqueued, so the
 exchange of layer l overlaps the backward of layers l-1..0.
 
-The exchange is shaped for xGMI, which is a full mesh of point-to-point links (7 x ~153 GB/s per
-GPU), not a switch: a ring all-reduce is bound by ONE link per hop, an all-to-all uses all seven
-at once.  So a bucket of N gradients travels as
+The exchange is SURVEY 8e's pattern - reduce-scatter, then all-gather - in one of three forms the
+whole group agrees on at construction (`collective`, `_choose_collective`):
 
-    1. cast to bf16                                  (N x 2 bytes instead of N x 4)
-    2. all-to-all: rank r receives chunk r of every rank's bucket     (reduce-scatter traffic pattern)
-    3. rank r sums its W chunks in FP32, scales by 1/W, rounds the mean to bf16
-    4. all-gather of the W reduced chunks
-    5. widen back into the fp32 bucket the optimizer reads
+    "rs_ag"      dist.reduce_scatter_tensor + dist.all_gather_into_tensor on the fp32 bucket itself: RCCL
+                 sums the W contributions of chunk r in fp32 on their way to rank r, the W means are
+                 gathered back into the bucket.  No receive buffer, no local sum pass.  THE DEFAULT for an
+                 fp32 wire over RCCL, and the form a HIP graph can carry: the data-parallel step - its
+                 collectives on the comm stream included - is captured by tim_amd.graph.GraphedStep and
+                 replayed (tested on a one-rank RCCL group: tests/test_gpu_dp.py, tools/dp_graph_check.py).
+    "a2a"        all-to-all (rank r receives chunk r of every rank's bucket), local fp32 sum
+                 (timhip_dp_reduce), all-gather.  xGMI is a full mesh of point-to-point links (7 x ~153 GB/s
+                 per GPU), an all-to-all drives all seven at once whatever ring RCCL would build; and it is
+                 the only form that accumulates a 16-bit wire in fp32 (`wire_dtype=torch.bfloat16`: 117
+                 instead of 233 MB per step and direction for C2a's 58.3 M parameters, each contribution and
+                 the mean rounded to 8 mantissa bits - a change in training numerics the caller has to
+                 want).  Default for 16-bit wires and for backends other than RCCL.  EAGER ONLY:
+                 all_to_all_single is send / receive pairs underneath, and captured they hang or crash
+                 hipStreamEndCapture on this stack (ROCm 7.0, RCCL 2.26: profiles/r05_rccl_capture_probe.txt).
+    "allreduce"  one fp32 all-reduce per range: what the group falls back to TOGETHER when a rank refuses
+                 the preferred form or the probe exchange fails anywhere.
 
-i.e. bf16 on the wire with fp32 accumulation (an all-reduce on bf16 tensors would accumulate in
-bf16 inside the collective).  117 MB per step per direction for the 58.3 M parameters of C2a
-instead of 233 MB.  THE DEFAULT IS `wire_dtype=torch.float32`: the exact fp32 mean, what the
-reference's DistributedDataParallel computes; then steps 1 and 5 do not exist and the collectives
-run on the gradient bucket itself (all-to-all out of it, all-gather into it: one local memory
-pass, the fp32 sum).  `wire_dtype=torch.bfloat16` is the opt-in bandwidth optimisation: each
-rank's contribution and the mean are rounded to 8 mantissa bits (2^-9 relative) before the
-optimizer sees them - a change in training numerics the caller has to want.  The few parameters
-outside the encoder Function (time MLP, DRLoc MLP: ~1.6 M) go through the same exchange as one
-more bucket when the backward finishes.
+`wire_dtype=torch.float32` (default) gives the exact fp32 mean, what the reference's
+DistributedDataParallel computes.  Which of "rs_ag" / "a2a" is faster on eight real GPUs is not known:
+no multi-GPU box has been available to this repo; TIM_AMD_DP_COLLECTIVE=a2a|rs_ag|
+allreduce switches without a code change.  The few parameters outside the encoder Function (time MLP,
+DRLoc MLP: ~1.6 M) go through the same exchange as one more bucket when the backward finishes.
 
 Gradient accumulation (`no_sync()`): passes inside the context leave their gradients in `p.grad`,
 un-exchanged.  The next synchronised pass folds those local sums into its buckets before the
@@ -55,13 +61,15 @@ class DataParallel(nn.Module):
         force: run the exchange even in a one-rank group (every collective is then a copy) - the single-GPU
         test of how the side-stream work interferes with the backward uses it.
         buckets_per_exchange: consecutive gradient buckets (contiguous in memory, tim.py:_GradBuckets) travel as one range.
-        Every exchange is ~5 enqueues on the comm stream and the host is close to being the bottleneck of the step (330
-        launches in ~6 ms), so nine separate exchanges cost the step 0.70 ms on one GPU (1-rank group: every
-        collective a copy) although their kernels run only 0.55 ms off the critical path; 2 / 3 / 4 per exchange: +0.49 /
-        0.47 / 0.43 ms with 0.39 / 0.34 / 0.32 ms of comm-stream kernel time; everything as ONE exchange at the end (no
-        overlap at all) +0.43 ms - the floor on one GPU is the exchange's own memory passes (narrow, sum, widen: ~0.8 GB)
-        plus the tail (the last range and the time-MLP parameters cannot overlap anything).  Measured with
-        tools/dp_single_gpu_check.py, C2a, B = 64, 5.65 ms step."""
+        What the wrapper costs on ONE GPU before a byte crosses a link (one-rank RCCL group, every collective a copy of the
+        whole range: ~0.9 GB of extra memory traffic per step beside the backward; C2a, B = 64, 5.22 ms plain step, round 5,
+        profiles/r05_dp_single_gpu_overhead.txt), eager / as a graph replay:
+            rs_ag      1: +0.57 / +0.51 ms   2: +0.40 / +0.46   4: +0.37 / +0.38   all: +0.48 / +0.32
+            a2a        1: +0.79              2: +0.51           4: +0.55           all: +0.61          (eager only)
+            allreduce  1: +0.35 / +0.38      2: +0.27 / +0.34   4: +0.22 / +0.22   all: +0.27 / +0.12  (in place on one rank)
+        i.e. every exchange costs launches on the comm stream and a join, fewer and larger ranges are cheaper until nothing is
+        left to overlap (eager "all": the tail is exposed; in a replay the host is out of the picture and "all" is cheapest
+        on one rank - on W ranks "all" has no overlap with the backward at all, so 4 stays the default)."""
         super().__init__()
         self.module = module
         self.pg = process_group

@@ -67,7 +67,18 @@ class GraphedStep:
         n_before = len(self.rt._gs_captured)   # (blocks of an earlier bare capture stay with the runtime)
         self.graph = torch.cuda.CUDAGraph()
         self.rt.invalidate_weights()  # the cast of every weight is part of the captured step
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, RCCL's watchdog thread polls the events of the warm-up steps' collectives while this thread
+        # captures; under the default (global) capture mode that hipEventQuery is an error on the OTHER thread ("operation not
+        # permitted when stream is capturing": the watchdog dies and takes the process with it - seen on a one-rank group,
+        # tools/dp_graph_check.py).  Thread-local mode checks the capturing thread only.
+        mode = "global"
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                mode = "thread_local"
+        except Exception:  # noqa: BLE001
+            pass
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.out = fn()
         # the gradient-scale blocks (non-finite flags) of the captured backward passes live and die with this object
         self._gs_blocks = self.rt.adopt_captured(since=n_before)
