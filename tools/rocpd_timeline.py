@@ -1,5 +1,5 @@
 """One step's kernel sequence (start offset, duration, gap to the previous kernel's end, short name, grid) from a rocprofv3
-rocpd database:  python tools/rocpd_timeline.py <results.db> <launches per step> [step index]"""
+rocpd database:  python tools/rocpd_timeline.py <results.db> <launches per step | 0 = find the period> [step index]"""
 import re, sqlite3, sys
 db = sys.argv[1]; per = int(sys.argv[2]); idx = int(sys.argv[3]) if len(sys.argv) > 3 else -2
 con = sqlite3.connect(db); cur = con.cursor()
@@ -12,6 +12,11 @@ name_col = "display_name" if "display_name" in scols else ("kernel_name" if "ker
 gx = "grid_size_x" if "grid_size_x" in dcols else "grid_x"
 wx = "workgroup_size_x" if "workgroup_size_x" in dcols else "workgroup_x"
 rows = cur.execute("select d.start, d.end, s.%s, d.%s, d.%s from %s d join %s s on d.kernel_id = s.id order by d.start" % (name_col, gx, wx, kd, ks)).fetchall()
+if per <= 0:   # find the step's period in the tail of the trace (the last launches are whole steps)
+    names = [r[2] for r in rows]
+    tail = names[-3000:] if len(names) > 3000 else names
+    per = next((p for p in range(20, len(tail) // 3) if all(tail[-1 - i] == tail[-1 - i - p] for i in range(2 * p))), 141)
+    rows = rows[len(rows) % per:]
 n = len(rows) // per
 if idx < 0: idx += n
 seg = rows[idx * per:(idx + 1) * per]
