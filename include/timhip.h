@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 4   /* 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
+#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
 
 enum {
   TIMHIP_OK = 0,
@@ -428,6 +428,17 @@ int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float*
                         int T, float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0,
                         float* d_e1, float* d_cls, float* d_te, float* d_mod, void* stream);
 
+/* The same with the CLS token vectors (ncls <= 8, [d] each) and the modality vectors (nmod <= 4, [2 d] each) given by pointer:
+ * host arrays of device pointers, 16-byte aligned - the separate nn.Parameters of encodings.py:29-35,158-175 as they lie (and, in
+ * the backward, their gradient views: accumulated into, zeroed by the caller).  Saves the two concatenations of a forward and
+ * the copy back of a backward. */
+int timhip_assemble_fwd_p(int precision, const TimSeqRow* rows, int B, int S, int d, const float* e0, const float* e1,
+                          int n_e_rows, const float* const* cls, int ncls, const float* te, int T, const float* const* mod,
+                          int nmod, float p_seq_drop, uint64_t seed, uint32_t site, float* x, void* x_T, void* stream);
+int timhip_assemble_bwd_p(const TimSeqRow* rows, int B, int S, int d, const float* dx, int n_e_rows, int T,
+                          float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0, float* d_e1, float* const* d_cls, int ncls,
+                          float* d_te, float* const* d_mod, int nmod, void* stream);
+
 /* ---- heads ------------------------------------------------------------------ */
 /* rows_T[B*n, E] (T) = x_T[b, s0 + i, :] for i < n : gathers the query rows a head reads */
 int timhip_gather_rows(int precision, const void* x_T, int B, int S, int E, int s0, int n,
@@ -445,6 +456,12 @@ int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, in
  * rows of the count <= 6 DISJOINT token ranges [s0[i], s0[i] + n[i]) (s0[i] >= F) <- d_rows[i][b*n[i] + j,:], every other row 0. */
 int timhip_dx_init(int B, int S, int F, int E, const float* feats_cot, int count, const int* s0, const int* n,
                    const float* const* d_rows, float* dx, void* stream);
+/* ... with range i given as nslab[i] (1 .. 16; NULL: 1 each) consecutive [B n[i], E] slabs at d_rows[i] that are added up on the
+ * way: the input-gradient product of a head with a long contraction (3806 action classes) runs as several column chunks of the
+ * contraction side by side, each into its own slab (tim_amd/functional.py: the 240 blocks of that product ran 60 contraction
+ * steps each while the other heads' blocks had finished after 2 - 5). */
+int timhip_dx_init_slabs(int B, int S, int F, int E, const float* feats_cot, int count, const int* s0, const int* n,
+                         const float* const* d_rows, const int* nslab, float* dx, void* stream);
 int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, const int* n,
                               const float* const* d_rows, float* dx, void* stream);
 int timhip_cast_rows_many(int precision, int count, const float* const* src, const int* rows, const int* cols,

@@ -688,3 +688,28 @@ def test_dx_init_writes_the_whole_stream():
     assert bad != 0
     bad = lib.timhip_dx_init(B, S, F, E, L.ptr(feats), 1, ia([F - 1]), ia([4]), pa(rows[:1]), L.ptr(dx), st())       # into the feature rows
     assert bad != 0
+
+
+def test_dx_init_adds_up_slabs():
+    """timhip_dx_init_slabs (round 5): a token range whose head rows arrive as several [B n, E] slabs - the column chunks of a
+    long-contraction input-gradient product - is the SUM of its slabs; ranges with one slab as before."""
+    B, S, F, E = 3, 23, 9, 64
+    g = torch.Generator().manual_seed(6)
+    feats = torch.randn(B, F, E, generator=g).to(DEV)
+    ranges = [(11, 4, 3), (18, 5, 1), (9, 2, 2)]
+    rows = [torch.randn(ns, B * n, E, generator=g).to(DEV) for _, n, ns in ranges]
+    want = torch.zeros(B, S, E, device=DEV)
+    want[:, :F] = feats
+    for (s0, n, ns), r in zip(ranges, rows):
+        acc = r[0].clone()
+        for z in range(1, ns):
+            acc += r[z]                                # the kernel's order of additions
+        want[:, s0:s0 + n] = acc.view(B, n, E)
+    dx = torch.full((B * S, E), float("nan"), device=DEV)
+    ia = lambda v: (C.c_int * len(v))(*v)
+    pa = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    L.call("timhip_dx_init_slabs", B, S, F, E, L.ptr(feats), 3, ia([r[0] for r in ranges]), ia([r[1] for r in ranges]), pa(rows),
+           ia([r[2] for r in ranges]), L.ptr(dx), st())
+    torch.cuda.synchronize()
+    assert torch.equal(dx.view(B, S, E), want)
+    assert L.load().timhip_dx_init_slabs(B, S, F, E, L.ptr(feats), 1, ia([11]), ia([4]), pa(rows[:1]), ia([0]), L.ptr(dx), st()) != 0

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TIM_AMD_LIB") or os.path.join(_HERE, "libtimhip.so")   # (TIM_AMD_LIB: an A/B build of the library, tools only)
 
-ABI_VERSION = 4   # include/timhip.h: TIMHIP_VERSION
+ABI_VERSION = 5   # include/timhip.h: TIMHIP_VERSION
 PREC_BF16, PREC_BF16X3, PREC_FP32, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32, "fp16": PREC_F16}
 H16 = (PREC_BF16, PREC_F16)   # 16-bit operand storage (the MFMA GEMM / attention / transposing weight-gradient kernels)
@@ -122,6 +122,8 @@ _SIGS = {
     "timhip_assemble_fwd": (C.c_int, [i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, f32, u64, u32,
                                       vp, vp, vp]),
     "timhip_assemble_bwd": (C.c_int, [vp, i32, i32, i32, vp, i32, i32, f32, u64, u32, vp, vp, vp, vp, vp, vp]),
+    "timhip_assemble_fwd_p": (C.c_int, [i32, vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, f32, u64, u32, vp, vp, vp]),
+    "timhip_assemble_bwd_p": (C.c_int, [vp, i32, i32, i32, vp, i32, i32, f32, u64, u32, vp, vp, vp, i32, vp, vp, i32, vp]),
     "timhip_gather_rows": (C.c_int, [i32, vp, i32, i32, i32, i32, i32, vp, vp]),
     "timhip_ce_mixup_fwd": (C.c_int, [vp, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp]),
     "timhip_ce_mixup_bwd": (C.c_int, [vp, i32, i32, i32, vp, vp, f32, f32, vp, vp, vp, vp, i32, vp]),
@@ -143,6 +145,7 @@ _SIGS = {
     "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "timhip_dx_init": (C.c_int, [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]),
+    "timhip_dx_init_slabs": (C.c_int, [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),
     "timhip_reload_env": (None, []),

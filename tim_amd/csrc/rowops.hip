@@ -683,20 +683,25 @@ __global__ __launch_bounds__(256) void time_l1_bwd_kernel(const float* __restric
 // ---------------------------------------------------------------------------
 // sequence assembly (encodings.py:190-250), batch-first, no transposes
 // ---------------------------------------------------------------------------
+// the CLS token vectors ([d] each) and modality vectors ([2 d] each) by pointer: they are separate parameters, and gathering
+// them into one buffer first cost two concatenation launches per forward (and a copy back per backward)
+constexpr int SV_CLS = 8, SV_MOD = 4;
+struct SeqVecs { const float* cls[SV_CLS]; const float* mod[SV_MOD]; };
+struct SeqVecGrads { float* cls[SV_CLS]; float* mod[SV_MOD]; };
 template <typename T>
 __global__ void assemble_fwd_kernel(const TimSeqRow* __restrict__ rows, int B, int S, int d,
                                     const float* __restrict__ e0, const float* __restrict__ e1, int n_e_rows,
-                                    const float* __restrict__ cls, const float* __restrict__ te, int Trows,
-                                    const float* __restrict__ mod, uint32_t thr, float scale, TimSeed seed,
+                                    SeqVecs sv, const float* __restrict__ te, int Trows,
+                                    uint32_t thr, float scale, TimSeed seed,
                                     uint32_t site, float* __restrict__ x, T* __restrict__ xt) {
   const int bs = blockIdx.x;  // b*S + s
   const int b = bs / S, s = bs % S;
   const TimSeqRow r = rows[s];
   const int E = 2 * d;
-  const float* left = r.kind == 1 ? cls + (size_t)r.src * d
+  const float* left = r.kind == 1 ? sv.cls[r.src & (SV_CLS - 1)]
                                   : (r.kind == 0 ? e0 : e1) + ((size_t)b * n_e_rows + r.src) * d;
   const float* right = te + ((size_t)b * Trows + r.te_row) * d;
-  const float* mv = r.mod >= 0 ? mod + (size_t)r.mod * E : nullptr;
+  const float* mv = r.mod >= 0 ? sv.mod[r.mod & (SV_MOD - 1)] : nullptr;
   for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
     float4 v = c < d ? *reinterpret_cast<const float4*>(left + c) : *reinterpret_cast<const float4*>(right + (c - d));
     if (mv) { const float4 m4 = *reinterpret_cast<const float4*>(mv + c); v.x += m4.x; v.y += m4.y; v.z += m4.z; v.w += m4.w; }
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __re
                                                            const float* __restrict__ dx, int n_e_rows, uint32_t thr,
                                                            float scale, TimSeed seed, uint32_t site,
                                                            float* __restrict__ d_e0, float* __restrict__ d_e1,
-                                                           float* __restrict__ d_cls, float* __restrict__ d_mod, int G) {
+                                                           SeqVecGrads sg, int G) {
   // A block walks G consecutive token rows and carries the modality / cls sums across rows that add into the same vector
   // (detection: 399 query rows share one cls vector and one modality vector - one atomic per row and column took 75 us at
   // S = 499, the adds being resolved one at a time at the memory side); the atomics go out when the target changes.
@@ -731,13 +736,15 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __re
     const int c = c0 + q * 4;
     float4 msum = make_float4(0.f, 0.f, 0.f, 0.f), csum = msum;
     int mtgt = -1, ctgt = -1;
-    auto flush = [&](float* base, int tgt, int width, float4& v) {
-      if (tgt >= 0 && base) {
-        float* p = base + (size_t)tgt * width + c;
+    auto flush = [&](float* vec, float4& v) {
+      if (vec) {
+        float* p = vec + c;
         atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
       }
       v = make_float4(0.f, 0.f, 0.f, 0.f);
     };
+    auto mvec = [&](int t) -> float* { return t >= 0 ? sg.mod[t & (SV_MOD - 1)] : nullptr; };
+    auto cvec = [&](int t) -> float* { return t >= 0 ? sg.cls[t & (SV_CLS - 1)] : nullptr; };
     for (int s = s_lo; s < s_hi; ++s) {
       const TimSeqRow r = rows[s];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -763,16 +770,16 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const TimSeqRow* __re
       if (rl == 0 && c < E) {
         const float4 a1 = red[1][q], a2 = red[2][q], a3 = red[3][q];
         acc.x += a1.x + a2.x + a3.x; acc.y += a1.y + a2.y + a3.y; acc.z += a1.z + a2.z + a3.z; acc.w += a1.w + a2.w + a3.w;
-        const int mt = (r.mod >= 0 && d_mod) ? r.mod : -1;
-        if (mt != mtgt) { flush(d_mod, mtgt, E, msum); mtgt = mt; }
+        const int mt = (r.mod >= 0 && mvec(r.mod)) ? r.mod : -1;
+        if (mt != mtgt) { flush(mvec(mtgt), msum); mtgt = mt; }
         if (mt >= 0) { msum.x += acc.x; msum.y += acc.y; msum.z += acc.z; msum.w += acc.w; }
-        const int ct = (c < d && r.kind == 1 && d_cls) ? r.src : -1;
-        if (ct != ctgt) { flush(d_cls, ctgt, d, csum); ctgt = ct; }
+        const int ct = (c < d && r.kind == 1 && cvec(r.src)) ? r.src : -1;
+        if (ct != ctgt) { flush(cvec(ctgt), csum); ctgt = ct; }
         if (ct >= 0) { csum.x += acc.x; csum.y += acc.y; csum.z += acc.z; csum.w += acc.w; }
       }
       __syncthreads();
     }
-    if (rl == 0 && c < E) { flush(d_mod, mtgt, E, msum); flush(d_cls, ctgt, d, csum); }
+    if (rl == 0 && c < E) { flush(mvec(mtgt), msum); flush(cvec(ctgt), csum); }
   }
 }
 
@@ -902,16 +909,26 @@ __global__ __launch_bounds__(256) void dx_init_kernel(int B, int S, int F, int E
                                                       float* __restrict__ dx, RowRanges rr) {
   const int b = blockIdx.x / S, s = blockIdx.x % S;
   const float* src = nullptr;
+  int nslab = 1;
+  size_t sstride = 0;
   if (s < F) {
     if (feats) src = feats + ((size_t)b * F + s) * E;
   } else {
 #pragma unroll
     for (int k = 0; k < RR_MAX; ++k)
-      if (k < rr.count && s >= rr.s0[k] && s < rr.s0[k] + rr.n[k]) src = (const float*)rr.src[k] + ((size_t)b * rr.n[k] + (s - rr.s0[k])) * E;
+      if (k < rr.count && s >= rr.s0[k] && s < rr.s0[k] + rr.n[k]) {
+        src = (const float*)rr.src[k] + ((size_t)b * rr.n[k] + (s - rr.s0[k])) * E;
+        nslab = rr.joff[k];                      // (dx_init: joff[k] = number of [B n, E] slabs of range k to add up, >= 1)
+        sstride = (size_t)B * rr.n[k] * E;
+      }
   }
   float* dst = dx + ((size_t)b * S + s) * E;
   for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
-    const float4 v = src ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = src ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 1; z < nslab; ++z) {
+      const float4 w = *reinterpret_cast<const float4*>(src + z * sstride + c);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
     *reinterpret_cast<float4*>(dst + c) = v;
   }
 }
@@ -1323,28 +1340,49 @@ int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const
   return TIMHIP_OK;
 }
 
-int timhip_assemble_fwd(int precision, const TimSeqRow* rows, int B, int S, int d, const float* e0, const float* e1,
-                        int n_e_rows, const float* cls, const float* te, int T_, const float* mod, float p_seq_drop,
-                        uint64_t seed, uint32_t site, float* x, void* x_T, void* stream) {
+static int assemble_fwd_launch(int precision, const TimSeqRow* rows, int B, int S, int d, const float* e0, const float* e1,
+                               int n_e_rows, const SeqVecs& sv, const float* te, int T_, float p_seq_drop, uint64_t seed,
+                               uint32_t site, float* x, void* x_T, void* stream) {
   if (!rows || !te || !x || !x_T || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
   const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
   const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
   DISPATCH_T(precision, hipLaunchKernelGGL(assemble_fwd_kernel<T>, dim3(B * S), dim3(256), 0, (hipStream_t)stream,
-                                           rows, B, S, d, e0, e1, n_e_rows, cls, te, T_, mod, thr, scale, seed, site, x,
+                                           rows, B, S, d, e0, e1, n_e_rows, sv, te, T_, thr, scale, seed, site, x,
                                            (T*)x_T));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
 
-int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float* dx, int n_e_rows, int T_,
-                        float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0, float* d_e1, float* d_cls,
-                        float* d_te, float* d_mod, void* stream) {
+int timhip_assemble_fwd(int precision, const TimSeqRow* rows, int B, int S, int d, const float* e0, const float* e1,
+                        int n_e_rows, const float* cls, const float* te, int T_, const float* mod, float p_seq_drop,
+                        uint64_t seed, uint32_t site, float* x, void* x_T, void* stream) {
+  SeqVecs sv;   // contiguous [ncls, d] / [nmod, 2 d] buffers: the table points into them
+  for (int i = 0; i < SV_CLS; ++i) sv.cls[i] = cls ? cls + (size_t)i * d : nullptr;
+  for (int i = 0; i < SV_MOD; ++i) sv.mod[i] = mod ? mod + (size_t)i * 2 * d : nullptr;
+  return assemble_fwd_launch(precision, rows, B, S, d, e0, e1, n_e_rows, sv, te, T_, p_seq_drop, seed, site, x, x_T, stream);
+}
+
+int timhip_assemble_fwd_p(int precision, const TimSeqRow* rows, int B, int S, int d, const float* e0, const float* e1,
+                          int n_e_rows, const float* const* cls, int ncls, const float* te, int T_, const float* const* mod,
+                          int nmod, float p_seq_drop, uint64_t seed, uint32_t site, float* x, void* x_T, void* stream) {
+  if (ncls < 0 || ncls > SV_CLS || nmod < 0 || nmod > SV_MOD || (ncls && !cls) || (nmod && !mod)) return TIMHIP_EINVAL;
+  SeqVecs sv;
+  for (int i = 0; i < SV_CLS; ++i) sv.cls[i] = i < ncls ? cls[i] : nullptr;
+  for (int i = 0; i < SV_MOD; ++i) sv.mod[i] = i < nmod ? mod[i] : nullptr;
+  for (int i = 0; i < ncls; ++i) if (!cls[i] || ((uintptr_t)cls[i] & 15)) return TIMHIP_EALIGN;
+  for (int i = 0; i < nmod; ++i) if (!mod[i] || ((uintptr_t)mod[i] & 15)) return TIMHIP_EALIGN;
+  return assemble_fwd_launch(precision, rows, B, S, d, e0, e1, n_e_rows, sv, te, T_, p_seq_drop, seed, site, x, x_T, stream);
+}
+
+static int assemble_bwd_launch(const TimSeqRow* rows, int B, int S, int d, const float* dx, int n_e_rows, int T_,
+                               float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0, float* d_e1, const SeqVecGrads& sg,
+                               float* d_te, void* stream) {
   if (!rows || !dx || B <= 0 || S <= 0 || d % 4) return TIMHIP_EINVAL;
   const uint32_t thr = p_seq_drop > 0.f ? drop_threshold(p_seq_drop) : 0u;
   const float scale = p_seq_drop > 0.f ? 1.f / (1.f - p_seq_drop) : 1.f;
   const int G = S >= 256 ? (S + 127) / 128 : 1;   // token rows per block: about 128 row groups, one atomic per group, vector and column
   hipLaunchKernelGGL(assemble_bwd_kernel, dim3((S + G - 1) / G, (2 * d + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, B, S, d, dx,
-                     n_e_rows, thr, scale, seed, site, d_e0, d_e1, d_cls, d_mod, G);
+                     n_e_rows, thr, scale, seed, site, d_e0, d_e1, sg, G);
   TIM_CHECK_LAUNCH();
   if (d_te) {
     hipLaunchKernelGGL(assemble_bwd_te_kernel, dim3(T_, B >= 32 ? 16 : (B >= 8 ? 4 : 1)), dim3(128), 0, (hipStream_t)stream, rows, B, S, d, dx, T_,
@@ -1352,6 +1390,25 @@ int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float*
     TIM_CHECK_LAUNCH();
   }
   return TIMHIP_OK;
+}
+
+int timhip_assemble_bwd(const TimSeqRow* rows, int B, int S, int d, const float* dx, int n_e_rows, int T_,
+                        float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0, float* d_e1, float* d_cls,
+                        float* d_te, float* d_mod, void* stream) {
+  SeqVecGrads sg;
+  for (int i = 0; i < SV_CLS; ++i) sg.cls[i] = d_cls ? d_cls + (size_t)i * d : nullptr;
+  for (int i = 0; i < SV_MOD; ++i) sg.mod[i] = d_mod ? d_mod + (size_t)i * 2 * d : nullptr;
+  return assemble_bwd_launch(rows, B, S, d, dx, n_e_rows, T_, p_seq_drop, seed, site, d_e0, d_e1, sg, d_te, stream);
+}
+
+int timhip_assemble_bwd_p(const TimSeqRow* rows, int B, int S, int d, const float* dx, int n_e_rows, int T_,
+                          float p_seq_drop, uint64_t seed, uint32_t site, float* d_e0, float* d_e1, float* const* d_cls, int ncls,
+                          float* d_te, float* const* d_mod, int nmod, void* stream) {
+  if (ncls < 0 || ncls > SV_CLS || nmod < 0 || nmod > SV_MOD || (ncls && !d_cls) || (nmod && !d_mod)) return TIMHIP_EINVAL;
+  SeqVecGrads sg;
+  for (int i = 0; i < SV_CLS; ++i) sg.cls[i] = i < ncls ? d_cls[i] : nullptr;
+  for (int i = 0; i < SV_MOD; ++i) sg.mod[i] = i < nmod ? d_mod[i] : nullptr;
+  return assemble_bwd_launch(rows, B, S, d, dx, n_e_rows, T_, p_seq_drop, seed, site, d_e0, d_e1, sg, d_te, stream);
 }
 
 int timhip_gather_rows(int precision, const void* x_T, int B, int S, int E, int s0, int n, void* rows_T, void* stream) {
@@ -1403,6 +1460,11 @@ int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, con
 
 int timhip_dx_init(int B, int S, int F, int E, const float* feats_cot, int count, const int* s0, const int* n,
                    const float* const* d_rows, float* dx, void* stream) {
+  return timhip_dx_init_slabs(B, S, F, E, feats_cot, count, s0, n, d_rows, nullptr, dx, stream);
+}
+
+int timhip_dx_init_slabs(int B, int S, int F, int E, const float* feats_cot, int count, const int* s0, const int* n,
+                         const float* const* d_rows, const int* nslab, float* dx, void* stream) {
   if (!dx || B <= 0 || S <= 0 || F < 0 || F > S || E % 4 || count < 0 || count > RR_MAX) return TIMHIP_EINVAL;
   RowRanges rr;
   rr.count = 0; rr.joff[0] = 0;
@@ -1414,6 +1476,8 @@ int timhip_dx_init(int B, int S, int F, int E, const float* feats_cot, int count
       for (int j = 0; j < i; ++j)
         if (s0[i] < s0[j] + n[j] && s0[j] < s0[i] + n[i]) return TIMHIP_EINVAL;   // overlapping ranges: the caller adds instead
       rr.s0[i] = s0[i]; rr.n[i] = n[i]; rr.src[i] = d_rows[i];
+      rr.joff[i] = nslab ? nslab[i] : 1;
+      if (rr.joff[i] < 1 || rr.joff[i] > 16) return TIMHIP_EINVAL;
     }
     rr.count = count;
   }

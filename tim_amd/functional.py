@@ -722,8 +722,9 @@ class EncoderFn(torch.autograd.Function):
             emb_saved[i] = (name, slot, xT, u, stats, Cin, site)
 
         # ---- sequence assembly (encodings.py:190-250)
-        cls = torch.cat([_f32c(P[fe + n]).reshape(1, d) for n in plan.cls_names], 0) if plan.cls_names else None
-        mod = torch.cat([_f32c(P[fe + n]).reshape(1, E) for n in plan.mod_names], 0) if plan.mod_names else None
+        # (the CLS token / modality vectors go to the kernel by pointer: separate parameters, no concatenation launches)
+        cls_v = [_f32c(P[fe + n]).reshape(-1) for n in plan.cls_names]
+        mod_v = [_f32c(P[fe + n]).reshape(-1) for n in plan.mod_names]
         # fp32 rows exist only at the two ends of the stack: the assembled input and the last layer's output (-> feats);
         # between layers every reader normalises the previous layer's pre-norm rows itself (timhip_layer_fwd_chained)
         xs_f = [None] * (Lyr + 1)
@@ -731,8 +732,8 @@ class EncoderFn(torch.autograd.Function):
         xs_f[Lyr] = torch.empty((M, E), dtype=torch.float32, device=dev)
         xs_t = [torch.empty((M, E), dtype=rt.op_dtype, device=dev) for _ in range(Lyr + 1)]
         tab = plan.table(dev)
-        call("timhip_assemble_fwd", rt.prec, ptr(tab), B, S, d, ptr(e_bufs[0]), ptr(e_bufs[1]), nf, ptr(cls),
-             ptr(te_c), T, ptr(mod), p_seq, seed, L.SITE_SEQ, ptr(xs_f[0]), ptr(xs_t[0]), st)
+        call("timhip_assemble_fwd_p", rt.prec, ptr(tab), B, S, d, ptr(e_bufs[0]), ptr(e_bufs[1]), nf, _parr(cls_v), len(cls_v),
+             ptr(te_c), T, _parr(mod_v), len(mod_v), p_seq, seed, L.SITE_SEQ, ptr(xs_f[0]), ptr(xs_t[0]), st)
 
         # ---- L post-norm encoder layers (transformers.py:44-45,92-111)
         desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, rt.layer_split_flags(E, FF), None)
@@ -845,12 +846,11 @@ class EncoderFn(torch.autograd.Function):
         # bf16: the layers' Linear gradients are written, not accumulated -> their buckets are not zero-filled (nor read)
         overwrite = rt.h16
         # every buffer of this pass that has to start at zero goes out in ONE multi-tensor launch with the buckets' fills: the
-        # cls / modality gradient sums (atomics accumulate into them) and the gradient-scale block of the fp16 mode
-        ncls, nmod = len(plan.cls_names), len(plan.mod_names)
-        cm = torch.empty(max(ncls, 1) * d + max(nmod, 1) * E, dtype=torch.float32, device=dev)
+        # gradient-scale block of the fp16 mode (the cls / modality gradient sums are accumulated straight into their views of
+        # the zero-filled front-end bucket)
         gs_block = torch.empty(8, dtype=torch.float32, device=dev) if rt.prec == L.PREC_F16 else None
-        grads = model._alloc_grad_buckets(names, params, dev, layer_overwrite=overwrite,
-                                          extra_zero=[cm] + ([gs_block] if gs_block is not None else []))
+        extra_zero = [gs_block] if gs_block is not None else []
+        grads = model._alloc_grad_buckets(names, params, dev, layer_overwrite=overwrite, extra_zero=extra_zero)
         G = grads.views
 
         # gradient stream of the last layer's output: the feature rows start as the incoming `feats` cotangent (a copy, not a
@@ -887,9 +887,24 @@ class EncoderFn(torch.autograd.Function):
             gT = torch.empty((B * n, _ru(Cn)), dtype=rt.op_dtype, device=dev)
             head_casts.append((go, B * n, Cn, gT))
             wg_items.append((gT, Cn, rows, E, B * n, G["cls_head." + pname + ".weight"], G["cls_head." + pname + ".bias"]))
-            d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
-            head_dgrads.append(dict(A=gT, B=rt.weight(w, True), M=B * n, N=E, K=Cn, out0=d_rows, ld0=E))
-            head_scatter.append((d_rows, s0, n))
+            # A head with a long contraction (the 3806 action classes) as column chunks of the contraction side by side, each into
+            # its own fp32 slab (dx_init adds them up): as ONE item its 240 blocks ran 60 contraction steps while the other heads'
+            # blocks had finished after 2 - 5 (49 us for 8 GFLOP).  At most six items per grouped launch.
+            Kp = _ru(Cn)
+            ns = 1
+            if rt.h16 and Kp >= 2048:
+                ns = max(1, min(4, Kp // 1024, 6 - (len(plan.heads) - 1)))
+            wT = rt.weight(w, True)
+            if ns == 1:
+                d_rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
+                head_dgrads.append(dict(A=gT, B=wT, M=B * n, N=E, K=Cn, out0=d_rows, ld0=E))
+            else:
+                d_rows = torch.empty((ns, B * n, E), dtype=torch.float32, device=dev)
+                step = _ru((Kp + ns - 1) // ns)
+                for j in range(ns):
+                    k0, k1 = j * step, min(Kp, (j + 1) * step)
+                    head_dgrads.append(dict(A=gT[:, k0:k1], B=wT[:, k0:k1], M=B * n, N=E, K=k1 - k0, out0=d_rows[j], ld0=E))
+            head_scatter.append((d_rows, s0, n, ns))
         # cotangent casts, input-gradient GEMMs and row scatters of all heads: one launch of each kind
         if 2 <= len(head_casts) <= 6:
             call("timhip_cast_rows_many", rt.prec, len(head_casts), _parr([c[0] for c in head_casts]),
@@ -904,8 +919,9 @@ class EncoderFn(torch.autograd.Function):
         gfeats = _f32c(g["feats"]) if g["feats"] is not None else None
         if len(head_scatter) <= 6 and disjoint:
             # one pass writes the whole stream: feature rows <- the `feats` cotangent, query rows <- their head's rows, rest 0
-            call("timhip_dx_init", B, S, F, E, ptr(gfeats), len(head_scatter), _iarr([h[1] for h in head_scatter]),
-                 _iarr([h[2] for h in head_scatter]), _parr([h[0] for h in head_scatter]), ptr(dx), st)
+            call("timhip_dx_init_slabs", B, S, F, E, ptr(gfeats), len(head_scatter), _iarr([h[1] for h in head_scatter]),
+                 _iarr([h[2] for h in head_scatter]), _parr([h[0] for h in head_scatter]), _iarr([h[3] for h in head_scatter]),
+                 ptr(dx), st)
         else:
             if gfeats is not None:
                 dx3[:, :F].copy_(gfeats)
@@ -913,8 +929,9 @@ class EncoderFn(torch.autograd.Function):
                 dx3[:, :F].zero_()
             if S > F:
                 dx3[:, F:].zero_()
-            for d_rows, s0, n in head_scatter:
-                call("timhip_scatter_rows_add", ptr(d_rows), B, S, E, s0, n, ptr(dx), st)
+            for d_rows, s0, n, ns in head_scatter:
+                for j in range(ns):
+                    call("timhip_scatter_rows_add", ptr(d_rows[j] if ns > 1 else d_rows), B, S, E, s0, n, ptr(dx), st)
         del head_dgrads, head_scatter, head_casts
         for slot, pname, s0, n, rows, h1, h2, y in ctx.reg_saved:
             go = g[slot]
@@ -1043,17 +1060,12 @@ class EncoderFn(torch.autograd.Function):
         d_e = [None, None]
         for name, slot, *_ in ctx.emb_saved:
             d_e[slot] = torch.empty((B * nf, d), dtype=torch.float32, device=dev)
-        # (cm: zero-filled with the gradient buckets at the top of the pass - atomics accumulate into both halves)
-        d_cls = cm[:max(ncls, 1) * d].view(max(ncls, 1), d)
-        d_mod = cm[max(ncls, 1) * d:].view(max(nmod, 1), E)
         d_te = torch.empty((B, T, d), dtype=torch.float32, device=dev)   # written in full by the kernel
-        call("timhip_assemble_bwd", ptr(plan.table(dev)), B, S, d, ptr(dx), nf, T, p_seq, seed, L.SITE_SEQ,
-             ptr(d_e[0]), ptr(d_e[1]), ptr(d_cls), ptr(d_te), ptr(d_mod), st)
-        dst = [G[fe + n] for n in plan.cls_names] + [G[fe + n] for n in plan.mod_names]
-        src = [d_cls[i].view_as(G[fe + n]) for i, n in enumerate(plan.cls_names)] + \
-              [d_mod[i].view_as(G[fe + n]) for i, n in enumerate(plan.mod_names)]
-        if dst:
-            torch._foreach_copy_(dst, src)   # one launch for the handful of token / modality parameters
+        # cls / modality gradients: atomics accumulate straight into the parameters' views of the (zero-filled) front-end bucket
+        d_cls = [G[fe + n].view(-1) for n in plan.cls_names]
+        d_mod = [G[fe + n].view(-1) for n in plan.mod_names]
+        call("timhip_assemble_bwd_p", ptr(plan.table(dev)), B, S, d, ptr(dx), nf, T, p_seq, seed, L.SITE_SEQ,
+             ptr(d_e[0]), ptr(d_e[1]), _parr(d_cls), len(d_cls), ptr(d_te), _parr(d_mod), len(d_mod), st)
 
         # ---- embedders backward
         d_inputs = {"visual": None, "audio": None}
