@@ -80,7 +80,7 @@ def det_train_step(model, batch, target, state):
         p.grad = None
     inner.rt.invalidate_weights()
     output, offsets, labels, queries, ious = model([batch["visual"], batch["audio"]], "encoder", batch["times"], target, label_queries=True)
-    loss = 0.0
+    loss = None
     sides = []
     if "visual" in inner.data_modality:
         ids = (0, 1, 2) if inner.include_verb_noun else (2,)
@@ -88,24 +88,30 @@ def det_train_step(model, batch, target, state):
     if "audio" in inner.data_modality:
         sides.append(((3,), 1, [labels[1]]))
     for mi, (cls_ids, reg_id, lab) in enumerate(sides):
-        iou, off = ious[reg_id], offsets[reg_id]
-        valid_reg = off[:, 0] != float("inf")                       # det train.py:223
-        valid_cls = iou >= 0.0
-        w = torch.where(iou < inner.iou_threshold, torch.ones_like(iou), iou)   # :228
-        # EMA of the positive count (:230): kept as a DEVICE scalar - the reference's `max(num_pos, 1)` compares a device tensor
-        # with a Python int, i.e. synchronises the host every step; clamp() is the same value without the read-back
-        num_pos = valid_reg.sum()
-        # ... and as ONE persistent tensor updated in place: a captured step (HIP-graph replay) then advances the average on every
-        # replay; a fresh tensor per step would freeze the replayed steps on the value the capture saw
+        # the side's loss in a handful of launches (tim_amd/losses.py:detection_side_loss - flags, weights, positive count, EMA
+        # normaliser and the divisions inside the kernels; the reference's `max(num_pos, 1)` compares a device tensor with a
+        # Python int, i.e. synchronises the host every step).  The normaliser is ONE persistent device scalar advanced in place:
+        # a captured step (HIP-graph replay) then advances the average on every replay.  TIM_AMD_DET_LOSS=composed: the same
+        # value from the separate focal / DIoU functions and torch glue (the round-4 form; tests compare the two)
         if ("norm", mi) not in state:
-            state[("norm", mi)] = torch.full((), 250.0, dtype=torch.float32, device=iou.device)              # parser.py:113-121
-        normaliser = 0.9 * state[("norm", mi)] + 0.1 * torch.clamp(num_pos, min=1).to(torch.float32)
-        state[("norm", mi)].copy_(normaliser.detach())
-        cls = sum(losses.focal_loss_sum(output[0][c], lab[j], row_weights=w, row_valid=valid_cls)
-                  for j, c in enumerate(cls_ids)) / (len(cls_ids) * normaliser)
-        reg = losses.diou_loss_sum(output[1][reg_id], torch.where(valid_reg[:, None], off, torch.zeros_like(off)),
-                                   row_valid=valid_reg) * 0.5 / normaliser   # :277-285, lambda_reg = 0.5 (parser.py:78)
-        loss = loss + cls + reg
+            state[("norm", mi)] = torch.full((), 250.0, dtype=torch.float32, device=ious[reg_id].device)      # parser.py:113-121
+        iou, off = ious[reg_id], offsets[reg_id]
+        if os.environ.get("TIM_AMD_DET_LOSS", "fused") != "composed":
+            side = losses.detection_side_loss([output[0][c] for c in cls_ids], lab, output[1][reg_id], off, iou, state[("norm", mi)],
+                                              inner.iou_threshold, lambda_reg=0.5, momentum=0.9)   # lambda_reg = 0.5 (parser.py:78)
+        else:
+            valid_reg = off[:, 0] != float("inf")                       # det train.py:223
+            valid_cls = iou >= 0.0
+            w = torch.where(iou < inner.iou_threshold, torch.ones_like(iou), iou)   # :228
+            num_pos = valid_reg.sum()
+            normaliser = 0.9 * state[("norm", mi)] + 0.1 * torch.clamp(num_pos, min=1).to(torch.float32)   # :230
+            state[("norm", mi)].copy_(normaliser.detach())
+            cls = sum(losses.focal_loss_sum(output[0][c], lab[j], row_weights=w, row_valid=valid_cls)
+                      for j, c in enumerate(cls_ids)) / (len(cls_ids) * normaliser)
+            reg = losses.diou_loss_sum(output[1][reg_id], torch.where(valid_reg[:, None], off, torch.zeros_like(off)),
+                                       row_valid=valid_reg) * 0.5 / normaliser   # :277-285
+            side = cls + reg
+        loss = side if mi == 0 else loss + side
     loss.backward()
     return {"loss": loss.detach(), "output": output, "offsets": offsets, "labels": labels, "queries": queries, "ious": ious}
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
+#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs, timhip_det_side_loss_{fwd,bwd}, timhip_sigmoid_bwd_rows; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
 
 enum {
   TIMHIP_OK = 0,
@@ -456,6 +456,10 @@ int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, in
  * rows of the count <= 6 DISJOINT token ranges [s0[i], s0[i] + n[i]) (s0[i] >= F) <- d_rows[i][b*n[i] + j,:], every other row 0. */
 int timhip_dx_init(int B, int S, int F, int E, const float* feats_cot, int count, const int* s0, const int* n,
                    const float* const* d_rows, float* dx, void* stream);
+/* dst[rows, ld] (operand dtype, zero padded beyond cols) = scale * grad_out * y * (1 - y): the backward of a sigmoid output layer
+ * (the regression heads of det head.py:95-163) written as the operand rows of the gradient GEMMs; scale: device scalar or NULL */
+int timhip_sigmoid_bwd_rows(int precision, const float* grad_out, const float* y, int rows, int cols, void* dst, int ld,
+                            const float* scale, void* stream);
 /* ... with range i given as nslab[i] (1 .. 16; NULL: 1 each) consecutive [B n[i], E] slabs at d_rows[i] that are added up on the
  * way: the input-gradient product of a head with a long contraction (3806 action classes) runs as several column chunks of the
  * contraction side by side, each into its own slab (tim_amd/functional.py: the 240 blocks of that product ran 60 contraction
@@ -521,6 +525,22 @@ int timhip_focal_loss_bwd(const float* logits, const float* targets, int rows, i
  * loss_sum and/or dpred (= grad_out[0] * d loss / d pred) are produced when non-NULL. */
 int timhip_diou_1d(const float* pred_offsets, const float* target_offsets, int n, const uint8_t* row_valid, float eps,
                    const float* grad_out, float* loss_sum, float* dpred, void* stream);
+/* One modality side of the detection training loss (det scripts/train.py:222-349) with the row flags derived where they are used:
+ * valid_cls = iou >= 0, row weight = iou < iou_threshold ? 1 : iou, positive = offsets[r, 0] != inf; the nheads <= 4 classification
+ * heads' focal sums, the DIoU sum of the positive rows and their count in one pass each, then
+ *   normaliser <- momentum * normaliser + (1 - momentum) * max(positives, 1)      (device scalar, in / out)
+ *   loss = focal / (nheads * normaliser) + (positives > 0 ? lambda_reg * DIoU / normaliser : 0)
+ * block (device float[8], out) = {loss, focal sum, DIoU sum, positives, normaliser used, 0, 0, 0}; the backward reads it.
+ * logits / targets / dlogits: host arrays of device pointers, [rows, C[k]] each; dlogits[k] may be NULL, dreg may be NULL. */
+int timhip_det_side_loss_fwd(const float* const* logits, const float* const* targets, const int* C, int nheads, int rows,
+                             const float* iou, const float* offsets, const float* reg_pred, float iou_threshold, float alpha,
+                             float gamma, float eps, float lambda_reg, float momentum, float* normaliser, float* block,
+                             void* stream);
+int timhip_det_side_loss_bwd(const float* const* logits, const float* const* targets, const int* C, int nheads, int rows,
+                             const float* iou, const float* offsets, const float* reg_pred, float iou_threshold, float alpha,
+                             float gamma, float eps, float lambda_reg, const float* block, const float* grad_out,
+                             float* const* dlogits, float* dreg, void* stream);
+
 
 /* ---------------------------------------------------------------- 1-D segment NMS */
 /* Batched soft-NMS over independent groups (one per video x class), bit-identical in its selection to

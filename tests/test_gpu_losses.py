@@ -124,3 +124,60 @@ def test_detection_losses(case):
     torch.cuda.synchronize()
     assert abs(reg.item() - float(g["diou"])) <= 1e-5 * abs(float(g["diou"]))
     assert np.abs(pred.grad.cpu().numpy() - g["dpred"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("heads,npos", [(1, 40), (3, 40), (2, 0)])
+def test_detection_side_loss_equals_its_composition(heads, npos):
+    """losses.detection_side_loss (timhip_det_side_loss_fwd / _bwd: one modality side of det scripts/train.py:222-349 in a handful
+    of launches, flags and weights derived inside the kernels) against the composition it replaces - focal_loss_sum /
+    diou_loss_sum (pinned to the reference-generated vectors above) and the loop's torch glue in float64: loss value, the EMA
+    normaliser it leaves behind, gradients of every head's logits and of the regression outputs; also without a single positive
+    row (no regression term, normaliser advanced with max(0, 1)), and twice in a row (the normaliser is a running value)."""
+    rows, thr, lam, mom = 300, 0.6, 0.5, 0.9
+    g = torch.Generator().manual_seed(7 + heads)
+    Cs = [13, 29, 97][:heads]
+    logits = [torch.randn(rows, c, generator=g) * 2.0 for c in Cs]
+    targets = [torch.rand(rows, c, generator=g).pow(8.0) for c in Cs]          # smoothed-label-like: mostly near 0
+    iou = torch.rand(rows, generator=g)
+    iou[torch.randperm(rows, generator=g)[:30]] = -1.0                          # rows outside every ground-truth window
+    pos = torch.zeros(rows, dtype=torch.bool)
+    cand = torch.nonzero(iou >= thr).flatten()
+    pos[cand[:npos]] = True
+    off = torch.full((rows, 2), float("inf"))
+    off[pos] = torch.rand(int(pos.sum()), 2, generator=g) * 3.0
+    reg = torch.rand(rows, 2, generator=g) * 3.0
+    norm0 = 250.0
+
+    def composed(norm_in):
+        xs = [x.double().requires_grad_(True) for x in logits]
+        r = reg.double().requires_grad_(True)
+        w = torch.where(iou < thr, torch.ones_like(iou), iou).double()
+        valid = iou >= 0
+        num_pos = int(pos.sum())
+        nm = mom * norm_in + (1.0 - mom) * max(num_pos, 1)
+        cls = sum(O.focal_loss(x[valid], t.double()[valid], w[valid], reduction="sum") for x, t in zip(xs, targets)) / (heads * nm)
+        tot = cls
+        if num_pos > 0:
+            tot = tot + lam * O.diou_1d(r[pos], off.double()[pos]).sum() / nm
+        (tot * 0.7).backward()
+        return tot.item(), nm, [x.grad for x in xs], (r.grad if r.grad is not None else torch.zeros_like(r))
+
+    want1 = composed(norm0)
+    want2 = composed(want1[1])
+    norm = torch.full((), norm0, dtype=torch.float32, device=DEV)
+    for want in (want1, want2):
+        xs = [x.to(DEV).requires_grad_(True) for x in logits]
+        r = reg.to(DEV).requires_grad_(True)
+        loss = losses.detection_side_loss(xs, [t.to(DEV) for t in targets], r, off.to(DEV), iou.to(DEV), norm, thr, lambda_reg=lam,
+                                          momentum=mom)
+        (loss * 0.7).backward()
+        torch.cuda.synchronize()
+        assert abs(loss.item() - want[0]) <= 2e-5 * abs(want[0]), (loss.item(), want[0])
+        assert abs(norm.item() - want[1]) <= 1e-5 * want[1]
+        for x, gw in zip(xs, want[2]):
+            sc = gw.abs().max().item()
+            assert (x.grad.cpu().double() - gw).abs().max().item() <= 2e-5 * sc
+            assert bool((x.grad.cpu()[iou < 0] == 0).all())
+        gr = r.grad.cpu().double() if r.grad is not None else torch.zeros(rows, 2, dtype=torch.float64)
+        assert (gr - want[3]).abs().max().item() <= 1e-5 * max(1e-6, want[3].abs().max().item()) + 1e-9
+        assert bool((gr[~pos] == 0).all())

@@ -130,6 +130,8 @@ _SIGS = {
     "timhip_focal_loss_fwd": (C.c_int, [vp, vp, i32, i32, vp, vp, f32, f32, vp, vp, vp]),
     "timhip_focal_loss_bwd": (C.c_int, [vp, vp, i32, i32, vp, vp, f32, f32, vp, vp, vp]),
     "timhip_diou_1d": (C.c_int, [vp, vp, i32, vp, f32, vp, vp, vp, vp]),
+    "timhip_det_side_loss_fwd": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, f32, vp, vp, vp]),
+    "timhip_det_side_loss_bwd": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp]),
     "timhip_softnms_1d_workspace_bytes": (C.c_size_t, [C.c_int64, i32]),
     "timhip_softnms_1d": (C.c_int, [vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, C.c_size_t, vp]),
     "timhip_nms_1d": (C.c_int, [vp, vp, vp, i32, f32, vp, vp, vp, vp]),
@@ -145,6 +147,7 @@ _SIGS = {
     "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "timhip_dx_init": (C.c_int, [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]),
+    "timhip_sigmoid_bwd_rows": (C.c_int, [i32, vp, vp, i32, i32, vp, i32, vp, vp]),
     "timhip_dx_init_slabs": (C.c_int, [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     "timhip_cast_rows_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),

@@ -228,6 +228,87 @@ __global__ void diou_kernel(const float* __restrict__ pred, const float* __restr
   }
 }
 
+// ---- one modality side of the detection training loss in a handful of launches (det scripts/train.py:222-349) -----------------
+// The loop derives, per query row, validity flags and weights from the IoU / offset targets the labelling kernel wrote
+// (valid_cls = iou >= 0, weight = iou < threshold ? 1 : iou, positive = offsets[r, 0] != inf), counts the positives, advances
+// the EMA normaliser and divides: ~25 elementwise / reduction launches of a few microseconds each per side in eager torch.
+// Here the flags are derived where they are used.  block = {loss, focal sum, DIoU sum, positives, normaliser used, 0, 0, 0}.
+__global__ void det_zero_kernel(float* block) { if (threadIdx.x < 8) block[threadIdx.x] = 0.f; }
+
+__device__ __forceinline__ bool det_positive(const float* __restrict__ off, int r) { return off[2 * r] != INFINITY; }
+
+__global__ __launch_bounds__(256) void det_focal_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n, int C,
+                                                            const float* __restrict__ iou, float thr, float alpha, float gamma,
+                                                            float* __restrict__ block) {
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float u = iou[i / C];
+    if (u >= 0.f) acc += (u < thr ? 1.f : u) * focal_term(x[i], t[i], alpha, gamma).loss;
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(block + 1, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// positives counted, DIoU loss of the positive rows summed (forward: dpred == NULL), or its gradient written (backward)
+__global__ __launch_bounds__(256) void det_rows_kernel(const float* __restrict__ pred, const float* __restrict__ off, int n, float eps,
+                                                       float* __restrict__ block, const float* __restrict__ gout, float lambda_reg,
+                                                       float* __restrict__ dpred) {
+  float acc = 0.f, cnt = 0.f;
+  const float g = dpred ? (gout ? gout[0] : 1.f) * lambda_reg / block[4] : 0.f;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    float dl = 0.f, dr = 0.f;
+    if (det_positive(off, r)) {
+      cnt += 1.f;
+      const float lp = pred[2 * r], rp = pred[2 * r + 1], lg = off[2 * r], rg = off[2 * r + 1];
+      const float lk = fminf(lp, lg), rk = fminf(rp, rg);
+      const float I = rk + lk, U = (lp + rp) + (lg + rg) - I, Uc = fmaxf(U, eps);
+      const float lc = fmaxf(lp, lg), rc = fmaxf(rp, rg), Lc = lc + rc, Lcc = fmaxf(Lc, eps);
+      const float rho = 0.5f * (rp - lp - rg + lg), z = rho / Lcc;
+      acc += 1.f - I / Uc + z * z;
+      if (dpred) {   // (the compiled TorchScript form of the reference's autodiff: see diou_kernel)
+        const float dI_l = lp < lg ? 1.f : 0.f, dI_r = rp < rg ? 1.f : 0.f;
+        const float dLc_l = lp > lg ? 1.f : 0.f, dLc_r = rp > rg ? 1.f : 0.f;
+        const float uok = U >= eps ? 1.f : 0.f, lok = Lc >= eps ? 1.f : 0.f;
+        const float a = 1.f / Uc, b = I / (Uc * Uc);
+        const float diou_l = dI_l * a - b * uok * (1.f - dI_l), diou_r = dI_r * a - b * uok * (1.f - dI_r);
+        const float dz_l = (-0.5f) / Lcc - rho / (Lcc * Lcc) * lok * dLc_l;
+        const float dz_r = (0.5f) / Lcc - rho / (Lcc * Lcc) * lok * dLc_r;
+        dl = g * (-diou_l + 2.f * z * dz_l);
+        dr = g * (-diou_r + 2.f * z * dz_r);
+      }
+    }
+    if (dpred) { dpred[2 * r] = dl; dpred[2 * r + 1] = dr; }
+  }
+  if (!dpred) {
+    acc = wave_sum(acc); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(block + 2, acc); atomicAdd(block + 3, cnt); }
+  }
+}
+
+// normaliser <- momentum * normaliser + (1 - momentum) * max(positives, 1)   (train.py:230: a running value across steps and sides);
+// loss = focal / (heads * normaliser) + lambda_reg * DIoU / normaliser   (no regression term without positives, train.py:277)
+__global__ void det_finish_kernel(float* __restrict__ block, float* __restrict__ normaliser, float momentum, float lambda_reg, int nheads) {
+  const float npos = block[3];
+  const float nm = momentum * normaliser[0] + (1.f - momentum) * fmaxf(npos, 1.f);
+  normaliser[0] = nm;
+  block[4] = nm;
+  block[0] = block[1] / ((float)nheads * nm) + (npos > 0.f ? lambda_reg * block[2] / nm : 0.f);
+}
+
+__global__ __launch_bounds__(256) void det_focal_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n, int C,
+                                                            const float* __restrict__ iou, float thr, float alpha, float gamma,
+                                                            const float* __restrict__ block, const float* __restrict__ gout, int nheads,
+                                                            float* __restrict__ dx) {
+  const float g = (gout ? gout[0] : 1.f) / ((float)nheads * block[4]);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float u = iou[i / C];
+    dx[i] = u >= 0.f ? g * (u < thr ? 1.f : u) * focal_term(x[i], t[i], alpha, gamma).dx : 0.f;
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -274,6 +355,52 @@ int timhip_diou_1d(const float* pred_offsets, const float* target_offsets, int n
   if (n == 0) return TIMHIP_OK;
   hipLaunchKernelGGL(diou_kernel, dim3((n + 255) / 256 > 256 ? 256 : (n + 255) / 256), dim3(256), 0, s, pred_offsets,
                      target_offsets, n, row_valid, eps, grad_out, loss_sum, dpred);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_det_side_loss_fwd(const float* const* logits, const float* const* targets, const int* C, int nheads, int rows,
+                             const float* iou, const float* offsets, const float* reg_pred, float iou_threshold, float alpha,
+                             float gamma, float eps, float lambda_reg, float momentum, float* normaliser, float* block,
+                             void* stream) {
+  if (!logits || !targets || !C || nheads < 1 || nheads > 4 || rows < 0 || !iou || !offsets || !reg_pred || !normaliser || !block)
+    return TIMHIP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(det_zero_kernel, dim3(1), dim3(64), 0, s, block);
+  if (rows > 0) {
+    for (int k = 0; k < nheads; ++k) {
+      if (!logits[k] || !targets[k] || C[k] <= 0) return TIMHIP_EINVAL;
+      const long long n = (long long)rows * C[k];
+      const int blocks = (int)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256);   // one atomic per block on a single address
+      hipLaunchKernelGGL(det_focal_fwd_kernel, dim3(blocks), dim3(256), 0, s, logits[k], targets[k], n, C[k], iou, iou_threshold,
+                         alpha, gamma, block);
+    }
+    hipLaunchKernelGGL(det_rows_kernel, dim3((rows + 255) / 256 > 256 ? 256 : (rows + 255) / 256), dim3(256), 0, s, reg_pred, offsets,
+                       rows, eps, block, (const float*)nullptr, lambda_reg, (float*)nullptr);
+  }
+  hipLaunchKernelGGL(det_finish_kernel, dim3(1), dim3(1), 0, s, block, normaliser, momentum, lambda_reg, nheads);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_det_side_loss_bwd(const float* const* logits, const float* const* targets, const int* C, int nheads, int rows,
+                             const float* iou, const float* offsets, const float* reg_pred, float iou_threshold, float alpha,
+                             float gamma, float eps, float lambda_reg, const float* block, const float* grad_out,
+                             float* const* dlogits, float* dreg, void* stream) {
+  if (!logits || !targets || !C || nheads < 1 || nheads > 4 || rows < 0 || !iou || !offsets || !reg_pred || !block || !dlogits)
+    return TIMHIP_EINVAL;
+  if (rows == 0) return TIMHIP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  for (int k = 0; k < nheads; ++k) {
+    if (!dlogits[k]) continue;
+    const long long n = (long long)rows * C[k];
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(det_focal_bwd_kernel, dim3(blocks), dim3(256), 0, s, logits[k], targets[k], n, C[k], iou, iou_threshold,
+                       alpha, gamma, block, grad_out, nheads, dlogits[k]);
+  }
+  if (dreg)
+    hipLaunchKernelGGL(det_rows_kernel, dim3((rows + 255) / 256 > 256 ? 256 : (rows + 255) / 256), dim3(256), 0, s, reg_pred, offsets,
+                       rows, eps, const_cast<float*>(block), grad_out, lambda_reg, dreg);
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

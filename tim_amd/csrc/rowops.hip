@@ -932,6 +932,22 @@ __global__ __launch_bounds__(256) void dx_init_kernel(int B, int S, int F, int E
     *reinterpret_cast<float4*>(dst + c) = v;
   }
 }
+// dst[r, c] = T(scale * g[r, c] * y[r, c] * (1 - y[r, c])) for c < cols, 0 up to ld: the backward of the regression heads' sigmoid
+// (det head.py:95-163: 2 outputs per query) straight into the zero-padded operand rows of the gradient GEMMs
+template <typename T>
+__global__ void sigmoid_bwd_rows_kernel(const float* __restrict__ g, const float* __restrict__ y, int rows, int cols,
+                                        T* __restrict__ dst, int ld, const float* __restrict__ vscale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * ld) return;
+  const int r = (int)(i / ld), c = (int)(i % ld);
+  float v = 0.f;
+  if (c < cols) {
+    const float yy = y[(size_t)r * cols + c];
+    v = g[(size_t)r * cols + c] * yy * (1.f - yy) * (vscale ? *vscale : 1.f);
+  }
+  dst[i] = OpT<T>::from_f(v);
+}
+
 // fp32 [rows, cols] -> T [rows, ld] (zero padded) for several matrices in one launch (blockIdx.z = matrix)
 struct CastMany {
   const float* src[RR_MAX]; void* dst[RR_MAX];
@@ -1454,6 +1470,16 @@ int timhip_scatter_ranges_add(int B, int S, int E, int count, const int* s0, con
   if (rc) return rc;
   for (int i = 0; i < count; ++i) { if (!d_rows[i]) return TIMHIP_EINVAL; rr.src[i] = d_rows[i]; }
   hipLaunchKernelGGL(scatter_ranges_add_kernel, dim3(B * rr.joff[count]), dim3(256), 0, (hipStream_t)stream, B, S, E, dx, rr);
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_sigmoid_bwd_rows(int precision, const float* grad_out, const float* y, int rows, int cols, void* dst, int ld,
+                            const float* scale, void* stream) {
+  if (!grad_out || !y || !dst || rows <= 0 || cols <= 0 || ld < cols) return TIMHIP_EINVAL;
+  const long long n = (long long)rows * ld;
+  DISPATCH_T(precision, hipLaunchKernelGGL(sigmoid_bwd_rows_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                           (hipStream_t)stream, grad_out, y, rows, cols, (T*)dst, ld, scale));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

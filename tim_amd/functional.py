@@ -796,8 +796,8 @@ class EncoderFn(torch.autograd.Function):
             pre = "reg_head." + pname + "."
             hid = E // 2
             rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
-            h1 = torch.zeros((B * n, _ru(hid)), dtype=rt.op_dtype, device=dev)
-            h2 = torch.zeros((B * n, _ru(hid)), dtype=rt.op_dtype, device=dev)
+            h1 = rt.out_op(B * n, hid, dev)    # (zero-filled only when hid is not a multiple of 64: padding columns)
+            h2 = rt.out_op(B * n, hid, dev)
             y = torch.empty((B * n, 2), dtype=torch.float32, device=dev)
             if n > 0:
                 call("timhip_gather_rows", rt.prec, ptr(xL_t), B, S, E, s0, n, ptr(rows), st)
@@ -939,16 +939,15 @@ class EncoderFn(torch.autograd.Function):
                 continue
             pre = "reg_head." + pname + "."
             hid = E // 2
-            # sigmoid backward on the [B*n, 2] outputs (2 columns: not worth a kernel of its own)
-            gz = _f32c(go) * y * (1.0 - y)
+            # sigmoid backward on the [B*n, 2] outputs, written as the zero-padded operand rows of the gradient GEMMs
             gzT = torch.empty((B * n, 64), dtype=rt.op_dtype, device=dev)
-            call("timhip_cast_rows", rt.prec, ptr(gz), B * n, 2, 2, ptr(gzT), 64, 0.0, 0, 0, gs_in, st)
+            call("timhip_sigmoid_bwd_rows", rt.prec, ptr(_f32c(go)), ptr(y), B * n, 2, ptr(gzT), 64, gs_in, st)
             wg_items.append((gzT, 2, h2, hid, B * n, G[pre + "4.weight"], G[pre + "4.bias"]))
-            dh2 = torch.zeros_like(h2)
+            dh2 = rt.out_op(B * n, hid, dev)
             rt.gemm(L.EPI_DRELU_T, gzT, rt.weight(P[pre + "4.weight"], True), B * n, hid, 2, dh2, dh2.shape[1],
                     aux=h2, ldaux=h2.shape[1])
             wg_items.append((dh2, hid, h1, hid, B * n, G[pre + "2.weight"], G[pre + "2.bias"]))
-            dh1 = torch.zeros_like(h1)
+            dh1 = rt.out_op(B * n, hid, dev)
             rt.gemm(L.EPI_DRELU_T, dh2, rt.weight(P[pre + "2.weight"], True), B * n, hid, hid, dh1, dh1.shape[1],
                     aux=h1, ldaux=h1.shape[1])
             wg_items.append((dh1, hid, rows, E, B * n, G[pre + "0.weight"], G[pre + "0.bias"]))

@@ -359,6 +359,71 @@ def ctr_diou_loss_1d(input_offsets, target_offsets, reduction: str = "none", eps
     raise NotImplementedError('ctr_diou_loss_1d: reduction "none" is not built (the training loop uses "sum")')
 
 
+class _DetSideLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aux, iou, offsets, reg_pred, *logits):
+        targets, normaliser, thr, alpha, gamma, eps, lam, mom = aux
+        _require_gpu(reg_pred, "detection side loss")
+        dev = reg_pred.device
+        xs = [_f32c(x) for x in logits]
+        ts = [_f32c(t).to(dev) for t in targets]
+        rows = iou.numel()
+        for x, t in zip(xs, ts):
+            if x.shape != t.shape or x.dim() != 2 or x.shape[0] != rows:
+                raise ValueError("logits / targets of one side must be [rows, C] with one row per query: %s vs %s, %d rows"
+                                 % (tuple(x.shape), tuple(t.shape), rows))
+        u = _f32c(iou).reshape(-1)
+        off = _f32c(offsets).reshape(-1, 2)
+        rp = _f32c(reg_pred).reshape(-1, 2)
+        if off.shape[0] != rows or rp.shape[0] != rows:
+            raise ValueError("one offset pair per query row")
+        block = torch.empty(8, dtype=torch.float32, device=dev)
+        Cs = (C.c_int * len(xs))(*[x.shape[1] for x in xs])
+        pa = lambda ts_: (C.c_void_p * len(ts_))(*[ptr(t) for t in ts_])   # noqa: E731
+        call("timhip_det_side_loss_fwd", pa(xs), pa(ts), Cs, len(xs), rows, ptr(u), ptr(off), ptr(rp), float(thr), float(alpha),
+             float(gamma), float(eps), float(lam), float(mom), ptr(normaliser), ptr(block), _stream())
+        ctx.consts = (float(thr), float(alpha), float(gamma), float(eps), float(lam), rows, tuple(reg_pred.shape))
+        ctx.n = len(xs)
+        ctx.save_for_backward(block, u, off, rp, *xs, *ts)
+        return block[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        block, u, off, rp, *rest = ctx.saved_tensors
+        xs, ts = rest[:ctx.n], rest[ctx.n:]
+        thr, alpha, gamma, eps, lam, rows, rshape = ctx.consts
+        gout = _f32c(g).reshape(1)
+        need = ctx.needs_input_grad
+        dxs = [torch.empty_like(x) if need[4 + i] else None for i, x in enumerate(xs)]
+        dreg = torch.empty_like(rp) if need[3] else None
+        Cs = (C.c_int * len(xs))(*[x.shape[1] for x in xs])
+        pa = lambda ts_: (C.c_void_p * len(ts_))(*[ptr(t) for t in ts_])   # noqa: E731
+        call("timhip_det_side_loss_bwd", pa(xs), pa(ts), Cs, len(xs), rows, ptr(u), ptr(off), ptr(rp), thr, alpha, gamma, eps, lam,
+             ptr(block), ptr(gout), pa(dxs), ptr(dreg), _stream())
+        return (None, None, None, dreg.view(rshape) if dreg is not None else None) + tuple(dxs)
+
+
+def detection_side_loss(cls_logits, cls_targets, reg_pred, offsets, iou, normaliser, iou_threshold, lambda_reg=0.5, momentum=0.9,
+                        alpha=0.25, gamma=2.0, eps=1e-8):
+    """One modality side of the detection training loss, det scripts/train.py:222-349, as a handful of launches:
+
+        valid_cls = iou >= 0;  w = where(iou < iou_threshold, 1, iou);  positive = offsets[:, 0] != inf
+        normaliser <- momentum * normaliser + (1 - momentum) * max(#positive, 1)          (`normaliser`: device scalar, updated
+                                                                                            IN PLACE - a replayed HIP graph advances it)
+        loss = sum_k focal_sum(cls_logits[k], cls_targets[k], w, valid_cls) / (K * normaliser)
+               + lambda_reg * diou_sum(reg_pred[positive], offsets[positive]) / normaliser      (when there is a positive row)
+
+    cls_logits / cls_targets: lists of the side's K heads ([rows, C_k] each; verb / noun / action, or the audio head).  The loop's
+    eager form derives the flags and weights with ~25 small torch launches per side; here the kernels derive them in place
+    (timhip_det_side_loss_fwd / _bwd).  Gradients flow to the logits and to reg_pred."""
+    if not isinstance(cls_logits, (list, tuple)):
+        cls_logits, cls_targets = [cls_logits], [cls_targets]
+    if normaliser.dtype != torch.float32 or normaliser.numel() != 1 or not normaliser.is_cuda:
+        raise ValueError("normaliser: a float32 scalar tensor on the GPU (it is advanced in place)")
+    aux = (list(cls_targets), normaliser, iou_threshold, alpha, gamma, eps, lambda_reg, momentum)
+    return _DetSideLossFn.apply(aux, iou, offsets, reg_pred, *cls_logits)
+
+
 def get_loss(criterion, pred, y, weights=None, reduction="mean"):
     """detection models/helpers/losses/loss.py:5-14, same arguments.  The focal criterion with row weights runs as one
     fused kernel; any other criterion takes the reference's generic route."""
