@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs, timhip_det_side_loss_{fwd,bwd}, timhip_sigmoid_bwd_rows; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
+#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs, timhip_det_side_loss_{fwd,bwd}, timhip_sigmoid_bwd_rows, timhip_time_l1_fwd_split3, timhip_gather_split3_ranges, TIMHIP_EPI_RELU_SPLIT3_T; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
 
 enum {
   TIMHIP_OK = 0,
@@ -77,7 +77,10 @@ enum {
   TIMHIP_EPI_GELU_DROP_G2 = 11, /* u = acc+bias ; out0(T) = dropmask * gelu(u) ; out1(T) = dropmask * gelu'(u): the factor the
                                    backward multiplies with, so that its epilogue (TIMHIP_EPI_MULAUX_T) needs no erf / exp and
                                    no second look at the dropout mask */
-  TIMHIP_EPI_MULAUX_T = 12      /* out0(T) = acc * aux(T) */
+  TIMHIP_EPI_MULAUX_T = 12,     /* out0(T) = acc * aux(T) */
+  TIMHIP_EPI_RELU_SPLIT3_T = 13 /* v = relu(acc + bias) as the split operand [hi | lo | hi]: out0(T)[m, n] = T(v), [m, ld1 + n] = T(v - hi),
+                                   [m, 2 ld1 + n] = T(v); ld1 = the block width (a multiple of 64), ld0 = the row stride (3 ld1) - what
+                                   timhip_split3_many (mode 0, relu) makes of the fp32 output, without the round trip (time MLP) */
 };
 
 /* Shape of one call.  M = B*S rows flow through the encoder. */
@@ -333,6 +336,11 @@ int timhip_dropout_rows_bwd(const float* g, int rows, int cols, int ldg, float* 
 /* time MLP layer 1 (K = 2, tim.py:67): h[r,j] = relu(t[r,0] w[j,0] + t[r,1] w[j,1] + b[j]) (T, ld) */
 int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const float* w,
                        const float* b, void* h, int ld, void* stream);
+/* The same with the row written as the split operand [hi | lo | hi] of the fp32 value (three 16-bit column blocks of width ld, a
+ * multiple of 64; row stride 3 ld; 16-bit modes): what timhip_split3_many (mode 0) makes of the fp32 output, without the fp32
+ * round trip and the second launch. */
+int timhip_time_l1_fwd_split3(int precision, const float* times, int rows, int d, const float* w, const float* b, void* h3,
+                              int ld, void* stream);
 /* dh: gradient w.r.t. the pre-activation of layer 1 (T).  dw[d,2] +=, db[d] +=, dt[rows,2] = (may be NULL) */
 int timhip_time_l1_bwd(int precision, const float* times, int rows, int d, const float* w,
                        const void* dh, int ld, float* dw, float* db, float* dt, const float* out_scale, void* stream);
@@ -452,6 +460,11 @@ int timhip_scatter_rows_add(const float* d_rows, int B, int S, int E, int s0, in
  * cast of several cotangent matrices (dst[i] is [rows[i], ld[i]], zero padded beyond cols[i]) in one launch. */
 int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, int count, const int* s0, const int* n,
                          void* const* rows_T, void* stream);
+/* rows3_T[i][b * n[i] + j, 0 .. 3 E) = the fp32 row x[b, s0[i] + j, :] as the split operand [hi | lo | hi] (three 16-bit column
+ * blocks of width E, a multiple of 64; 16-bit modes): timhip_gather_ranges on the fp32 rows + timhip_split3_many (mode 0) in one
+ * launch - how the fp16 mode feeds its classification heads (count 1 .. 6 ranges) */
+int timhip_gather_split3_ranges(int precision, const float* x, int B, int S, int E, int count, const int* s0, const int* n,
+                                void* const* rows3_T, void* stream);
 /* dx[B,S,E] (fp32, the gradient entering the last encoder layer) written in one pass: rows s < F <- feats_cot[b,s,:] (NULL: 0),
  * rows of the count <= 6 DISJOINT token ranges [s0[i], s0[i] + n[i]) (s0[i] >= F) <- d_rows[i][b*n[i] + j,:], every other row 0. */
 int timhip_dx_init(int B, int S, int F, int E, const float* feats_cot, int count, const int* s0, const int* n,

@@ -15,7 +15,7 @@ PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32, "fp16
 H16 = (PREC_BF16, PREC_F16)   # 16-bit operand storage (the MFMA GEMM / attention / transposing weight-gradient kernels)
 
 (EPI_STORE_T, EPI_RELU_T, EPI_STORE_F32, EPI_GELU_DROP_T2, EPI_DROP_RES_F32, EPI_ADD_F32,
- EPI_DGELU_T, EPI_DRELU_T, EPI_ATOMIC_F32, EPI_SIGMOID_F32, EPI_DRELU_F32IN_T, EPI_GELU_DROP_G2, EPI_MULAUX_T) = range(13)
+ EPI_DGELU_T, EPI_DRELU_T, EPI_ATOMIC_F32, EPI_SIGMOID_F32, EPI_DRELU_F32IN_T, EPI_GELU_DROP_G2, EPI_MULAUX_T, EPI_RELU_SPLIT3_T) = range(14)
 
 # dropout site ids (csrc/common.h)
 SITE_FEAT_V, SITE_FEAT_A, SITE_SEQ = 1, 2, 3
@@ -101,6 +101,7 @@ _SIGS = {
     "timhip_attention_bwd": (C.c_int, [C.POINTER(TimDesc), vp, vp, vp, vp, vp, vp, sz, vp]),
     "timhip_attention_bwd_workspace_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_time_l1_fwd": (C.c_int, [i32, vp, i32, i32, vp, vp, vp, i32, vp]),
+    "timhip_time_l1_fwd_split3": (C.c_int, [i32, vp, i32, i32, vp, vp, vp, i32, vp]),
     "timhip_time_l1_bwd": (C.c_int, [i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "timhip_dropout_mask": (C.c_int, [u64, u32, f32, i32, i32, vp, vp]),
     "timhip_dropout_salt": (C.c_int, [vp]),
@@ -145,6 +146,7 @@ _SIGS = {
     "timhip_layer_ln_partial_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_ln_partials_reduce": (C.c_int, [vp, i32, i32, i32, vp, vp, vp]),
     "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "timhip_gather_split3_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "timhip_dx_init": (C.c_int, [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]),
     "timhip_sigmoid_bwd_rows": (C.c_int, [i32, vp, vp, i32, i32, vp, i32, vp, vp]),

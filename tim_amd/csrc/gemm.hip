@@ -724,6 +724,8 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
   e.acc_scale = te.acc_scale;
   e.a_wrap = te.a_wrap_k / 64;
   if (e.ln_stats && (epi != TIMHIP_EPI_DROP_RES_F32 || !e.res || !e.ln_w || !e.ln_b)) return TIMHIP_EINVAL;
+  if (epi == TIMHIP_EPI_RELU_SPLIT3_T && (!h16_storage(precision) || e.out1 || e.ld1 % 64 || e.ld1 < N || e.ld0 < 3 * e.ld1 || splitk > 1))
+    return TIMHIP_EINVAL;   // three column blocks of width ld1 in a row of stride ld0
   e.slab_stride = splitk > 1 ? (long long)M * te.ld0 : 0;
 
   bool vec = (e.ld0 % 4 == 0) && (((uintptr_t)e.out0 & 15) == 0);
@@ -833,6 +835,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
     CASE(TIMHIP_EPI_DRELU_F32IN_T)
     CASE(TIMHIP_EPI_GELU_DROP_G2)
     CASE(TIMHIP_EPI_MULAUX_T)
+    CASE(TIMHIP_EPI_RELU_SPLIT3_T)
 #undef CASE
     default: return TIMHIP_EINVAL;
   }

@@ -93,6 +93,12 @@ __device__ __forceinline__ void epi_one(const EpiDev& e, int m, int n, int N, fl
     atomicAdd(((float*)e.out0) + i0, v);
   } else if (EPI == TIMHIP_EPI_SIGMOID_F32) {
     ((float*)e.out0)[i0] = 1.f / (1.f + __expf(-v));
+  } else if (EPI == TIMHIP_EPI_RELU_SPLIT3_T) {
+    const float r = fmaxf(v, 0.f);
+    const T hi = OpT<T>::from_f(r);
+    ((T*)e.out0)[i0] = hi;
+    ((T*)e.out0)[i0 + e.ld1] = OpT<T>::from_f(r - OpT<T>::to_f(hi));
+    ((T*)e.out0)[i0 + 2 * (size_t)e.ld1] = hi;
   }
 }
 
@@ -184,6 +190,13 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
     } else if (EPI == TIMHIP_EPI_SIGMOID_F32) {
       nt_store4<float>((float*)e.out0 + i0, 1.f / (1.f + __expf(-v0)), 1.f / (1.f + __expf(-v1)),
                     1.f / (1.f + __expf(-v2)), 1.f / (1.f + __expf(-v3)));
+    } else if (EPI == TIMHIP_EPI_RELU_SPLIT3_T) {
+      const float r0 = fmaxf(v0, 0.f), r1 = fmaxf(v1, 0.f), r2 = fmaxf(v2, 0.f), r3 = fmaxf(v3, 0.f);
+      T* o = (T*)e.out0 + i0;
+      store4<T>(o, r0, r1, r2, r3);
+      store4<T>(o + e.ld1, r0 - OpT<T>::to_f(OpT<T>::from_f(r0)), r1 - OpT<T>::to_f(OpT<T>::from_f(r1)),
+                r2 - OpT<T>::to_f(OpT<T>::from_f(r2)), r3 - OpT<T>::to_f(OpT<T>::from_f(r3)));
+      store4<T>(o + 2 * (size_t)e.ld1, r0, r1, r2, r3);
     }
   } else {
     if (n < N) epi_one<EPI, T>(e, m, n, N, v0, k0);

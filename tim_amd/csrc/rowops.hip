@@ -564,7 +564,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 template <typename T>
 __global__ __launch_bounds__(256) void time_l1_fwd_kernel(const float* __restrict__ times, int rows, int d,
                                                           const float* __restrict__ w, const float* __restrict__ b,
-                                                          T* __restrict__ h, int ld, int rows_pb) {
+                                                          T* __restrict__ h, int ld, int rows_pb, int split) {
+  // split != 0 (timhip_time_l1_fwd_split3): the row is written as the three 16-bit column blocks [hi | lo | hi] of the fp32 value
+  // (block width ld, row stride 3 ld) - what timhip_split3_many (mode 0) made of this kernel's fp32 output in a second launch
+  const int rs = split ? 3 * ld : ld;
   // a thread owns 4 consecutive columns (its weights stay in registers) and walks the block's rows: 16-byte stores, a few
   // hundred blocks (one block per row and 4-byte stores took 15.6 us for the 8000 x 512 rows of C2a)
   const int r0 = blockIdx.x * rows_pb, r1 = min(rows, r0 + rows_pb);
@@ -584,7 +587,15 @@ __global__ __launch_bounds__(256) void time_l1_fwd_kernel(const float* __restric
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = 4 * q0 + u < d ? fmaxf(fmaf(t0, w0[u], fmaf(t1, w1[u], bb[u])), 0.f) : 0.f;
-        store4<T>(h + (size_t)r * ld + 4 * q0, v[0], v[1], v[2], v[3]);
+        T* dst = h + (size_t)r * rs + 4 * q0;
+        store4<T>(dst, v[0], v[1], v[2], v[3]);
+        if (split) {
+          float lo[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) lo[u] = v[u] - OpT<T>::to_f(OpT<T>::from_f(v[u]));
+          store4<T>(dst + ld, lo[0], lo[1], lo[2], lo[3]);
+          store4<T>(dst + 2 * ld, v[0], v[1], v[2], v[3]);
+        }
       }
     }
     return;
@@ -594,7 +605,12 @@ __global__ __launch_bounds__(256) void time_l1_fwd_kernel(const float* __restric
     for (int j = threadIdx.x; j < ld; j += blockDim.x) {
       float v = 0.f;
       if (j < d) v = fmaxf(fmaf(t0, w[2 * j], fmaf(t1, w[2 * j + 1], b[j])), 0.f);
-      h[(size_t)r * ld + j] = OpT<T>::from_f(v);
+      const T hi = OpT<T>::from_f(v);
+      h[(size_t)r * rs + j] = hi;
+      if (split) {
+        h[(size_t)r * rs + ld + j] = OpT<T>::from_f(v - OpT<T>::to_f(hi));
+        h[(size_t)r * rs + 2 * ld + j] = hi;
+      }
     }
   }
 }
@@ -883,6 +899,30 @@ __global__ void gather_ranges_kernel(const T* __restrict__ xt, int B, int S, int
     float a0, a1, a2, a3;
     load4<T>(src + c, a0, a1, a2, a3);
     store4<T>(dst + c, a0, a1, a2, a3);
+  }
+}
+// the gathered fp32 rows written straight as split operands [hi | lo | hi] (three 16-bit column blocks of width E, row stride 3 E):
+// gather_ranges + split3 (mode 0) of the classification heads' fp16 path in one launch, without the fp32 row buffers
+template <typename T>
+__global__ void gather_split3_ranges_kernel(const float* __restrict__ x, int B, int S, int E, RowRanges rr) {
+  const int per = rr.joff[rr.count];
+  const int b = blockIdx.x / per, jg = blockIdx.x % per;
+  int r = 0;
+#pragma unroll
+  for (int k = 1; k < RR_MAX; ++k)
+    if (k < rr.count && jg >= rr.joff[k]) r = k;
+  const int j = jg - rr.joff[r];
+  const float* src = x + ((size_t)b * S + rr.s0[r] + j) * E;
+  T* dst = (T*)rr.dst[r] + ((size_t)b * rr.n[r] + j) * 3 * E;
+  for (int c = threadIdx.x * 4; c < E; c += blockDim.x * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + c);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    float lo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) lo[u] = f[u] - OpT<T>::to_f(OpT<T>::from_f(f[u]));
+    store4<T>(dst + c, f[0], f[1], f[2], f[3]);
+    store4<T>(dst + E + c, lo[0], lo[1], lo[2], lo[3]);
+    store4<T>(dst + 2 * E + c, f[0], f[1], f[2], f[3]);
   }
 }
 __global__ void scatter_ranges_add_kernel(int B, int S, int E, float* __restrict__ dx, RowRanges rr) {
@@ -1338,7 +1378,18 @@ int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const
   const int rpb = rows >= 4096 ? 16 : (rows >= 512 ? 4 : 1);
   dim3 grid((rows + rpb - 1) / rpb);
   DISPATCH_T(precision, hipLaunchKernelGGL(time_l1_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, times,
-                                           rows, d, w, b, (T*)h, ld, rpb));
+                                           rows, d, w, b, (T*)h, ld, rpb, 0));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_time_l1_fwd_split3(int precision, const float* times, int rows, int d, const float* w, const float* b, void* h3,
+                              int ld, void* stream) {
+  if (!times || !w || !b || !h3 || rows <= 0 || ld < d || (ld % 64) || !h16_storage(precision)) return TIMHIP_EINVAL;
+  const int rpb = rows >= 4096 ? 16 : (rows >= 512 ? 4 : 1);
+  dim3 grid((rows + rpb - 1) / rpb);
+  DISPATCH_H16(precision, hipLaunchKernelGGL(time_l1_fwd_kernel<HT>, grid, dim3(256), 0, (hipStream_t)stream, times,
+                                             rows, d, w, b, (HT*)h3, ld, rpb, 1));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }
@@ -1458,6 +1509,19 @@ int timhip_gather_ranges(int precision, const void* x_T, int B, int S, int E, in
   for (int i = 0; i < count; ++i) { if (!rows_T[i]) return TIMHIP_EINVAL; rr.dst[i] = rows_T[i]; }
   DISPATCH_T(precision, hipLaunchKernelGGL(gather_ranges_kernel<T>, dim3(B * rr.joff[count]), dim3(256), 0,
                                            (hipStream_t)stream, (const T*)x_T, B, S, E, rr));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
+}
+
+int timhip_gather_split3_ranges(int precision, const float* x, int B, int S, int E, int count, const int* s0, const int* n,
+                                void* const* rows3_T, void* stream) {
+  if (!x || !rows3_T || B <= 0 || E % 64 || !h16_storage(precision)) return TIMHIP_EINVAL;
+  RowRanges rr;
+  int rc = fill_ranges(rr, count, s0, n);
+  if (rc) return rc;
+  for (int i = 0; i < count; ++i) { if (!rows3_T[i] || ((uintptr_t)rows3_T[i] & 7)) return TIMHIP_EINVAL; rr.dst[i] = rows3_T[i]; }
+  DISPATCH_H16(precision, hipLaunchKernelGGL(gather_split3_ranges_kernel<HT>, dim3(B * rr.joff[count]), dim3(256), 0,
+                                             (hipStream_t)stream, x, B, S, E, rr));
   TIM_CHECK_LAUNCH();
   return TIMHIP_OK;
 }

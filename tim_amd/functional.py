@@ -493,13 +493,11 @@ class TimeMlpFn(torch.autograd.Function):
         if rt.split:
             # fp16 model: split operands (Runtime.__init__).  h1 / h2 are kept as [hi | lo | hi] blocks; their first block is
             # the plain fp16 operand the backward reads (row stride 3 ldd)
-            f1 = torch.empty((R, d), dtype=torch.float32, device=dev)
-            call("timhip_time_l1_fwd", L.PREC_FP32, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(f1), d, _stream())
+            # (layer 1 and the epilogue of layer 2 write the [hi | lo | hi] blocks themselves: no fp32 round trip, no split launches)
             h1 = torch.empty((R, 3 * ldd), dtype=rt.op_dtype, device=dev)
-            rt.split3([(f1, R, d, d, h1)], mode=0)
-            rt.gemm(L.EPI_STORE_F32, h1, rt.weight_split(w2), R, d, 3 * ldd, f1, d, bias=b2c, rep=3)
-            h2 = torch.empty((R, 3 * ldd), dtype=rt.op_dtype, device=dev)
-            rt.split3([(f1, R, d, d, h2)], mode=0, relu=True)
+            call("timhip_time_l1_fwd_split3", rt.prec, ptr(t2), R, d, ptr(w0c), ptr(b0c), ptr(h1), ldd, _stream())
+            h2 = (torch.empty if d == ldd else torch.zeros)((R, 3 * ldd), dtype=rt.op_dtype, device=dev)   # (padding columns stay zero)
+            rt.gemm(L.EPI_RELU_SPLIT3_T, h1, rt.weight_split(w2), R, d, 3 * ldd, h2, 3 * ldd, ld1=ldd, bias=b2c, rep=3)
             rt.gemm(L.EPI_STORE_F32, h2, rt.weight_split(w4), R, d, 3 * ldd, u3, d, bias=b4c, rep=3)
         else:
             h1 = rt.out_op(R, d, dev)
@@ -769,13 +767,12 @@ class EncoderFn(torch.autograd.Function):
             logits = torch.empty((B * n, Cn), dtype=torch.float32, device=dev)
             bias = _f32c(P["cls_head." + pname + ".bias"])
             if rt.split:   # fp32 rows of the last layer -> [hi | lo | hi] fp16 blocks, weights [hi | hi | lo]: K = 3 E
-                rows = torch.empty((B * n, E), dtype=torch.float32, device=dev)
                 rows3 = torch.empty((B * n, 3 * E), dtype=rt.op_dtype, device=dev)
                 if n > 0:
-                    head_ranges.append((s0, n, rows))
-                    head_splits.append((rows, B * n, E, E, rows3))
+                    head_ranges.append((s0, n, rows3))
                     head_gemms.append(dict(A=rows3, B=rt.weight_split(w), M=B * n, N=Cn, K=3 * E, out0=logits, ld0=Cn, bias=bias, rep=3))
-                head_saved.append((slot, pname, s0, n, None))
+                # (the backward's fp16 rows ARE the first block of rows3: T(fp32 row) = the operand copy the last LayerNorm wrote)
+                head_saved.append((slot, pname, s0, n, rows3[:, :E] if n > 0 else None))
             else:
                 rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
                 if n > 0:
@@ -784,9 +781,11 @@ class EncoderFn(torch.autograd.Function):
                 head_saved.append((slot, pname, s0, n, rows))
             outs[slot] = logits
         # the heads' row gathers and GEMMs are independent and tiny: one launch of each kind for all of them
-        if rt.split:
-            _gather_head_rows(rt, xs_f[Lyr], B, S, E, head_ranges, st, prec=L.PREC_FP32)
-            rt.split3(head_splits, mode=0)
+        if rt.split:   # gathered and split in one launch (E is a multiple of 64: d_model % 32 == 0)
+            for i0 in range(0, len(head_ranges), 6):
+                grp = head_ranges[i0:i0 + 6]
+                call("timhip_gather_split3_ranges", rt.prec, ptr(xs_f[Lyr]), B, S, E, len(grp), _iarr([r[0] for r in grp]),
+                     _iarr([r[1] for r in grp]), _parr([r[2] for r in grp]), st)
         else:
             _gather_head_rows(rt, xL_t, B, S, E, head_ranges, st)
         rt.gemm_many(L.EPI_STORE_F32, head_gemms)
@@ -862,17 +861,9 @@ class EncoderFn(torch.autograd.Function):
         # fp32 stream dx and every parameter gradient stay true-scale; only fp16 tensors carry the factor.
         gs = rt.grad_scale([_f32c(v) for v in gouts if v is not None], dev, out=gs_block)
         gs_in, gs_out = (ptr(gs), ptr(gs) + 4) if gs is not None else (None, None)
-        if rt.split:   # the forward fed the heads from the fp32 rows: gather their fp16 copies for the weight gradients
-            hranges, hs2 = [], []
-            for slot, pname, s0, n, _ in ctx.head_saved:
-                rows = torch.empty((B * n, E), dtype=rt.op_dtype, device=dev)
-                if n > 0 and g[slot] is not None:
-                    hranges.append((s0, n, rows))
-                hs2.append((slot, pname, s0, n, rows))
-            _gather_head_rows(rt, xL_t, B, S, E, hranges, st)
-            head_saved = hs2
-        else:
-            head_saved = ctx.head_saved
+        # (fp16: the forward fed the heads from the fp32 rows as [hi | lo | hi] blocks; the weight gradients read the hi block -
+        #  row stride 3 E - as their fp16 activations: no second gather)
+        head_saved = ctx.head_saved
 
         # ---- heads (their weight gradients are collected and launched grouped by row count)
         wg_items = []

@@ -70,7 +70,7 @@ for n, p in model.named_parameters():
         if (p.grad - g_dp[n]).abs().max().item() > tol:
             acc_bad += 1
             print("ACCUM MISMATCH rank", rank, n, (p.grad - g_dp[n]).abs().max().item(), g_dp[n].abs().max().item())
-print("ACCUM rank", rank, "mismatches", acc_bad, flush=True)
+os.write(1, ("ACCUM rank %d mismatches %d\n" % (rank, acc_bad)).encode())   # (one write: two ranks share the pipe)
 # every rank must hold the same averaged gradients
 flat = torch.cat([v.reshape(-1) for v in g_dp.values()]).cpu()
 other = flat.clone()
@@ -88,8 +88,8 @@ if rank == 0:
         if (a - 0.5 * b).abs().max().item() > tol:
             bad += 1
             print("MISMATCH", n, (a - 0.5 * b).abs().max().item(), b.abs().max().item())
-    print("RESULT params", len(g_dp), "mismatches", bad, "ranks_agree", same, flush=True)
+    os.write(1, ("RESULT params %d mismatches %d ranks_agree %s\n" % (len(g_dp), bad, same)).encode())
 else:
-    print("RANK1 ranks_agree", same, flush=True)
+    os.write(1, ("RANK1 ranks_agree %s\n" % same).encode())
 dist.barrier()
 dist.destroy_process_group()
