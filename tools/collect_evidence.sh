@@ -2,7 +2,7 @@
 # Evidence of one round, run on the GPU box through gpurun:  bash tools/collect_evidence.sh r03_a
 # -> gpurun_out/<tag>/: bench_default.json, kernel stats of a 35-step profiled run, PMC passes (FETCH_SIZE / WRITE_SIZE / SQ
 # counters, each in its own run with --kernel-trace only), the library calibration table.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /root/repo
@@ -16,8 +16,11 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/traffic/w -o p --o
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/sq/a -o p --output-format csv -- $B --steps 9 --warmup 2 > /dev/null 2>&1
 cd /root/repo
 python tools/rocpd_stats.py $OUT/prof/c2a_results.db > $OUT/kernel_stats.csv 2> $OUT/kernel_stats.err
+python tools/rocpd_timeline.py $OUT/prof/c2a_results.db 0 -2 > $OUT/timeline_c2a.txt 2>&1
 python tools/pmc_traffic.py $OUT/traffic $OUT/pmc_traffic.json > /dev/null 2> $OUT/pmc_traffic.err
 python tools/pmc_summary.py $OUT/sq gemm_nt_ldp gemm_nt_ld gemm_nt_pp wgrad_ld attn_fwd attn_bwd_rows ln_bwd ln_fwd8 gemm_nt_h16 > $OUT/pmc_sq_summary.txt 2>&1
+(hostname; cat /proc/loadavg; nproc) > $OUT/box.txt 2>&1
+python tools/evidence_summary.py $OUT 0 $OUT/summary.json > $OUT/summary.out 2>&1
 rm -rf $OUT/prof $OUT/traffic $OUT/sq
 ls -la $OUT
 # secondary configurations: kernel stats of the C4 training step and of C1
