@@ -500,6 +500,17 @@ def test_gemm_pingpong_kernel(prec, M, N, K, loaders, knobs):
     _check_layer_gemm_epilogues(prec, M, N, K)
 
 
+@pytest.mark.parametrize("tmw", ["4", "5"])
+@pytest.mark.parametrize("M,N,K", [(7984, 1024, 1024), (7984, 2048, 192), (9925, 1000, 192), (8000, 3072, 128)])
+def test_gemm_pingpong_row_tile_forced(M, N, K, tmw, knobs):
+    """the 128-row (TMW = 4) and the 160-row (TMW = 5) tile of the loader-wave NT kernels FORCED (TIMHIP_GEMM_TMW) on row counts
+    neither divides (round-4 advisor finding: the per-launch choice `pp_tmw` had no direct test): one tile per block and the
+    walk, every epilogue, ragged last row panel and column tile, against fp64"""
+    _pp_knobs(knobs, True)
+    knobs(TIMHIP_GEMM_TMW=tmw)
+    _check_layer_gemm_epilogues("fp16", M, N, K)
+
+
 @pytest.mark.tuning
 @pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("M,N,K", _PP_SHAPES)
