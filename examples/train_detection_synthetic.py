@@ -42,24 +42,19 @@ def main(argv=None):
     ri = lambda hi: torch.from_numpy(rs.randint(0, hi, (B, ngt))).to(dev)
     target = {"v_gt_segments": seg(), "a_gt_segments": seg(), "verb": ri(vc[0]), "noun": ri(vc[1]), "action": ri(vc[2]),
               "class_id": ri(ac)}
-    crit = losses.sigmoid_focal_loss
-    normaliser, hist = 100.0, []
+    # the loop's EMA normaliser (det train.py:230) as a device scalar the loss kernels advance in place: no host read-back per
+    # step (the reference's `max(num_pos, 1)` synchronises), and a captured step (tim_amd.graph.GraphedStep) advances it per replay
+    normaliser, hist = torch.full((), 100.0, dtype=torch.float32, device=dev), []
     for step in range(args.steps):
         output, offsets, labels, _, ious = model([inp["visual"], inp["audio"]], "encoder", inp["times"], target, label_queries=True)
-        loss = 0.0
-        for m, (cls_ids, reg_id, lab) in enumerate((((0, 1, 2), 0, labels[0]), ((3,), 1, [labels[1]]))):   # visual, audio
-            iou, off = ious[m], offsets[m]
-            valid_reg = off[:, 0] != float("inf")                       # det train.py:223
-            valid_cls = iou >= 0.0
-            w = iou.clone()
-            w[w < model.iou_threshold] = 1.0                             # :228
-            normaliser = 0.9 * normaliser + 0.1 * max(int(valid_reg.sum()), 1)
-            # classification: focal loss with IoU row weights over the valid rows, summed (:235-262) - masked form, no filtering
-            cls = sum(losses.focal_loss_sum(output[0][c], lab[j], row_weights=w, row_valid=valid_cls)
-                      for j, c in enumerate(cls_ids)) / (len(cls_ids) * normaliser)
-            reg = losses.diou_loss_sum(output[1][reg_id], torch.where(valid_reg[:, None], off, torch.zeros_like(off)),
-                                       row_valid=valid_reg) / normaliser   # :277-285
-            loss = loss + cls + reg
+        loss = None
+        for m, (cls_ids, lab) in enumerate((((0, 1, 2), labels[0]), ((3,), [labels[1]]))):   # visual, audio
+            # one modality side of det train.py:222-349 in a handful of launches: valid_cls = iou >= 0, row weight = iou below
+            # the threshold ? 1 : iou, positives = offsets != inf, focal sums of the side's heads / (heads * normaliser) + lambda_reg *
+            # DIoU sum of the positive rows / normaliser (lambda_reg = 1 here)
+            side = losses.detection_side_loss([output[0][c] for c in cls_ids], lab, output[1][m], offsets[m], ious[m], normaliser,
+                                              model.iou_threshold, lambda_reg=1.0, momentum=0.9)
+            loss = side if loss is None else loss + side
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()

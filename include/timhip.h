@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs, timhip_det_side_loss_{fwd,bwd}, timhip_sigmoid_bwd_rows, timhip_time_l1_fwd_split3, timhip_gather_split3_ranges, TIMHIP_EPI_RELU_SPLIT3_T; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
+#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs, timhip_det_side_loss_{fwd,bwd}, timhip_sigmoid_bwd_rows, timhip_time_l1_fwd_split3, timhip_gather_split3_ranges, TIMHIP_EPI_RELU_SPLIT3_T, timhip_layernorm_{fwd,bwd}2, timhip_cast_rows_pair; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
 
 enum {
   TIMHIP_OK = 0,
@@ -282,6 +282,10 @@ int timhip_grad_scale(const float* const* cot, const long long* counts, int n, f
 /* fp32 -> T with optional dropout (p_drop > 0) and zero padding to ld; scale: optional device scalar multiplied in */
 int timhip_cast_rows(int precision, const float* src, int rows, int cols, int lds, void* dst, int ld,
                      float p_drop, uint64_t seed, uint32_t site, const float* scale, void* stream);
+/* timhip_cast_rows for TWO contiguous fp32 matrices with the same row count in one launch (the two embedders' inputs: widths
+ * cols[i], operand rows of stride ld[i], dropout site sites[i]; same masks as two timhip_cast_rows calls) */
+int timhip_cast_rows_pair(int precision, const float* const* src, const int* cols, void* const* dst, const int* ld, int rows,
+                          float p_drop, uint64_t seed, const uint32_t* sites, void* stream);
 
 /* LayerNorm over the last dim of act(y): x = LN(act(y)) * w + b.
  * act: 0 none, 1 relu, 2 gelu(erf).  Writes x_f32 (may be null, row stride ldx, column
@@ -296,6 +300,16 @@ int timhip_layernorm_bwd(int precision, const float* dx, int lddx, const float* 
                          const float* stats, int rows, int cols, int act, const float* w,
                          float* dy_f32, int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed,
                          uint32_t site, float* dgamma, float* dbeta, const float* t_scale, void* stream);
+/* Two LayerNorms of the same width and activation over STACKED rows in one launch (round 5: the two modality embedders,
+ * encodings.py:21-26): rows [0, split_row) use (w, b), rows from split_row on (w2, b2); in the backward the parameter gradients of
+ * the two halves go to (dgamma, dbeta) and (dgamma2, dbeta2) - accumulated, the caller zeroes them - and split_row must be a
+ * multiple of 16 (a block of the backward owns 16 consecutive rows).  Everything else as timhip_layernorm_fwd / _bwd. */
+int timhip_layernorm_fwd2(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w, const float* b,
+                          int split_row, const float* w2, const float* b2, float* x_f32, int ldx, void* x_T, int ldt, float* stats,
+                          void* stream);
+int timhip_layernorm_bwd2(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats, int rows, int cols,
+                          int act, const float* w, int split_row, const float* w2, float* dy_f32, int lddy, void* dy_T, int ldt,
+                          float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, const float* t_scale, void* stream);
 
 /* structured attention over qkv[B*S, 3E] (T): token i attends to the F feature tokens and to
  * itself.  o[B*S,E] (T), lse[B,H,S] fp32. */

@@ -146,6 +146,9 @@ _SIGS = {
     "timhip_layer_ln_partial_bytes": (sz, [C.POINTER(TimDesc)]),
     "timhip_ln_partials_reduce": (C.c_int, [vp, i32, i32, i32, vp, vp, vp]),
     "timhip_gather_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "timhip_layernorm_fwd2": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp]),
+    "timhip_layernorm_bwd2": (C.c_int, [i32, vp, i32, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "timhip_cast_rows_pair": (C.c_int, [i32, vp, vp, vp, vp, i32, f32, u64, vp, vp]),
     "timhip_gather_split3_ranges": (C.c_int, [i32, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "timhip_scatter_ranges_add": (C.c_int, [i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "timhip_dx_init": (C.c_int, [i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]),

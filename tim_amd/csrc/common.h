@@ -439,14 +439,16 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
                       const float* w, const float* b, float* x_f32, int ldx, void* x_T, int ldt,
                       float* stats, hipStream_t s, uint8_t* mask_out = nullptr, int mask_cols = 0, float mask_p = 0.f,
                       uint64_t mask_seed = 0, uint32_t mask_site = 0,
-                      const uint32_t* run_if = nullptr);   // run_if: control words of gemm_nt_ldln_kernel; the launch does nothing unless a tile of the launch in front of it timed out
+                      const uint32_t* run_if = nullptr,   // run_if: control words of gemm_nt_ldln_kernel; the launch does nothing unless a tile of the launch in front of it timed out
+                      int split_row = 0, const float* w2 = nullptr, const float* b2 = nullptr);   // rows >= split_row (> 0) use w2 / b2
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy,
                       const float* stats, int rows, int cols, int act, const float* w, float* dy_f32,
                       int lddy, void* dy_T, int ldt, float p_drop, uint64_t seed, uint32_t site,
                       float* dgamma, float* dbeta, float* partial_ws, hipStream_t s, bool defer_colsum = false,
                       const float* t_scale = nullptr,   // t_scale: device scalar multiplied into the operand-dtype copy dy_T
                       const void* add_T = nullptr, int ldadd = 0, const float* add_scale = nullptr,   // dx += add_scale * add_T
-                      int stream16 = 0);   // bit 0: dx is a T matrix (times 1 / add_scale); bit 1: dy_f32 is written as a T matrix times t_scale
+                      int stream16 = 0,   // bit 0: dx is a T matrix (times 1 / add_scale); bit 1: dy_f32 is written as a T matrix times t_scale
+                      int split_row = 0, const float* w2 = nullptr, float* dgamma2 = nullptr, float* dbeta2 = nullptr);   // blocks from split_row on: second parameter set
 size_t tim_layernorm_bwd_ws(int rows, int cols);
 int tim_layernorm_bwd_blocks(int rows);   // partial rows one backward launch over `rows` rows writes
 int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);

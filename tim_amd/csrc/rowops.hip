@@ -211,6 +211,32 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, int rows, int co
   }
 }
 
+// two matrices with the same row count in one launch (blockIdx.z): the two modality embedders' inputs - same arithmetic and the same
+// mask indexing as cast_rows_kernel (row * quads-per-row + quad, per site), contiguous fp32 rows
+struct CastPair { const float* src[2]; void* dst[2]; int cols[2], ld[2]; uint32_t site[2]; };
+template <typename T>
+__global__ void cast_rows_pair_kernel(CastPair cp, int rows, uint32_t thr, float scale, TimSeed seed) {
+  const int z = blockIdx.z, r = blockIdx.y;
+  const float* __restrict__ src = cp.src[z];
+  T* __restrict__ dst = (T*)cp.dst[z];
+  const int cols = cp.cols[z], ld = cp.ld[z], colsq = (cols + 3) >> 2;
+  const bool vec = (cols & 3) == 0 && ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)dst) & 15) == 0);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q * 4 < ld; q += gridDim.x * blockDim.x) {
+    float k[4] = {1.f, 1.f, 1.f, 1.f};
+    if (thr != 0u && q < colsq) drop_mask4(seed, cp.site[z], (uint64_t)r * colsq + q, thr, scale, k[0], k[1], k[2], k[3]);
+    if (vec && q * 4 + 3 < cols) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * cols + q * 4);
+      store4<T>(dst + (size_t)r * ld + q * 4, v.x * k[0], v.y * k[1], v.z * k[2], v.w * k[3]);
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = q * 4 + j;
+      if (c < ld) dst[(size_t)r * ld + c] = OpT<T>::from_f(c < cols ? src[(size_t)r * cols + c] * k[j] : 0.f);
+    }
+  }
+}
+
 // d_x[r, c] = g[r, c] * mask  (backward of the feature dropout on raw inputs)
 __global__ void drop_bwd_rows_kernel(const float* __restrict__ g, int rows, int cols, int ldg, float* __restrict__ dx,
                                      int ldx, uint32_t thr, float scale, TimSeed seed, uint32_t site) {
@@ -261,16 +287,22 @@ __device__ __forceinline__ float act_grad_f(int act, float v) {
 
 constexpr int LN_MAXV_MAX = 8;  // float4 per lane: cols <= 2048 (kernels are instantiated for 1, 2, 4, 8)
 
+// A second parameter set for the rows from `row` on (round 5): the two modality embedders' LayerNorms (encodings.py:21-26; same
+// width, same activation, different gamma / beta) run as ONE launch over their stacked rows, forward and backward.  row =
+// 0x7fffffff: one parameter set.  The backward picks per BLOCK (the caller stacks the halves at a multiple of the block's rows).
+struct LnSplit { int row; const float* w2; const float* b2; float* dg2; float* db2; };
+
 template <typename T, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ y, int rows, int cols, int ldy,
                                                      int act, const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ xf, int ldx,
                                                      T* __restrict__ xt, int ldt, float* __restrict__ stats,
                                                      uint32_t* __restrict__ mbits, int mwords, uint32_t mthr,
-                                                     TimSeed mseed, uint32_t msite) {
+                                                     TimSeed mseed, uint32_t msite, LnSplit sp) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (row >= sp.row) { w = sp.w2; b = sp.b2; }
   if (mbits) {   // dropout keep-bits for the GEMM that consumes this row (common.h: drop_bits32): VALU work under the row's loads
     for (int wd = lane; wd < mwords; wd += 64)
       mbits[(size_t)row * mwords + wd] = drop_bits32(mseed, msite, ((uint64_t)row * mwords + wd) * 8, mthr);
@@ -325,7 +357,8 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w, const float* __restrict__ b,
                                                       float* __restrict__ xf, int ldx, T* __restrict__ xt, int ldt,
                                                       float* __restrict__ stats, uint32_t* __restrict__ mbits, int mwords,
-                                                      uint32_t mthr, TimSeed mseed, uint32_t msite, const uint32_t* __restrict__ run_if) {
+                                                      uint32_t mthr, TimSeed mseed, uint32_t msite, const uint32_t* __restrict__ run_if,
+                                                      LnSplit sp) {
   // the stand-by launch behind a GEMM that already normalised its rows (gemm_nt_ldln_kernel): run_if = that kernel's control
   // words {epoch, done, time-out word of even launches, of odd launches}; the launch in front of this one has advanced the epoch
   if (run_if && run_if[2 + ((run_if[0] - 1u) & 1u)] == 0u) return;
@@ -335,6 +368,8 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
   for (int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += gridDim.x * (blockDim.x >> 6)) {
   float4 v[NS][2], gw[NS][2], gb[NS][2];
   const float* yr = y + (size_t)row * ldy;
+  const float* wr = row >= sp.row ? sp.w2 : w;
+  const float* br = row >= sp.row ? sp.b2 : b;
 #pragma unroll
   for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -343,8 +378,8 @@ __global__ __launch_bounds__(256) void ln_fwd8_kernel(const float* __restrict__ 
   for (int i = 0; i < NS; ++i)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      gw[i][h] = *reinterpret_cast<const float4*>(w + i * 512 + lane * 8 + h * 4);
-      gb[i][h] = *reinterpret_cast<const float4*>(b + i * 512 + lane * 8 + h * 4);
+      gw[i][h] = *reinterpret_cast<const float4*>(wr + i * 512 + lane * 8 + h * 4);
+      gb[i][h] = *reinterpret_cast<const float4*>(br + i * 512 + lane * 8 + h * 4);
     }
   if (mbits) {   // dropout keep-bits for the GEMM that consumes this row: VALU work under the row's loads
     for (int wd = lane; wd < mwords; wd += 64)
@@ -420,8 +455,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      TimSeed seed, uint32_t site, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int rows_pb,
                                                      float* __restrict__ partial, const float* __restrict__ t_scale,
-                                                     const T* __restrict__ addt, int ldadd, const float* __restrict__ add_scale) {
+                                                     const T* __restrict__ addt, int ldadd, const float* __restrict__ add_scale,
+                                                     LnSplit sp) {
   extern __shared__ float red[];  // [4][2][cols]
+  if (blockIdx.x * rows_pb >= sp.row) { w = sp.w2; dgamma = sp.dg2; dbeta = sp.db2; }
   const float ts = t_scale ? *t_scale : 1.f;   // factor on the operand-dtype copy (gradient scale of the fp16 mode)
   // optional second addend of the incoming gradient, in the operand dtype: dx_eff = dx + add_scale * addt.  The input-gradient
   // GEMM in front of this LayerNorm then stores its (scaled) 16-bit product instead of reading the fp32 stream and writing
@@ -1172,8 +1209,13 @@ int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float
 int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w,
                       const float* b, float* xf, int ldx, void* xt, int ldt, float* stats, hipStream_t s,
                       uint8_t* mask_out, int mask_cols, float mask_p, uint64_t mask_seed, uint32_t mask_site,
-                      const uint32_t* run_if) {
+                      const uint32_t* run_if, int split_row, const float* w2, const float* b2) {
   if (!y || !w || !b || rows <= 0) return TIMHIP_EINVAL;
+  LnSplit sp{0x7fffffff, nullptr, nullptr, nullptr, nullptr};
+  if (split_row > 0 && split_row < rows) {
+    if (!w2 || !b2 || (((uintptr_t)w2 | (uintptr_t)b2) & 15)) return TIMHIP_EINVAL;
+    sp.row = split_row; sp.w2 = w2; sp.b2 = b2;
+  }
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || (xf && ldx % 4) || (xt && ldt % 4)) return TIMHIP_EUNSUPPORTED;
   dim3 grid((rows + 3) / 4);
   uint32_t* mbits = nullptr;
@@ -1184,14 +1226,14 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
     mbits = (uint32_t*)mask_out; mwords = mask_cols / 32; mthr = drop_threshold(mask_p);
   }
 #define LN_FWD(NV) hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, dim3(256), 0, s, y, rows, cols, ldy, act, w, b, \
-                                   xf, ldx, (T*)xt, ldt, stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site)
+                                   xf, ldx, (T*)xt, ldt, stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site, sp)
   const int nv = (cols + 255) / 256;
   // encoder widths (512 / 1024 / 2048 columns, 16-byte aligned rows): the 8-columns-per-lane kernel
   const bool al8 = (ldy % 4) == 0 && (!xt || ldt % 8 == 0) && (!xf || ldx % 4 == 0) &&
                    ((((uintptr_t)y | (uintptr_t)xt | (uintptr_t)xf | (uintptr_t)w | (uintptr_t)b) & 15) == 0);
   const dim3 grid8 = run_if ? dim3(min((int)grid.x, 256)) : grid;
 #define LN_FWD8(NS) hipLaunchKernelGGL((ln_fwd8_kernel<T, NS>), grid8, dim3(256), 0, s, y, rows, ldy, act, w, b, xf, ldx, (T*)xt, ldt, \
-                                     stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site, run_if)
+                                     stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site, run_if, sp)
   if (run_if && !(al8 && (cols == 512 || cols == 1024 || cols == 2048))) return TIMHIP_EUNSUPPORTED;   // (only the 8-column kernel has the switch)
   if (al8 && (cols == 512 || cols == 1024 || cols == 2048)) {
     DISPATCH_T(precision, if (cols == 512) LN_FWD8(1); else if (cols == 1024) LN_FWD8(2); else LN_FWD8(4));
@@ -1219,8 +1261,13 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,
                       float p_drop, uint64_t seed, uint32_t site, float* dgamma, float* dbeta, float* partial_ws,
                       hipStream_t s, bool defer_colsum, const float* t_scale, const void* addt, int ldadd,
-                      const float* add_scale, int stream16) {
+                      const float* add_scale, int stream16, int split_row, const float* w2, float* dgamma2, float* dbeta2) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
+  LnSplit sp{0x7fffffff, nullptr, nullptr, nullptr, nullptr};
+  if (split_row > 0 && split_row < rows) {   // (per block: the halves must meet at a multiple of the block's rows, no partials)
+    if (!w2 || partial_ws || split_row % ln_bwd_rows_per_block(rows)) return TIMHIP_EINVAL;
+    sp.row = split_row; sp.w2 = w2; sp.dg2 = dgamma2; sp.db2 = dbeta2;
+  }
   if (stream16 && (act != 0 || !h16_storage(precision) || !add_scale || !t_scale)) return TIMHIP_EUNSUPPORTED;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4) || (addt && ldadd % 4))
     return TIMHIP_EUNSUPPORTED;
@@ -1231,14 +1278,14 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
-                                   (const T*)addt, ldadd, add_scale)
+                                   (const T*)addt, ldadd, add_scale, sp)
   const int nv = (cols + 255) / 256;
 #define LN_BWD0(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, true>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
-                                   (const T*)addt, ldadd, add_scale)
+                                   (const T*)addt, ldadd, add_scale, sp)
 #define LN_BWD16(NV, SV) hipLaunchKernelGGL((ln_bwd_kernel<HT, NV, true, SV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (HT*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
-                                   (const HT*)addt, ldadd, add_scale)
+                                   (const HT*)addt, ldadd, add_scale, sp)
 #define LN_BWD16_NV(SV) do { if (nv <= 1) LN_BWD16(1, SV); else if (nv <= 2) LN_BWD16(2, SV); else if (nv <= 4) LN_BWD16(4, SV); else LN_BWD16(8, SV); } while (0)
   if (stream16) {
     DISPATCH_H16(precision, { if (stream16 == 1) LN_BWD16_NV(1); else if (stream16 == 2) LN_BWD16_NV(2); else LN_BWD16_NV(3); });
@@ -1370,6 +1417,40 @@ int timhip_layernorm_bwd(int precision, const float* dx, int lddx, const float* 
                          void* stream) {
   return tim_layernorm_bwd(precision, dx, lddx, y, ldy, stats, rows, cols, act, w, dy_f32, lddy, dy_T, ldt, p_drop,
                            seed, site, dgamma, dbeta, nullptr, (hipStream_t)stream, false, t_scale);
+}
+
+int timhip_layernorm_fwd2(int precision, const float* y, int rows, int cols, int ldy, int act, const float* w, const float* b,
+                          int split_row, const float* w2, const float* b2, float* x_f32, int ldx, void* x_T, int ldt, float* stats,
+                          void* stream) {
+  return tim_layernorm_fwd(precision, y, rows, cols, ldy, act, w, b, x_f32, ldx, x_T, ldt, stats, (hipStream_t)stream, nullptr, 0, 0.f,
+                           0, 0, nullptr, split_row, w2, b2);
+}
+
+int timhip_layernorm_bwd2(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats, int rows, int cols,
+                          int act, const float* w, int split_row, const float* w2, float* dy_f32, int lddy, void* dy_T, int ldt,
+                          float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, const float* t_scale, void* stream) {
+  return tim_layernorm_bwd(precision, dx, lddx, y, ldy, stats, rows, cols, act, w, dy_f32, lddy, dy_T, ldt, 0.f, 0, 0, dgamma, dbeta,
+                           nullptr, (hipStream_t)stream, false, t_scale, nullptr, 0, nullptr, 0, split_row, w2, dgamma2, dbeta2);
+}
+
+// two feature matrices (the two modality embedders' inputs: different widths, different dropout sites) cast in one launch
+int timhip_cast_rows_pair(int precision, const float* const* src, const int* cols, void* const* dst, const int* ld, int rows,
+                          float p_drop, uint64_t seed, const uint32_t* sites, void* stream) {
+  if (!src || !cols || !dst || !ld || !sites || rows <= 0) return TIMHIP_EINVAL;
+  CastPair cp;
+  int maxq = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (!src[i] || !dst[i] || cols[i] <= 0 || ld[i] < cols[i] || ld[i] % 4) return TIMHIP_EINVAL;
+    cp.src[i] = src[i]; cp.dst[i] = dst[i]; cp.cols[i] = cols[i]; cp.ld[i] = ld[i]; cp.site[i] = sites[i];
+    maxq = ld[i] / 4 > maxq ? ld[i] / 4 : maxq;
+  }
+  const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  dim3 grid((maxq + 255) / 256, rows, 2);
+  DISPATCH_T(precision, hipLaunchKernelGGL(cast_rows_pair_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, cp, rows, thr, scale,
+                                           TimSeed(seed)));
+  TIM_CHECK_LAUNCH();
+  return TIMHIP_OK;
 }
 
 int timhip_time_l1_fwd(int precision, const float* times, int rows, int d, const float* w, const float* b, void* h,

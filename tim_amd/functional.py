@@ -690,34 +690,52 @@ class EncoderFn(torch.autograd.Function):
         fe = "feature_encoding."
 
         # ---- modality embedders: e = LN(GELU(drop(x) W^T + b))  (encodings.py:21-26,140-153)
+        # Two modalities: their rows are STACKED ([visual | audio], R = B * nf rows each) so that the casts, the projections and the
+        # LayerNorms are one launch each (timhip_cast_rows_pair, the grouped GEMM, timhip_layernorm_fwd2; the backward's
+        # LayerNorm needs the halves to meet at a multiple of its 16-row blocks)
         emb_saved = []
         emb_gemms = []
         e_bufs = [None, None]
+        R = B * nf
         for name, slot in plan.embedders:
             x = visual if name == "visual" else audio
             if x.dim() != 3 or x.shape[0] != B or x.shape[1] != nf:
                 raise ValueError("%s input must be [B=%d, num_feats=%d, C], got %s" % (name, B, nf, tuple(x.shape)))
+        ne = len(plan.embedders)
+        pair = ne == 2 and R % 16 == 0 and os.environ.get("TIM_AMD_EMBEDDER_PAIR", "1") != "0"   # (env: A/B switch)
+        u_all = torch.empty((ne * R, d), dtype=torch.float32, device=dev)
+        e_all = torch.empty((ne * R, d), dtype=torch.float32, device=dev)
+        stats_all = torch.empty((ne * R, 2), dtype=torch.float32, device=dev)
+        x2s, xTs, sites = [], [], []
+        for i, (name, slot) in enumerate(plan.embedders):
+            x = visual if name == "visual" else audio
             Cin = x.shape[2]
-            x2 = _f32c(x).reshape(B * nf, Cin)
-            R = B * nf
-            xT = torch.empty((R, _ru(Cin)), dtype=rt.op_dtype, device=dev)
-            site = L.SITE_FEAT_V if name == "visual" else L.SITE_FEAT_A
-            call("timhip_cast_rows", rt.prec, ptr(x2), R, Cin, Cin, ptr(xT), xT.shape[1], p_feat, seed, site, None, st)
+            x2s.append(_f32c(x).reshape(R, Cin))
+            xTs.append(torch.empty((R, _ru(Cin)), dtype=rt.op_dtype, device=dev))
+            sites.append(L.SITE_FEAT_V if name == "visual" else L.SITE_FEAT_A)
+        if pair:
+            call("timhip_cast_rows_pair", rt.prec, _parr(x2s), _iarr([t.shape[1] for t in x2s]), _parr(xTs),
+                 _iarr([t.shape[1] for t in xTs]), R, p_feat, seed, (C.c_uint32 * 2)(*sites), st)
+        for i, (name, slot) in enumerate(plan.embedders):
+            x2, xT, site = x2s[i], xTs[i], sites[i]
+            Cin = x2.shape[1]
+            if not pair:
+                call("timhip_cast_rows", rt.prec, ptr(x2), R, Cin, Cin, ptr(xT), xT.shape[1], p_feat, seed, site, None, st)
             w = P[fe + name + "_embedder.1.weight"]
-            u = torch.empty((R, d), dtype=torch.float32, device=dev)
+            u = u_all[i * R:(i + 1) * R]
             emb_gemms.append(dict(A=xT, B=rt.weight(w), M=R, N=d, K=Cin, out0=u, ld0=d,
                                   bias=_f32c(P[fe + name + "_embedder.1.bias"])))
-            emb_saved.append((name, slot, xT, u, None, Cin, site))
+            emb_saved.append((name, slot, xT, u, stats_all[i * R:(i + 1) * R], Cin, site))
+            e_bufs[slot] = e_all[i * R:(i + 1) * R]
         rt.gemm_many(L.EPI_STORE_F32, emb_gemms)   # the two modality embedders (under-filled, independent): one grouped launch
-        del emb_gemms
-        for i, (name, slot, xT, u, _, Cin, site) in enumerate(emb_saved):
-            R = B * nf
-            e = torch.empty((R, d), dtype=torch.float32, device=dev)
-            stats = torch.empty((R, 2), dtype=torch.float32, device=dev)
-            rt.ln_fwd(u, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), _f32c(P[fe + name + "_embedder.3.bias"]),
-                      xf=e, ldx=d, stats=stats)
-            e_bufs[slot] = e
-            emb_saved[i] = (name, slot, xT, u, stats, Cin, site)
+        del emb_gemms, x2s
+        lnp = [(_f32c(P[fe + name + "_embedder.3.weight"]), _f32c(P[fe + name + "_embedder.3.bias"])) for name, _ in plan.embedders]
+        if pair:
+            call("timhip_layernorm_fwd2", rt.prec, ptr(u_all), 2 * R, d, d, 2, ptr(lnp[0][0]), ptr(lnp[0][1]), R, ptr(lnp[1][0]),
+                 ptr(lnp[1][1]), ptr(e_all), d, None, 0, ptr(stats_all), st)
+        else:
+            for i, (name, slot, xT, u, stats, Cin, site) in enumerate(emb_saved):
+                rt.ln_fwd(u, R, d, 2, lnp[i][0], lnp[i][1], xf=e_bufs[slot], ldx=d, stats=stats)
 
         # ---- sequence assembly (encodings.py:190-250)
         # (the CLS token / modality vectors go to the kernel by pointer: separate parameters, no concatenation launches)
@@ -816,6 +834,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.drop = (p_feat, p_seq, p_enc, seed)
         ctx.salt_epoch = _SALT["epoch"] if training else None
         ctx.emb_saved, ctx.layer_saved, ctx.head_saved, ctx.reg_saved = emb_saved, layer_saved, head_saved, reg_saved
+        ctx.emb_pair = (u_all, stats_all) if pair else None
         ctx.xs_t, ctx.lparams = xs_t, lparams
         ctx.in_shapes = (tuple(visual.shape), tuple(audio.shape))
         ctx.save_for_backward(*params)
@@ -1048,8 +1067,9 @@ class EncoderFn(torch.autograd.Function):
 
         # ---- sequence assembly backward
         d_e = [None, None]
-        for name, slot, *_ in ctx.emb_saved:
-            d_e[slot] = torch.empty((B * nf, d), dtype=torch.float32, device=dev)
+        d_e_all = torch.empty((len(ctx.emb_saved) * B * nf, d), dtype=torch.float32, device=dev)   # (stacked like the forward's rows)
+        for i, (name, slot, *_) in enumerate(ctx.emb_saved):
+            d_e[slot] = d_e_all[i * B * nf:(i + 1) * B * nf]
         d_te = torch.empty((B, T, d), dtype=torch.float32, device=dev)   # written in full by the kernel
         # cls / modality gradients: atomics accumulate straight into the parameters' views of the (zero-filled) front-end bucket
         d_cls = [G[fe + n].view(-1) for n in plan.cls_names]
@@ -1061,12 +1081,21 @@ class EncoderFn(torch.autograd.Function):
         d_inputs = {"visual": None, "audio": None}
         emb_items = []
         need_in = {"visual": ctx.needs_input_grad[3], "audio": ctx.needs_input_grad[4]}
-        for name, slot, xT, u, stats, Cin, site in ctx.emb_saved:
-            R = B * nf
+        R = B * nf
+        duT_all = rt.out_op(len(ctx.emb_saved) * R, d, dev)
+        if ctx.emb_pair is not None:   # both modalities' LayerNorm backward as one launch over the stacked rows
+            (n0, _, _, _, _, _, _), (n1, _, _, _, _, _, _) = ctx.emb_saved
+            u_all, stats_all = ctx.emb_pair
+            call("timhip_layernorm_bwd2", rt.prec, ptr(d_e_all), d, ptr(u_all), d, ptr(stats_all), 2 * R, d, 2,
+                 ptr(_f32c(P[fe + n0 + "_embedder.3.weight"])), R, ptr(_f32c(P[fe + n1 + "_embedder.3.weight"])), None, 0,
+                 ptr(duT_all), duT_all.stride(0), ptr(G[fe + n0 + "_embedder.3.weight"]), ptr(G[fe + n0 + "_embedder.3.bias"]),
+                 ptr(G[fe + n1 + "_embedder.3.weight"]), ptr(G[fe + n1 + "_embedder.3.bias"]), gs_in, st)
+        for i, (name, slot, xT, u, stats, Cin, site) in enumerate(ctx.emb_saved):
             w = P[fe + name + "_embedder.1.weight"]
-            duT = rt.out_op(R, d, dev)
-            rt.ln_bwd(d_e[slot], u, stats, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), dyt=duT,
-                      dgamma=G[fe + name + "_embedder.3.weight"], dbeta=G[fe + name + "_embedder.3.bias"], t_scale=gs_in)
+            duT = duT_all[i * R:(i + 1) * R]
+            if ctx.emb_pair is None:
+                rt.ln_bwd(d_e[slot], u, stats, R, d, 2, _f32c(P[fe + name + "_embedder.3.weight"]), dyt=duT,
+                          dgamma=G[fe + name + "_embedder.3.weight"], dbeta=G[fe + name + "_embedder.3.bias"], t_scale=gs_in)
             emb_items.append((duT, d, xT, Cin, R, G[fe + name + "_embedder.1.weight"], G[fe + name + "_embedder.1.bias"]))
             if need_in[name]:
                 gx = torch.empty((R, Cin), dtype=torch.float32, device=dev)
