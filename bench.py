@@ -571,7 +571,7 @@ def main():
         te_issue = time.perf_counter() - te0
         torch.cuda.synchronize()
         eager = {"ms_per_step": round((time.perf_counter() - te0) / ne * 1e3, 3), "host_issue_ms_per_step": round(te_issue / ne * 1e3, 3),
-                 "steps": ne, "launches_per_step": 144 if args.workload == "C2a" else None}
+                 "steps": ne, "launches_per_step": 125 if args.workload == "C2a" else None}
         if live:
             import ctypes as C
             ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int(0)
