@@ -722,6 +722,12 @@ def main():
                    "global_batch": world * B, "parallelism": "dp%d" % world, "precision": args.precision},
     }
     out["windows_per_s"] = round(world * B * args.steps / dt, 1)
+    try:   # which box, and how busy its host was (the eager figures depend on it; the replay should not)
+        import socket
+        out["box"] = {"hostname": socket.gethostname(), "loadavg_1_5_15": [round(x, 2) for x in os.getloadavg()],
+                      "host_threads": os.cpu_count(), "gpu": torch.cuda.get_device_name(dev)}
+    except Exception:  # noqa: BLE001
+        pass
     if force_dp:
         out["forced_one_rank_dp"] = "TIM_AMD_BENCH_FORCE_DP=1: the data-parallel path on a one-rank RCCL group (every collective a copy) - a test mode, not a measurement"
     if eager is not None:

@@ -1265,13 +1265,16 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
   LnSplit sp{0x7fffffff, nullptr, nullptr, nullptr, nullptr};
   if (split_row > 0 && split_row < rows) {   // (per block: the halves must meet at a multiple of the block's rows, no partials)
-    if (!w2 || partial_ws || split_row % ln_bwd_rows_per_block(rows)) return TIMHIP_EINVAL;
+    const int rpb_ = (!partial_ws && tim_knobs().ln_rpb_small >= 4) ? tim_knobs().ln_rpb_small / 4 * 4 : ln_bwd_rows_per_block(rows);
+    if (!w2 || partial_ws || split_row % rpb_) return TIMHIP_EINVAL;
     sp.row = split_row; sp.w2 = w2; sp.dg2 = dgamma2; sp.db2 = dbeta2;
   }
   if (stream16 && (act != 0 || !h16_storage(precision) || !add_scale || !t_scale)) return TIMHIP_EUNSUPPORTED;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4) || (addt && ldadd % 4))
     return TIMHIP_EUNSUPPORTED;
-  const int rpb = ln_bwd_rows_per_block(rows);
+  int rpb = ln_bwd_rows_per_block(rows);
+  // launches that end in atomics on dgamma / dbeta (no partials: the time MLP's and the embedders' LayerNorms): A/B knob of their own
+  if (!partial_ws && tim_knobs().ln_rpb_small >= 4) rpb = tim_knobs().ln_rpb_small / 4 * 4;
   dim3 grid((rows + rpb - 1) / rpb);
   const size_t shmem = (size_t)4 * 2 * cols * sizeof(float);
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
