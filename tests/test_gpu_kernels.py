@@ -724,3 +724,110 @@ def test_dx_init_adds_up_slabs():
     torch.cuda.synchronize()
     assert torch.equal(dx.view(B, S, E), want)
     assert L.load().timhip_dx_init_slabs(B, S, F, E, L.ptr(feats), 1, ia([11]), ia([4]), pa(rows[:1]), ia([0]), L.ptr(dx), st()) != 0
+
+
+# ---- round 5: the fused / paired entry points against the launches they replace (bit for bit) ----------------------------------
+@pytest.mark.parametrize("prec", ["fp16", "bf16", "fp32"])
+def test_cast_rows_pair_is_two_cast_rows(prec):
+    """timhip_cast_rows_pair: two feature matrices of different widths, one launch - the same operand rows and the same dropout
+    masks (per site) as two timhip_cast_rows calls"""
+    rt = Runtime(prec)
+    R, cols, sites, seed, p = 96, [24, 40], [L.SITE_FEAT_V, L.SITE_FEAT_A], 0x1234567, 0.5
+    src = [rnd(R, c, seed=3 + i).to(DEV) for i, c in enumerate(cols)]
+    want = [torch.empty((R, _ru(c)), dtype=rt.op_dtype, device=DEV) for c in cols]
+    got = [torch.full((R, _ru(c)), 7.0, dtype=rt.op_dtype, device=DEV) for c in cols]
+    for s_, c, w, site in zip(src, cols, want, sites):
+        L.call("timhip_cast_rows", rt.prec, L.ptr(s_), R, c, c, L.ptr(w), w.shape[1], p, seed, site, None, st())
+    pa = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    ia = lambda v: (C.c_int * len(v))(*v)
+    L.call("timhip_cast_rows_pair", rt.prec, pa(src), ia(cols), pa(got), ia([g.shape[1] for g in got]), R, p, seed,
+           (C.c_uint32 * 2)(*sites), st())
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    assert not torch.equal(got[0][:, :24], got[1][:, :24])
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_layernorm_pair_is_two_layernorms(prec):
+    """timhip_layernorm_fwd2 / _bwd2: two LayerNorms (GELU in front, as the modality embedders) over stacked rows with a second
+    parameter set from the split row on - outputs, statistics, operand-dtype gradients and both parameter-gradient pairs equal two
+    separate launches (the parameter gradients up to the order of their atomics)"""
+    rt = Runtime(prec)
+    R, d = 160, 512
+    u = rnd(2 * R, d, seed=1).to(DEV)
+    g = rnd(2 * R, d, seed=2).to(DEV)
+    ws = [(1.0 + 0.1 * rnd(d, seed=3 + i)).to(DEV) for i in range(2)]
+    bs = [(0.1 * rnd(d, seed=5 + i)).to(DEV) for i in range(2)]
+    e_w, st_w = torch.empty(2 * R, d, device=DEV), torch.empty(2 * R, 2, device=DEV)
+    e_g, st_g = torch.empty_like(e_w), torch.empty_like(st_w)
+    for i in range(2):
+        sl = slice(i * R, (i + 1) * R)
+        rt.ln_fwd(u[sl], R, d, 2, ws[i], bs[i], xf=e_w[sl], ldx=d, stats=st_w[sl])
+    L.call("timhip_layernorm_fwd2", rt.prec, L.ptr(u), 2 * R, d, d, 2, L.ptr(ws[0]), L.ptr(bs[0]), R, L.ptr(ws[1]), L.ptr(bs[1]),
+           L.ptr(e_g), d, None, 0, L.ptr(st_g), st())
+    torch.cuda.synchronize()
+    assert torch.equal(e_w, e_g) and torch.equal(st_w, st_g)
+    dy_w = torch.zeros((2 * R, d), dtype=rt.op_dtype, device=DEV)
+    dy_g = torch.zeros_like(dy_w)
+    dgw = [torch.zeros(d, device=DEV) for _ in range(4)]
+    dgg = [torch.zeros(d, device=DEV) for _ in range(4)]
+    for i in range(2):
+        sl = slice(i * R, (i + 1) * R)
+        rt.ln_bwd(g[sl], u[sl], st_w[sl], R, d, 2, ws[i], dyt=dy_w[sl], dgamma=dgw[2 * i], dbeta=dgw[2 * i + 1])
+    L.call("timhip_layernorm_bwd2", rt.prec, L.ptr(g), d, L.ptr(u), d, L.ptr(st_g), 2 * R, d, 2, L.ptr(ws[0]), R, L.ptr(ws[1]), None, 0,
+           L.ptr(dy_g), d, L.ptr(dgg[0]), L.ptr(dgg[1]), L.ptr(dgg[2]), L.ptr(dgg[3]), None, st())
+    torch.cuda.synchronize()
+    assert torch.equal(dy_w, dy_g)
+    for a, b in zip(dgw, dgg):
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+    assert L.load().timhip_layernorm_bwd2(rt.prec, L.ptr(g), d, L.ptr(u), d, L.ptr(st_g), 2 * R, d, 2, L.ptr(ws[0]), R + 8, L.ptr(ws[1]),
+                                          None, 0, L.ptr(dy_g), d, L.ptr(dgg[0]), L.ptr(dgg[1]), L.ptr(dgg[2]), L.ptr(dgg[3]), None,
+                                          st()) != 0      # the halves must meet at a multiple of the 16-row blocks
+
+
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("d", [32, 512])
+def test_split_operands_written_by_their_producers(prec, d):
+    """round 5: time-MLP layer 1 (timhip_time_l1_fwd_split3), the relu + split epilogue (TIMHIP_EPI_RELU_SPLIT3_T) and the heads'
+    row gather (timhip_gather_split3_ranges) write [hi | lo | hi] blocks themselves - bit for bit what timhip_split3_many (mode 0)
+    made of the fp32 values in a second launch"""
+    rt = Runtime(prec)
+    R, ldd = 200, _ru(d)
+    t2 = torch.rand(R, 2, generator=torch.Generator().manual_seed(1)).to(DEV)
+    w0, b0 = rnd(d, 2, seed=2).to(DEV), rnd(d, seed=3).to(DEV)
+    f1 = torch.empty(R, d, device=DEV)
+    L.call("timhip_time_l1_fwd", L.PREC_FP32, L.ptr(t2), R, d, L.ptr(w0), L.ptr(b0), L.ptr(f1), d, st())
+    want = torch.zeros((R, 3 * ldd), dtype=rt.op_dtype, device=DEV)
+    rt.split3([(f1, R, d, d, want)], mode=0)
+    got = torch.full((R, 3 * ldd), 5.0, dtype=rt.op_dtype, device=DEV)
+    L.call("timhip_time_l1_fwd_split3", rt.prec, L.ptr(t2), R, d, L.ptr(w0), L.ptr(b0), L.ptr(got), ldd, st())
+    torch.cuda.synchronize()
+    assert torch.equal(want, got)
+    # GEMM epilogue: relu(A W^T + b) as split blocks
+    A, _ = to_op(rt, rnd(R, 64, seed=4))
+    W, _ = to_op(rt, rnd(d, 64, seed=5, scale=0.2))
+    bias = rnd(d, seed=6).to(DEV)
+    f2 = torch.empty(R, d, device=DEV)
+    rt.gemm(L.EPI_STORE_F32, A, W, R, d, 64, f2, d, bias=bias)
+    want2 = torch.zeros((R, 3 * ldd), dtype=rt.op_dtype, device=DEV)
+    rt.split3([(f2, R, d, d, want2)], mode=0, relu=True)
+    got2 = torch.zeros((R, 3 * ldd), dtype=rt.op_dtype, device=DEV)
+    rt.gemm(L.EPI_RELU_SPLIT3_T, A, W, R, d, 64, got2, 3 * ldd, ld1=ldd, bias=bias)
+    torch.cuda.synchronize()
+    assert torch.equal(want2, got2)
+    if d % 64 == 0:   # heads: rows gathered from the fp32 stream and split in one pass
+        B, S, E = 3, 11, d
+        x = rnd(B * S, E, seed=7).to(DEV)
+        ranges = [(4, 3), (8, 2)]
+        ia = lambda v: (C.c_int * len(v))(*v)
+        pa = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        rows = [torch.empty(B * n, E, device=DEV) for _, n in ranges]
+        L.call("timhip_gather_ranges", L.PREC_FP32, L.ptr(x), B, S, E, 2, ia([r[0] for r in ranges]), ia([r[1] for r in ranges]), pa(rows), st())
+        want3 = [torch.empty((B * n, 3 * E), dtype=rt.op_dtype, device=DEV) for _, n in ranges]
+        rt.split3([(r_, B * n, E, E, w_) for r_, (_, n), w_ in zip(rows, ranges, want3)], mode=0)
+        got3 = [torch.empty((B * n, 3 * E), dtype=rt.op_dtype, device=DEV) for _, n in ranges]
+        L.call("timhip_gather_split3_ranges", rt.prec, L.ptr(x), B, S, E, 2, ia([r[0] for r in ranges]), ia([r[1] for r in ranges]), pa(got3), st())
+        torch.cuda.synchronize()
+        for a, b in zip(want3, got3):
+            assert torch.equal(a, b)
