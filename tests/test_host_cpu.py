@@ -215,3 +215,46 @@ def test_layer_split_mode_is_validated(monkeypatch):
     monkeypatch.setenv("TIM_AMD_SPLIT_LAYER_WEIGHTS", "all")
     assert Runtime("fp16").layer_split == ("in", "out", "l1", "l2")
     assert Runtime("bf16").layer_split == ()                     # (the switch is an fp16-mode option)
+
+
+def test_gradient_bucket_layout_is_cached_and_consistent():
+    """tim.py:_BucketLayout (round 5: computed once per model instead of per backward pass): every parameter's view has its shape
+    and lies inside its bucket, buckets are contiguous in completion order, the pieces of the one split call tile the allocation,
+    and the zero fills expressed through those pieces cover exactly the ranges the layout lists (whole accumulated buckets;
+    LayerNorm slices, slot paddings and alignment tails of the overwritten layer buckets)."""
+    import torch
+    from tim_amd.tim import TIM, _BucketLayout, _GradBuckets
+    cfg = H.tiny_cfg("recognition", "audio_visual", "audio_visual", True)
+    m = TIM(cfg.num_class, visual_input_dim=cfg.visual_input_dim, audio_input_dim=cfg.audio_input_dim, d_model=cfg.d_model,
+            nhead=cfg.nhead, num_layers=cfg.num_layers, num_feats=cfg.num_feats)
+    names, params = m._encoder_param_names, m._encoder_param_list()
+    for overwrite in (False, True):
+        lay = _BucketLayout(names, params, m._bucket_of, overwrite)
+        assert sum(lay.piece_sizes) == lay.total and lay.order[0] == "heads" and lay.order[-1] == "front"
+        starts, pos = [], 0
+        for sz in lay.piece_sizes:
+            starts.append(pos)
+            pos += sz
+        got = set()
+        for kind, k, rng in lay.zero_spec:
+            if kind == "flat":
+                got.add(lay.bucket[k])
+            elif kind == "piece":
+                got.add((starts[k], lay.piece_sizes[k]))
+            else:
+                got.add((starts[k] + rng[0], rng[1] - rng[0]))
+        assert got == set(lay.zero)
+        gb = m._alloc_grad_buckets(names, params, torch.device("cpu"), layer_overwrite=overwrite)
+        assert m._alloc_grad_buckets(names, params, torch.device("cpu"), layer_overwrite=overwrite).base.numel() == gb.base.numel()
+        assert len(m._bucket_layouts) <= 2                       # one layout per overwrite mode, reused
+        ref = _GradBuckets(m.rt, names, params, torch.device("cpu"), m._bucket_of, overwrite)   # (a fresh layout: same result)
+        for n, p in zip(names, params):
+            v = gb.views[n]
+            assert v.shape == p.shape and v.is_contiguous()
+            off = (v.data_ptr() - gb.base.data_ptr()) // 4
+            st, nb = lay.bucket[m._bucket_of(n)]
+            assert st <= off and off + p.numel() <= st + nb
+            assert (ref.views[n].data_ptr() - ref.base.data_ptr()) // 4 == off
+        # consecutive buckets are contiguous
+        for a, b in zip(lay.order, lay.order[1:]):
+            assert lay.bucket[a][0] + lay.bucket[a][1] == lay.bucket[b][0]

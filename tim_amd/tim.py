@@ -174,54 +174,113 @@ class _AVGAParams(nn.Module):
         return torch.einsum("rs,rsc->rc", attn, cells).reshape(B, T, C)
 
 
-class _GradBuckets:
-    def __init__(self, rt, names, params, dev, bucket_of, layer_overwrite=False, extra_zero=()):
-        """layer_overwrite: the encoder layers' Linear weight/bias gradients are written by the kernels
-        (TIMHIP_DESC_WGRAD_OVERWRITE); their buckets are left uninitialised except the LayerNorm slices,
-        which the kernels accumulate into."""
-        self.rt = rt
-        self.views = {}
-        self.flat = {}
-        self.members = {}   # bucket -> [(parameter, its gradient view)]: what a data-parallel hook needs to fold in earlier,
-        #                     locally accumulated .grad values (tim_amd/dp.py: gradient accumulation under no_sync)
+class _BucketLayout:
+    """Where every parameter's gradient lives inside ONE flat allocation - computed once per (parameter names, shapes, overwrite
+    mode) and reused by every backward pass (round 5: building it per pass cost 0.5 ms of host time per C2a step, a sixth of the
+    eager step's issue time).  Buckets in the order the backward completes them (heads, last layer ... first layer, front end):
+    consecutive buckets are contiguous, so the data-parallel exchange can take several as one range; 256-byte aligned bucket
+    starts (the tail padding is exchanged too)."""
+
+    def __init__(self, names, params, bucket_of, layer_overwrite):
         sizes = {}
         for n, p in zip(names, params):
             b = bucket_of(n)
             sizes[b] = sizes.get(b, 0) + (p.numel() + 3) // 4 * 4
-        # ONE allocation, the buckets laid out in the order the backward completes them (heads, last layer ... first layer,
-        # front end): consecutive buckets are contiguous, so the data-parallel exchange can take several as one range
+
         def order(b):
             return (0, 0) if b == "heads" else ((1, -int(b[5:])) if b.startswith("layer") else (2, 0))
         self.order = sorted(sizes, key=order)
-        total = sum((sizes[b] + 63) // 64 * 64 for b in self.order)
-        self.base = torch.empty(total, dtype=torch.float32, device=dev)
+        self.bucket = {}                 # bucket -> (start, padded size)
         pos = 0
         for b in self.order:
-            n = (sizes[b] + 63) // 64 * 64                 # 256-byte aligned bucket starts (the tail padding is exchanged too)
-            self.flat[b] = self.base[pos:pos + n]
+            n = (sizes[b] + 63) // 64 * 64
+            self.bucket[b] = (pos, n)
             pos += n
+        self.total = pos
         # zero fills: whole buckets the kernels accumulate into (heads, front end), and of the overwritten layer buckets only
-        # the pieces nobody writes (alignment tails) or that are accumulated into (LayerNorm slices) - ONE multi-tensor launch
-        # for all the small pieces (they used to be a fill launch per layer)
-        # (`extra_zero`: other small buffers of the same backward pass that must start at zero - they ride in the same launch)
-        accumulated = list(extra_zero)
+        # the pieces nobody writes (alignment tails) or that are accumulated into (LayerNorm slices)
+        self.zero = []                   # (start, length) inside the flat allocation
         for b in self.order:
+            st, n = self.bucket[b]
             if not (layer_overwrite and b.startswith("layer")):
-                accumulated.append(self.flat[b])
-            elif self.flat[b].numel() > sizes[b]:
-                accumulated.append(self.flat[b][sizes[b]:])
+                self.zero.append((st, n))
+            elif n > sizes[b]:
+                self.zero.append((st + sizes[b], n - sizes[b]))
+        self.param = []                  # per parameter, in `names` order: (name, bucket, start, numel, shape)
         off = {b: 0 for b in sizes}
         for n, p in zip(names, params):
             b = bucket_of(n)
-            self.views[n] = self.flat[b][off[b]:off[b] + p.numel()].view(p.shape)
-            self.members.setdefault(b, []).append((p, self.views[n]))
+            st = self.bucket[b][0] + off[b]
+            self.param.append((n, b, st, p.numel(), tuple(p.shape)))
             if layer_overwrite and b.startswith("layer"):
                 if ".norm" in n:
-                    accumulated.append(self.views[n])
+                    self.zero.append((st, p.numel()))
                 pad = (p.numel() + 3) // 4 * 4 - p.numel()
                 if pad:                                   # alignment padding is part of the all-reduced buffer
-                    accumulated.append(self.flat[b][off[b] + p.numel():off[b] + p.numel() + pad])
+                    self.zero.append((st + p.numel(), pad))
             off[b] += (p.numel() + 3) // 4 * 4
+        # the flat allocation as consecutive pieces in memory order - per bucket its parameters' slots (padded to 4 elements) and
+        # then its alignment tail - so that ONE split call yields every piece; piece_of[i] = the piece of parameter i
+        by_bucket = {b: [] for b in self.order}
+        for i, pr in enumerate(self.param):
+            by_bucket[pr[1]].append(i)
+        self.piece_sizes, self.piece_of = [], [0] * len(self.param)
+        for b in self.order:
+            used = 0
+            for i in by_bucket[b]:
+                slot = (self.param[i][3] + 3) // 4 * 4
+                self.piece_of[i] = len(self.piece_sizes)
+                self.piece_sizes.append(slot)
+                used += slot
+            if self.bucket[b][1] > used:
+                self.piece_sizes.append(self.bucket[b][1] - used)
+        # the zero fills in terms of those pieces (no fresh slices per pass): whole buckets, whole pieces, or a slot's padding
+        starts, pos_ = [], 0
+        for sz in self.piece_sizes:
+            starts.append(pos_)
+            pos_ += sz
+        piece_at = {st: k for k, st in enumerate(starts)}
+        bucket_at = {st: b for b, (st, n) in self.bucket.items()}
+        self.zero_spec = []
+        for st, n in self.zero:
+            if st in bucket_at and self.bucket[bucket_at[st]][1] == n:
+                self.zero_spec.append(("flat", bucket_at[st], 0))
+            elif st in piece_at and self.piece_sizes[piece_at[st]] == n:
+                self.zero_spec.append(("piece", piece_at[st], 0))
+            else:   # the padding behind a parameter inside its slot, or a LayerNorm slice narrower than its slot
+                k = max(kk for kk, s0 in enumerate(starts) if s0 <= st)
+                self.zero_spec.append(("sub", k, (st - starts[k], st - starts[k] + n)))
+
+
+class _GradBuckets:
+    def __init__(self, rt, names, params, dev, bucket_of, layer_overwrite=False, extra_zero=(), layout=None):
+        """layer_overwrite: the encoder layers' Linear weight/bias gradients are written by the kernels
+        (TIMHIP_DESC_WGRAD_OVERWRITE); their buckets are left uninitialised except the LayerNorm slices,
+        which the kernels accumulate into."""
+        self.rt = rt
+        lay = layout if layout is not None else _BucketLayout(names, params, bucket_of, layer_overwrite)
+        self.order = lay.order
+        # ONE allocation; parameter `.grad`s are views into it
+        self.base = torch.empty(lay.total, dtype=torch.float32, device=dev)
+        self.flat = {b: self.base[st:st + n] for b, (st, n) in lay.bucket.items()}
+        self.views = {}
+        self.members = {}   # bucket -> [(parameter, its gradient view)]: what a data-parallel hook needs to fold in earlier,
+        #                     locally accumulated .grad values (tim_amd/dp.py: gradient accumulation under no_sync)
+        base = self.base
+        pieces = base.split(lay.piece_sizes)      # one call for all slots (a slice + a view per parameter cost 0.25 ms per pass)
+        want_members = rt.bucket_hook is not None     # (only a data-parallel hook reads them)
+        views, members = self.views, self.members
+        for (n, b, st, numel, shape), p, k in zip(lay.param, params, lay.piece_of):
+            pc = pieces[k]
+            v = (pc if pc.numel() == numel else pc[:numel]).view(shape)
+            views[n] = v
+            if want_members:
+                members.setdefault(b, []).append((p, v))
+        # ONE multi-tensor launch for all the pieces that must start at zero
+        # (`extra_zero`: other small buffers of the same backward pass - they ride in the same launch)
+        accumulated = list(extra_zero)
+        for kind, k, rng in lay.zero_spec:
+            accumulated.append(self.flat[k] if kind == "flat" else (pieces[k] if kind == "piece" else pieces[k][rng[0]:rng[1]]))
         if accumulated:
             torch._foreach_zero_(accumulated)
 
@@ -400,7 +459,11 @@ class TIM(nn.Module):
         return "heads"
 
     def _alloc_grad_buckets(self, names, params, dev, layer_overwrite=False, extra_zero=()):
-        return _GradBuckets(self.rt, names, params, dev, self._bucket_of, layer_overwrite, extra_zero)
+        key = (bool(layer_overwrite), id(names), len(names))     # (`names`: the model's persistent parameter-name list)
+        lay = self.__dict__.setdefault("_bucket_layouts", {}).get(key)
+        if lay is None or lay.param[0][0] != names[0] or lay.param[-1][0] != names[-1]:   # (an id reused by another list)
+            lay = self._bucket_layouts[key] = _BucketLayout(names, params, self._bucket_of, layer_overwrite)
+        return _GradBuckets(self.rt, names, params, dev, self._bucket_of, layer_overwrite, extra_zero, layout=lay)
 
     # ---- the reference's public interface ------------------------------------------------------------
     def forward_encoder(self, inputs, time_encodings, num_v_queries, num_a_queries):
