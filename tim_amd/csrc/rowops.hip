@@ -100,33 +100,61 @@ __global__ __launch_bounds__(256) void cast_weights_kernel(CastBatch cb) {
   const float* __restrict__ src = it.src;
   T* __restrict__ plain = (T*)it.plain;
   T* __restrict__ tr = (T*)it.tr;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  // 16-bit copies leave in 16-byte stores where alignment allows (round 5: 8 columns / 8 rows per lane; the leading dimensions
+  // are multiples of 64 elements): a lane owns 8 consecutive columns of a row on the way in, 8 consecutive rows of a column on
+  // the way out
+  constexpr bool W16 = sizeof(T) == 2;
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;      // 8 column octets x 32 rows per pass
   const bool vec = (cols & 3) == 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < 2; ++i) {
+    const int r = r0 + ty + 32 * i, c = c0 + tx * 8;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = 0.f;
     if (r < rows) {
-      if (vec && c + 3 < cols) {
-        v = *reinterpret_cast<const float4*>(src + (size_t)r * cols + c);
+      if (vec && c + 7 < cols) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (size_t)r * cols + c);
+        const float4 b = *reinterpret_cast<const float4*>(src + (size_t)r * cols + c + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
       } else {
-        if (c < cols) v.x = src[(size_t)r * cols + c];
-        if (c + 1 < cols) v.y = src[(size_t)r * cols + c + 1];
-        if (c + 2 < cols) v.z = src[(size_t)r * cols + c + 2];
-        if (c + 3 < cols) v.w = src[(size_t)r * cols + c + 3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c + u < cols) v[u] = src[(size_t)r * cols + c + u];
       }
-      if (c < ldp) store4<T>(plain + (size_t)r * ldp + c, v.x, v.y, v.z, v.w);  // ldp % 64 == 0: whole quads
+      if (c < ldp) {   // ldp % 64 == 0: whole octets
+        if constexpr (W16) {
+          typedef T v8_t __attribute__((ext_vector_type(8)));
+          v8_t pk;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pk[u] = OpT<T>::from_f(v[u]);
+          *reinterpret_cast<v8_t*>(plain + (size_t)r * ldp + c) = pk;
+        } else {
+          store4<T>(plain + (size_t)r * ldp + c, v[0], v[1], v[2], v[3]);
+          store4<T>(plain + (size_t)r * ldp + c + 4, v[4], v[5], v[6], v[7]);
+        }
+      }
     }
-    float* t = &tile[ty + 16 * i][tx * 4];
-    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    float* t = &tile[ty + 32 * i][tx * 8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = v[u];
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = c0 + ty + 16 * i, r = r0 + tx * 4;
-    if (c < cols && r < ldt) {
-      const int lc = ty + 16 * i, lr = tx * 4;
-      store4<T>(tr + (size_t)c * ldt + r, tile[lr][lc], tile[lr + 1][lc], tile[lr + 2][lc], tile[lr + 3][lc]);
+  for (int i = 0; i < 2; ++i) {
+    const int lc = ty + 32 * i, lr = tx * 8;
+    const int c = c0 + lc, r = r0 + lr;
+    if (c < cols && r < ldt) {    // ldt % 64 == 0: whole octets
+      if constexpr (W16) {
+        typedef T v8_t __attribute__((ext_vector_type(8)));
+        v8_t pk;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pk[u] = OpT<T>::from_f(tile[lr + u][lc]);
+        *reinterpret_cast<v8_t*>(tr + (size_t)c * ldt + r) = pk;
+      } else {
+        store4<T>(tr + (size_t)c * ldt + r, tile[lr][lc], tile[lr + 1][lc], tile[lr + 2][lc], tile[lr + 3][lc]);
+        store4<T>(tr + (size_t)c * ldt + r + 4, tile[lr + 4][lc], tile[lr + 5][lc], tile[lr + 6][lc], tile[lr + 7][lc]);
+      }
     }
   }
 }
