@@ -152,8 +152,8 @@ class Runtime:
         weight is found stale, every stale weight this runtime has seen is refreshed in the same launch
         (after an optimizer step that is all of them: one kernel instead of one per weight)."""
         ent = self._wcache.get(id(p))
-        ver = (p.data_ptr(), p._version)
-        if ent is None or ent[0] != ver or ent[1].device != p.device:
+        # (same storage address and version = same contents on the same device: no separate device comparison on the fast path)
+        if ent is None or ent[0] != (p.data_ptr(), p._version):
             self._wparams[id(p)] = weakref.ref(p)
             self._refresh(p.device)
             ent = self._wcache[id(p)]

@@ -272,7 +272,9 @@ class _GradBuckets:
         views, members = self.views, self.members
         for (n, b, st, numel, shape), p, k in zip(lay.param, params, lay.piece_of):
             pc = pieces[k]
-            v = (pc if pc.numel() == numel else pc[:numel]).view(shape)
+            v = pc if pc.numel() == numel else pc[:numel]
+            if len(shape) != 1:                      # (biases / LayerNorm vectors: the piece is the view)
+                v = v.view(shape)
             views[n] = v
             if want_members:
                 members.setdefault(b, []).append((p, v))
