@@ -498,7 +498,7 @@ def main():
         # fp32 on the wire = the exact mean the reference's DistributedDataParallel computes (the default of tim_amd.dp);
         # TIM_AMD_DP_WIRE=bf16 selects the half-traffic exchange (bf16 payload, fp32 accumulation, all-to-all form: eager only)
         wire = torch.bfloat16 if os.environ.get("TIM_AMD_DP_WIRE", "fp32") == "bf16" else torch.float32
-        run_model = DataParallel(model, wire_dtype=wire, force=force_dp)
+        run_model = DataParallel(model, wire_dtype=wire, force=force_dp, buckets_per_exchange=int(os.environ.get("TIM_AMD_DP_BUCKETS", "4")))
     batch = make_batch(cfg, B, 0 if detection else nv, na, seed=100 + rank, dev=dev)  # each rank its own shard of windows
     R = {"target": make_det_targets(cfg, B, 6, 5 + rank, dev)} if (detection and args.det_train) else [None]
 
