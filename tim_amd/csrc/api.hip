@@ -166,6 +166,7 @@ void read_knobs(TimKnobs& k) {
   k.gemm_tmw = env_int("TIMHIP_GEMM_TMW", 0);
   k.ln_rpb_small = env_int("TIMHIP_LN_RPB_SMALL", 0);
   k.gemm_pp_min = env_int("TIMHIP_GEMM_PP_MIN_TILES", 192);
+  k.attn_ks = env_int("TIMHIP_ATTN_KS", 1);
 }
 }  // namespace
 const TimKnobs& tim_knobs() {

@@ -24,8 +24,15 @@ struct AttnArgsM {
 };
 #ifdef TIMHIP_TUNING
 #define ATT_ABL(a, bit) (((a).abl & (bit)) != 0)
+// (tuning, abl bit 16, fused form: wave 0's shader-clock stamps per block into the workspace - tools/attn_one.py prints the phases)
+#define ATT_STAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (FUSED && ATT_ABL(a, 16) && tid == 0)                                                                      \
+      reinterpret_cast<unsigned long long*>(dS_scr)[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
 #else
 #define ATT_ABL(a, bit) false
+#define ATT_STAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
@@ -59,7 +66,13 @@ __device__ __forceinline__ void keep_pair(const AttnArgsM& a, uint64_t rowbase, 
   for (int u = 0; u < 4; ++u) { k0[u] = g ? oth[u] : own[u]; k1[u] = g ? own[u] : oth[u]; }
 }
 
-template <typename HT, int DH, int NJB, bool FUSED = false>
+// KS (round 5, fused form only): phase 1 in two halves around one block barrier, so that all EIGHT waves work and no SIMD carries
+// two whole row blocks (S = 155: five 32-row blocks on four SIMDs used to put two of them on one SIMD, three waves idle):
+//   1a  item (row block, key half): S^T / dP^T / dS / P~ of 64 of the 128 keys -> LDS (ten items over the eight waves);
+//   1b  item (row block, head-dim half): dQ = dS K over all keys for 64 of the 128 head-dim columns, dS read back from LDS
+//       in the k-order of tr_frag (two 8-byte reads per fragment) - the same values in the same accumulation order as the
+//       one-wave form, so the results are bit-identical.
+template <typename HT, int DH, int NJB, bool FUSED = false, bool KS = false>
 __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv, const HT* __restrict__ o,
                                                      const float* __restrict__ lse, const HT* __restrict__ d_o,
                                                      HT* __restrict__ dqkv, HT* __restrict__ dS_scr,
@@ -86,64 +99,130 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
   HT* dSs = dS_scr + (size_t)bh * S * FP;
   HT* Pts = Pt_scr + (size_t)bh * S * FP;
   // (K and V staged as a pair: every load of both tiles ahead of the first LDS write - one memory latency, not two)
-  stage_tile_pair<DH>(sK, base + E, sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
-  __syncthreads();
+  ATT_STAMP(0);
+  // key-split form: this thread's 16-byte chunks of the Q / dO rows (row (tid >> 4) + 32 sw, chunk tid & 15) - requested before
+  // the K / V staging, written to LDS by phase 0, and kept in registers for phase 2 (which wants exactly these chunks again)
+  constexpr int NSW = (FUSED && KS) ? 6 : 1;   // S <= 192 (fused_fits)
+  constexpr int NKV = (FUSED && KS) ? 4 : 1;   // 128 key rows / 32
+  vec8<HT> qv[NSW], dv[NSW], kst[NKV], vst[NKV];
+  vec8<HT> ov, kv, vv;   // one sweep's O / own-key / own-value chunks: requested one pipeline step ahead of their use
+  auto load_okv = [&](int sw) {
+    const int c = tid & 15, row = (tid >> 4) + 32 * sw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ov[e] = (HT)0.f; kv[e] = (HT)0.f; vv[e] = (HT)0.f; }
+    if (row < S) {
+      const size_t ro = ATT_ABL(a, 4) ? (size_t)(row & 1) : (size_t)row;   // (tuning: operand rows from two cached rows)
+      ov = *reinterpret_cast<const vec8<HT>*>(obase + ro * E + c * 8);
+      if (row >= F) {
+        kv = *reinterpret_cast<const vec8<HT>*>(base + ro * ld + E + c * 8);
+        vv = *reinterpret_cast<const vec8<HT>*>(base + ro * ld + 2 * E + c * 8);
+      }
+    }
+  };
+  if constexpr (FUSED && KS) {
+    // request order = arrival order: the K / V tiles, then the Q / dO row sweeps 0, 1, ... - the products on row block 0 start
+    // while the later sweeps are still in flight (phase 1 below)
+    const int c = tid & 15, r0 = tid >> 4;
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int row = r0 + 32 * u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kst[u][e] = (HT)0.f; vst[u][e] = (HT)0.f; }
+      if (row < F) {
+        const size_t ro = ATT_ABL(a, 4) ? (size_t)(row & 1) : (size_t)row;
+        kst[u] = *reinterpret_cast<const vec8<HT>*>(base + ro * ld + E + c * 8);
+        vst[u] = *reinterpret_cast<const vec8<HT>*>(base + ro * ld + 2 * E + c * 8);
+      }
+    }
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+      const int row = r0 + 32 * sw;
+      const bool valid = row < S;
+      const size_t ro = (size_t)(valid ? (ATT_ABL(a, 4) ? (row & 1) : row) : 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qv[sw][e] = (HT)0.f; dv[sw][e] = (HT)0.f; }
+      if (valid) {
+        qv[sw] = *reinterpret_cast<const vec8<HT>*>(base + ro * ld + c * 8);
+        dv[sw] = *reinterpret_cast<const vec8<HT>*>(dobase + ro * E + c * 8);
+      }
+      if (sw == 0) load_okv(0);
+    }
+    {   // the rows' log-sum-exp, one thread per row
+      float* sL0 = reinterpret_cast<float*>(sP + ((S + 31) & ~31) * FP * 2) + ((S + 31) & ~31);
+      if (tid < ((S + 31) & ~31)) sL0[tid] = tid < S ? lsebase[tid] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NKV; ++u) {
+      const int to = tile_off<128>(r0 + 32 * u, c);
+      *reinterpret_cast<vec8<HT>*>(sK + to) = kst[u];
+      *reinterpret_cast<vec8<HT>*>(sV + to) = vst[u];
+    }
+  } else {
+    stage_tile_pair<DH>(sK, base + E, sV, base + 2 * E, ld, FP, F, tid, blockDim.x);
+    __syncthreads();
+  }
+  ATT_STAMP(1);
 
   const int li = lane & 31, g = lane >> 5;
   const int nrb = FUSED ? ((S + 31) >> 5) : min((S + 31) >> 5, (part + 1) * a.rper);
 
   // ---------------- phase 1 ----------------
   const int nwaves = blockDim.x >> 6;
-  for (int rb = (FUSED ? 0 : part * a.rper) + wave; rb < nrb; rb += nwaves) {
-    const int row = rb * 32 + li;
-    const bool valid = row < S;
-    const int rowc = valid ? row : S - 1;
-    const bool isq = rowc >= F;
-    const int rowl = ATT_ABL(a, 4) ? (rowc & 1) : rowc;
-    const HT* qp = base + (size_t)rowl * ld;
-    const HT* dop = dobase + (size_t)rowl * E;
-    const HT* op = obase + (size_t)rowl * E;
-    vec8<HT> qf[NKK], df[NKK];
-    float delta = 0.f;
+  if constexpr (FUSED && KS) {
+    static_assert(!KS || (FUSED && NJB == 4 && DH == 128), "key-split phase 1: the fused 128 x 128 form");
+    const int SPr = (S + 31) & ~31;
+    float* sDelta = reinterpret_cast<float*>(sP + SPr * FP * 2);   // [SP] rowsum(dO * O)
+    float* sL = sDelta + SPr;                                      // [SP] the row's log-sum-exp
+    float* sDs = sL + SPr;                                         // [SP] a query row's self term of dS (0 for feature rows)
+    // ---- phase 0 (per sweep): the Q / dO rows into LDS by coalesced loads (16 lanes per 256-byte row), into the space that
+    //      will hold the row block's dS / P~; per-row scalars (delta, lse, self terms) and a query token's own key / value
+    //      gradient rows on the way.  One lane per row of a 32 x 32 MFMA operand read global memory 32 lines per instruction
+    //      before.
+    auto sweep_store = [&](const vec8<HT>& q8, const vec8<HT>& d8, const vec8<HT>& o8, const vec8<HT>& k8, const vec8<HT>& v8,
+                           int sw) {
+      const int c = tid & 15, row = (tid >> 4) + 32 * sw;
+      const bool valid = row < S, isq = valid && row >= F;
+      const int to = tile_off<128>(row, c);
+      *reinterpret_cast<vec8<HT>*>(sS + to) = q8;
+      *reinterpret_cast<vec8<HT>*>(sP + to) = d8;
+      float dl = dot8(d8, o8), t = dot8(q8, k8), u = dot8(d8, v8);
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) {
-      qf[kk] = *reinterpret_cast<const vec8<HT>*>(qp + kk * 16 + g * 8);
-      df[kk] = *reinterpret_cast<const vec8<HT>*>(dop + kk * 16 + g * 8);
-      delta += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(op + kk * 16 + g * 8));
-    }
-    delta += __shfl_xor(delta, 32, 64);
-    const float l = lsebase[rowc];
-    const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
-
-    // self terms (scalar per row)
-    float ds_self = 0.f, pt_self = 0.f;
-    if (isq) {
-      float t = 0.f, u = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) {
-        t += dot8(qf[kk], *reinterpret_cast<const vec8<HT>*>(qp + E + kk * 16 + g * 8));
-        u += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + kk * 16 + g * 8));
-      }
-      ds_self = t; pt_self = u;
-    }
-    {
-      const float t2 = __shfl_xor(ds_self, 32, 64), u2 = __shfl_xor(pt_self, 32, 64);
-      if (isq) {
-        const float t = (ds_self + t2) * a.scale, u = pt_self + u2;
-        const float p = __expf(t - l);
+      for (int m = 1; m < 16; m <<= 1) { dl += __shfl_xor(dl, m, 64); t += __shfl_xor(t, m, 64); u += __shfl_xor(u, m, 64); }
+      float ds_self = 0.f, pt_self = 0.f;
+      if (isq) {   // (rows >= F >= 97: never in sweeps 0 .. 2, i.e. always behind the first barrier - sL is complete)
+        const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + row) * (uint64_t)a.LP;
+        const float p = __expf(t * a.scale - sL[row]);
         const float keep = a.thr != 0u ? keep1(a, rowbase, F) : 1.f;
-        ds_self = p * (u * keep - delta) * a.scale;
+        ds_self = p * (u * keep - dl) * a.scale;
         pt_self = p * keep;
       }
-    }
-    // per key block: S^T, dP^T -> dS^T (registers) -> dQ^T += K^T dS^T
-    f32x16_t qa[NDB];
+      if (c == 0) { sDelta[row] = dl; sDs[row] = ds_self; }
+      if (isq && !ATT_ABL(a, 2)) {
+        HT* dq = dbase + (size_t)row * ld + c * 8;
+        float kself[8], vself[8];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+        for (int e = 0; e < 8; ++e) { kself[e] = ds_self * (float)q8[e]; vself[e] = pt_self * (float)d8[e]; }
+        store8_h<HT>(dq + E, kself);
+        store8_h<HT>(dq + 2 * E, vself);
+      }
+    };
+    // ---- 1a unit: (row block, key block) -> dS / P~ in LDS over the row block's Q / dO (read into registers first, one block
+    //      barrier between the reads and the writes)
+    vec8<HT> qf[NKK], df[NKK];
+    auto read_frags = [&](int rb) {
+      const int row = rb * 32 + li;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) qa[db][r] = 0.f;
-#pragma unroll 1
-    for (int jb = 0; jb < NJB; ++jb) {
+      for (int kk = 0; kk < NKK; ++kk) {
+        qf[kk] = *reinterpret_cast<const vec8<HT>*>(sS + tile_off<128>(row, kk * 2 + g));
+        df[kk] = *reinterpret_cast<const vec8<HT>*>(sP + tile_off<128>(row, kk * 2 + g));
+      }
+    };
+    auto item_a = [&](int rb, int jb) {
+      const int row = rb * 32 + li;
+      const bool valid = row < S;
+      const int rowc = valid ? row : S - 1;
+      const float delta = sDelta[row], l = sL[row];
+      const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
       f32x16_t sc, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
@@ -155,21 +234,20 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
         dp = mfma16<HT>(vf, df[kk], dp);
       }
 #pragma unroll
-      for (int qp = 0; qp < 2; ++qp) {
-        float kk[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
-        if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp, g, kk[0], kk[1]);
+      for (int qp2 = 0; qp2 < 2; ++qp2) {
+        float kk2[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+        if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp2, g, kk2[0], kk2[1]);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int q = 2 * qp + h2, r = 4 * q + t;
+            const int q = 2 * qp2 + h2, r = 4 * q + t;
             const int key = jb * 32 + 8 * q + 4 * g + t;
             const float p = key < F ? __expf(sc[r] * a.scale - l) : 0.f;
-            sc[r] = p * (dp[r] * kk[h2][t] - delta) * a.scale;
-            dp[r] = p * kk[h2][t];
+            sc[r] = p * (dp[r] * kk2[h2][t] - delta) * a.scale;
+            dp[r] = p * kk2[h2][t];
           }
       }
-      // hand dS and the dropped probabilities P~ to the key-side kernel (16-byte stores: pair_exchange)
 #pragma unroll
       for (int p2 = 0; p2 < 2; ++p2) {
         float vs[8], vp[8];
@@ -177,65 +255,230 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
                       sc[8 * p2 + 6], sc[8 * p2 + 7], g);
         pair_exchange(vp, dp[8 * p2], dp[8 * p2 + 1], dp[8 * p2 + 2], dp[8 * p2 + 3], dp[8 * p2 + 4], dp[8 * p2 + 5],
                       dp[8 * p2 + 6], dp[8 * p2 + 7], g);
-        if constexpr (FUSED) {
-          if (!valid) {   // padded rows of the last row block contribute nothing to dK / dV
+        if (!valid) {   // padded rows of the last row block contribute nothing to dK / dV (nor to a dQ that is never stored)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { vs[u] = 0.f; vp[u] = 0.f; }
-          }
-          const int to = tile_off<128>(row, jb * 4 + 2 * p2 + g);
-          store8_h<HT>(reinterpret_cast<HT*>(sS + to), vs);
-          store8_h<HT>(reinterpret_cast<HT*>(sP + to), vp);
-        } else if (valid && !ATT_ABL(a, 1)) {
-          const size_t so = (size_t)row * FP + jb * 32 + 16 * p2 + 8 * g;
-          store8_h<HT>(dSs + so, vs);
-          store8_h<HT>(Pts + so, vp);
+          for (int u = 0; u < 8; ++u) { vs[u] = 0.f; vp[u] = 0.f; }
         }
+        const int to = tile_off<128>(row, jb * 4 + 2 * p2 + g);
+        store8_h<HT>(reinterpret_cast<HT*>(sS + to), vs);
+        store8_h<HT>(reinterpret_cast<HT*>(sP + to), vp);
+      }
+    };
+    // ---- 1b unit: (row block, head-dim block) -> dQ over all keys, dS from LDS in tr_frag's k-order
+    auto item_b = [&](int rb, int db) {
+      const int row = rb * 32 + li;
+      const bool valid = row < S;
+      const int rowc = valid ? row : S - 1;
+      const bool isq = rowc >= F;
+      const HT* qp = base + (size_t)rowc * ld;
+      f32x16_t qa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qa[r] = 0.f;
+      const float ds_self = sDs[row];
+      // a query row's own key (the self term of dQ): requested before the products
+      vec8<HT> ksf[2];
+#pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ksf[p2][e] = (HT)0.f;
+        if (isq) ksf[p2] = *reinterpret_cast<const vec8<HT>*>(qp + E + 32 * db + 16 * p2 + 8 * g);
       }
 #pragma unroll
-      for (int aa = 0; aa < 2; ++aa) {
-        const vec8<HT> sf = pack8<HT>(sc, aa);
+      for (int jb = 0; jb < NJB; ++jb)
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
+        for (int aa = 0; aa < 2; ++aa) {
+          // k-slot u of lane (row, g) <-> key 32 jb + 16 aa + 8 (u >> 2) + 4 g + (u & 3)   (mfma_tiles.h: tr_frag)
+          typedef HT h4_t __attribute__((ext_vector_type(4)));
+          const h4_t lo = *reinterpret_cast<const h4_t*>(sS + tile_off<128>(row, jb * 4 + 2 * aa) + 8 * g);
+          const h4_t hi = *reinterpret_cast<const h4_t*>(sS + tile_off<128>(row, jb * 4 + 2 * aa + 1) + 8 * g);
+          vec8<HT> sf;
+          sf[0] = lo[0]; sf[1] = lo[1]; sf[2] = lo[2]; sf[3] = lo[3]; sf[4] = hi[0]; sf[5] = hi[1]; sf[6] = hi[2]; sf[7] = hi[3];
           const vec8<HT> kf = tr_frag<DH, HT>(sK, jb * 32 + 16 * aa, db, lane);
-          qa[db] = mfma16<HT>(kf, sf, qa[db]);
+          qa = mfma16<HT>(kf, sf, qa);
         }
-      }
-    }
-    {
-      // lanes l and l ^ 32 trade quads (mfma_tiles.h: pair_exchange) so that every store is 16 bytes per lane
       HT* dq = dbase + (size_t)row * ld;
       const bool st = valid && !ATT_ABL(a, 2);
 #pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2) {
+        float v[8];
+        pair_exchange(v, qa[8 * p2], qa[8 * p2 + 1], qa[8 * p2 + 2], qa[8 * p2 + 3], qa[8 * p2 + 4], qa[8 * p2 + 5],
+                      qa[8 * p2 + 6], qa[8 * p2 + 7], g);
+        if (st) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = fmaf(ds_self, (float)ksf[p2][u], v[u]);   // (ds_self = 0 for feature rows)
+          store8_h<HT>(dq + 32 * db + 16 * p2 + 8 * g, v);
+        }
+      }
+    };
+    // ---- the pipeline: step s = waves 0 - 3: dS / P~ of row block s (one key block each); waves 4 - 7: dQ of row block s - 1
+    //      (one head-dim block each); every thread: sweep s + 1 into LDS.  Two barriers per step: Q / dO fragments read ->
+    //      barrier -> the same space written.  Each SIMD hosts one wave of either kind.
+    sweep_store(qv[0], dv[0], ov, kv, vv, 0);
+    lds_barrier();
+    ATT_STAMP(2);
+#pragma unroll
+    for (int s_ = 0; s_ <= NSW; ++s_) {
+      if (s_ <= nrb) {
+        if (s_ + 1 < nrb) load_okv(s_ + 1);
+        if (wave < 4 && s_ < nrb) read_frags(s_);
+        lds_barrier();
+        if (wave < 4) {
+          if (s_ < nrb && !ATT_ABL(a, 64)) item_a(s_, wave);
+        } else {
+          if (s_ >= 1 && !ATT_ABL(a, 32)) item_b(s_ - 1, wave - 4);
+        }
+        if (s_ + 1 < NSW) {
+          if (s_ + 1 < nrb && !ATT_ABL(a, 128)) sweep_store(qv[(s_ + 1) % NSW], dv[(s_ + 1) % NSW], ov, kv, vv, s_ + 1);
+        }
+        lds_barrier();
+      }
+    }
+    ATT_STAMP(3);
+  } else {
+    for (int rb = (FUSED ? 0 : part * a.rper) + wave; rb < nrb; rb += nwaves) {
+      const int row = rb * 32 + li;
+      const bool valid = row < S;
+      const int rowc = valid ? row : S - 1;
+      const bool isq = rowc >= F;
+      const int rowl = ATT_ABL(a, 4) ? (rowc & 1) : rowc;
+      const HT* qp = base + (size_t)rowl * ld;
+      const HT* dop = dobase + (size_t)rowl * E;
+      const HT* op = obase + (size_t)rowl * E;
+      vec8<HT> qf[NKK], df[NKK];
+      float delta = 0.f;
+  #pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        qf[kk] = *reinterpret_cast<const vec8<HT>*>(qp + kk * 16 + g * 8);
+        df[kk] = *reinterpret_cast<const vec8<HT>*>(dop + kk * 16 + g * 8);
+        delta += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(op + kk * 16 + g * 8));
+      }
+      delta += __shfl_xor(delta, 32, 64);
+      const float l = lsebase[rowc];
+      const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
+
+      // self terms (scalar per row)
+      float ds_self = 0.f, pt_self = 0.f;
+      if (isq) {
+        float t = 0.f, u = 0.f;
+  #pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+          t += dot8(qf[kk], *reinterpret_cast<const vec8<HT>*>(qp + E + kk * 16 + g * 8));
+          u += dot8(df[kk], *reinterpret_cast<const vec8<HT>*>(qp + 2 * E + kk * 16 + g * 8));
+        }
+        ds_self = t; pt_self = u;
+      }
+      {
+        const float t2 = __shfl_xor(ds_self, 32, 64), u2 = __shfl_xor(pt_self, 32, 64);
+        if (isq) {
+          const float t = (ds_self + t2) * a.scale, u = pt_self + u2;
+          const float p = __expf(t - l);
+          const float keep = a.thr != 0u ? keep1(a, rowbase, F) : 1.f;
+          ds_self = p * (u * keep - delta) * a.scale;
+          pt_self = p * keep;
+        }
+      }
+      // per key block: S^T, dP^T -> dS^T (registers) -> dQ^T += K^T dS^T
+      f32x16_t qa[NDB];
+  #pragma unroll
       for (int db = 0; db < NDB; ++db)
-#pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2) {
-          float v[8];
-          pair_exchange(v, qa[db][8 * p2], qa[db][8 * p2 + 1], qa[db][8 * p2 + 2], qa[db][8 * p2 + 3], qa[db][8 * p2 + 4],
-                        qa[db][8 * p2 + 5], qa[db][8 * p2 + 6], qa[db][8 * p2 + 7], g);
-          const int dh = 32 * db + 16 * p2 + 8 * g;
-          if (st) {
-            if (isq) {
-              const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(qp + E + dh);
-              // fp16: the q / dO chunks are the fragments the products above used (columns 16 kk + 8 g = dh) - no second read;
-              // bf16: read again (kept live as operands AND as values to convert, the fragments cost this kernel 200 spilled
-              // registers with this compiler)
-              constexpr bool REUSE = sizeof(HT) == 2 && __is_same(HT, f16_t);
-              const vec8<HT> qf8 = REUSE ? qf[2 * db + p2] : *reinterpret_cast<const vec8<HT>*>(qp + dh);
-              const vec8<HT> d8 = REUSE ? df[2 * db + p2] : *reinterpret_cast<const vec8<HT>*>(dop + dh);
-              float kself[8], vself[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                v[u] = fmaf(ds_self, (float)kf[u], v[u]);
-                kself[u] = ds_self * (float)qf8[u];      // a query token's own key / value receive the self term only
-                vself[u] = pt_self * (float)d8[u];
-              }
-              store8_h<HT>(dq + E + dh, kself);
-              store8_h<HT>(dq + 2 * E + dh, vself);
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) qa[db][r] = 0.f;
+  #pragma unroll 1
+      for (int jb = 0; jb < NJB; ++jb) {
+        f32x16_t sc, dp;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+  #pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+          const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(sK + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+          const vec8<HT> vf = *reinterpret_cast<const vec8<HT>*>(sV + tile_off<DH>(jb * 32 + li, kk * 2 + g));
+          sc = mfma16<HT>(kf, qf[kk], sc);
+          dp = mfma16<HT>(vf, df[kk], dp);
+        }
+  #pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          float kk[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+          if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp, g, kk[0], kk[1]);
+  #pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int q = 2 * qp + h2, r = 4 * q + t;
+              const int key = jb * 32 + 8 * q + 4 * g + t;
+              const float p = key < F ? __expf(sc[r] * a.scale - l) : 0.f;
+              sc[r] = p * (dp[r] * kk[h2][t] - delta) * a.scale;
+              dp[r] = p * kk[h2][t];
             }
-            store8_h<HT>(dq + dh, v);
+        }
+        // hand dS and the dropped probabilities P~ to the key-side kernel (16-byte stores: pair_exchange)
+  #pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+          float vs[8], vp[8];
+          pair_exchange(vs, sc[8 * p2], sc[8 * p2 + 1], sc[8 * p2 + 2], sc[8 * p2 + 3], sc[8 * p2 + 4], sc[8 * p2 + 5],
+                        sc[8 * p2 + 6], sc[8 * p2 + 7], g);
+          pair_exchange(vp, dp[8 * p2], dp[8 * p2 + 1], dp[8 * p2 + 2], dp[8 * p2 + 3], dp[8 * p2 + 4], dp[8 * p2 + 5],
+                        dp[8 * p2 + 6], dp[8 * p2 + 7], g);
+          if constexpr (FUSED) {
+            if (!valid) {   // padded rows of the last row block contribute nothing to dK / dV
+  #pragma unroll
+              for (int u = 0; u < 8; ++u) { vs[u] = 0.f; vp[u] = 0.f; }
+            }
+            const int to = tile_off<128>(row, jb * 4 + 2 * p2 + g);
+            store8_h<HT>(reinterpret_cast<HT*>(sS + to), vs);
+            store8_h<HT>(reinterpret_cast<HT*>(sP + to), vp);
+          } else if (valid && !ATT_ABL(a, 1)) {
+            const size_t so = (size_t)row * FP + jb * 32 + 16 * p2 + 8 * g;
+            store8_h<HT>(dSs + so, vs);
+            store8_h<HT>(Pts + so, vp);
           }
         }
+  #pragma unroll
+        for (int aa = 0; aa < 2; ++aa) {
+          const vec8<HT> sf = pack8<HT>(sc, aa);
+  #pragma unroll
+          for (int db = 0; db < NDB; ++db) {
+            const vec8<HT> kf = tr_frag<DH, HT>(sK, jb * 32 + 16 * aa, db, lane);
+            qa[db] = mfma16<HT>(kf, sf, qa[db]);
+          }
+        }
+      }
+      {
+        // lanes l and l ^ 32 trade quads (mfma_tiles.h: pair_exchange) so that every store is 16 bytes per lane
+        HT* dq = dbase + (size_t)row * ld;
+        const bool st = valid && !ATT_ABL(a, 2);
+  #pragma unroll
+        for (int db = 0; db < NDB; ++db)
+  #pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            float v[8];
+            pair_exchange(v, qa[db][8 * p2], qa[db][8 * p2 + 1], qa[db][8 * p2 + 2], qa[db][8 * p2 + 3], qa[db][8 * p2 + 4],
+                          qa[db][8 * p2 + 5], qa[db][8 * p2 + 6], qa[db][8 * p2 + 7], g);
+            const int dh = 32 * db + 16 * p2 + 8 * g;
+            if (st) {
+              if (isq) {
+                const vec8<HT> kf = *reinterpret_cast<const vec8<HT>*>(qp + E + dh);
+                // fp16: the q / dO chunks are the fragments the products above used (columns 16 kk + 8 g = dh) - no second read;
+                // bf16: read again (kept live as operands AND as values to convert, the fragments cost this kernel 200 spilled
+                // registers with this compiler)
+                constexpr bool REUSE = sizeof(HT) == 2 && __is_same(HT, f16_t);
+                const vec8<HT> qf8 = REUSE ? qf[2 * db + p2] : *reinterpret_cast<const vec8<HT>*>(qp + dh);
+                const vec8<HT> d8 = REUSE ? df[2 * db + p2] : *reinterpret_cast<const vec8<HT>*>(dop + dh);
+                float kself[8], vself[8];
+  #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  v[u] = fmaf(ds_self, (float)kf[u], v[u]);
+                  kself[u] = ds_self * (float)qf8[u];      // a query token's own key / value receive the self term only
+                  vself[u] = pt_self * (float)d8[u];
+                }
+                store8_h<HT>(dq + E + dh, kself);
+                store8_h<HT>(dq + 2 * E + dh, vself);
+              }
+              store8_h<HT>(dq + dh, v);
+            }
+          }
+      }
     }
+
   }
 
   if constexpr (FUSED) {
@@ -276,13 +519,28 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
         if (idx < SP * 16) *reinterpret_cast<vec8<HT>*>(sX + tile_off<128>(idx >> 4, idx & 15)) = xr[u];
       }
     };
-    x_load(base, ld);
+    ATT_STAMP(4);
+    if constexpr (KS) {
+#pragma unroll
+      for (int u = 0; u < XU; ++u) xr[u] = qv[u];
+    } else {
+      x_load(base, ld);
+    }
 #pragma unroll
     for (int prod = 0; prod < 2; ++prod) {
-      __syncthreads();   // phase 1 (prod 0) / the previous product's fragment reads (prod 1) are done with this space
+      lds_barrier();   // phase 1 (prod 0) / the previous product's fragment reads (prod 1) are done with this space
+      if (prod == 0) ATT_STAMP(5);
       x_store();
-      if (prod == 0) x_load(dobase, (size_t)E);
-      __syncthreads();
+      if (prod == 0) {
+        if constexpr (KS) {
+#pragma unroll
+          for (int u = 0; u < XU; ++u) xr[u] = dv[u];
+        } else {
+          x_load(dobase, (size_t)E);
+        }
+      }
+      lds_barrier();
+      if (prod == 1) ATT_STAMP(6);
       const char* sY = prod ? sP : sS;
       // two accumulator sets (even / odd 16-row steps: SP / 16 is even) - four independent MFMA chains per wave, and the
       // fragments of both steps of a pair are requested before the first MFMA
@@ -321,11 +579,12 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
             pair_exchange(v, acc[j][8 * p2], acc[j][8 * p2 + 1], acc[j][8 * p2 + 2], acc[j][8 * p2 + 3], acc[j][8 * p2 + 4],
                           acc[j][8 * p2 + 5], acc[j][8 * p2 + 6], acc[j][8 * p2 + 7], g);
             const int k = wi * 32 + 16 * p2 + 8 * g;
-            if (n < F) store8_h<HT>(out + (size_t)n * ld + k, v);
+            if (n < F && !ATT_ABL(a, 2)) store8_h<HT>(out + (size_t)n * ld + k, v);
           }
         }
       }
     }
+    ATT_STAMP(7);
   }
 }
 
@@ -478,16 +737,17 @@ static inline int rows_waves(int S) {
 static inline bool fused_fits(const TimDesc& d) {
   if (tim_knobs().attn_fused == 0) return false;
   const int SP = (d.S + 31) & ~31;
-  return d.E / d.H == 128 && (d.F + 31) / 32 == 4 && (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 <= 160 * 1024;
+  return d.E / d.H == 128 && (d.F + 31) / 32 == 4 && (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 + (size_t)SP * 12 <= 160 * 1024;
 }
 
-template <typename HT>
-int launch_bwd_fused(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, hipStream_t s) {
+template <typename HT, bool KS>
+int launch_bwd_fused(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, void* stamps,
+                     hipStream_t s) {
   const int SP = (d.S + 31) & ~31;
-  const size_t lds = (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2;
-  (void)hipFuncSetAttribute((const void*)attn_bwd_rows<HT, 128, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_bwd_rows<HT, 128, 4, true>), dim3(d.B * d.H), dim3(512), lds, s, (const HT*)qkv, (const HT*)o, lse,
-                     (const HT*)d_o, (HT*)dqkv, (HT*)nullptr, (HT*)nullptr, make_args2(d));
+  const size_t lds = (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 + (KS ? (size_t)SP * 12 : 0);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_rows<HT, 128, 4, true, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_bwd_rows<HT, 128, 4, true, KS>), dim3(d.B * d.H), dim3(512), lds, s, (const HT*)qkv, (const HT*)o, lse,
+                     (const HT*)d_o, (HT*)dqkv, (HT*)stamps, (HT*)nullptr, make_args2(d));
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
@@ -529,7 +789,14 @@ size_t tim_attention_bwd2_ws(const TimDesc& d) {
 int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                             void* dqkv, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!h16_storage(d.precision) || (d.E % 8) != 0 || d.B * d.H > 65535) return TIMHIP_EUNSUPPORTED;
-  if (fused_fits(d)) DISPATCH_H16(d.precision, return (launch_bwd_fused<HT>(d, qkv, o, lse, d_o, dqkv, s)));
+  if (fused_fits(d)) {
+    void* stamps = nullptr;   // (tuning builds, abl bit 16: per-block phase stamps into the caller's workspace, 64 B per block)
+#ifdef TIMHIP_TUNING
+    if (((d.reserved >> 8) & 16) && ws && ws_bytes >= (size_t)d.B * d.H * 64) stamps = ws;
+#endif
+    if (tim_knobs().attn_ks != 0) DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, true>(d, qkv, o, lse, d_o, dqkv, stamps, s)));
+    DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, false>(d, qkv, o, lse, d_o, dqkv, stamps, s)));
+  }
   if (!ws || ws_bytes < tim_attention_bwd2_ws(d)) return TIMHIP_EUNSUPPORTED;
   const int DHv = d.E / d.H, NJBv = (d.F + 31) / 32;
 #define B2(DHc, NJBc) DISPATCH_H16(d.precision, return (launch_bwd2<HT, DHc, NJBc>(d, qkv, o, lse, d_o, dqkv, ws, s)))

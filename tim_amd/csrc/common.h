@@ -293,6 +293,7 @@ struct TimKnobs {
   int ln_rpb;         // TIMHIP_LN_RPB       rows per LayerNorm-backward block (0: by shape)
   int ln_rpb_small;   // TIMHIP_LN_RPB_SMALL rows per block of the LayerNorm-backward launches that end in atomics (0: as TIMHIP_LN_RPB)
   int gemm_tmw;       // TIMHIP_GEMM_TMW     5 / 4: force the 160- / 128-row tile of the loader-wave NT kernels (0: by shape)
+  int attn_ks;        // TIMHIP_ATTN_KS      0: fused attention backward with the one-wave-per-row-block phase 1 (default 1: key-split)
   int gemm_pp_min;    // TIMHIP_GEMM_PP_MIN_TILES  fewest 160 x 256 tiles the one-block-per-CU NT kernels are used for (default 192)
 };
 const TimKnobs& tim_knobs();

@@ -120,6 +120,15 @@ __device__ __forceinline__ void stage_tile_pair(char* tile0, const HT* src0, cha
   }
 }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence as well: it waits for the
+// acknowledgement of every global store the wave has in flight (microseconds behind a row of 16-bit gradient stores), which no
+// phase boundary that hands over LDS contents needs.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // V^T / K^T fragment for the PV-style MFMA: lane (i = lane & 31 -> dh 32*db + i, g = lane >> 5)
 // gets the 8 values tile[key(u)][dh], key(u) = kb + 8*(u>>2) + 4*g + (u&3)   (kb = 32*jb + 16*a)
 template <int DH, typename HT>
