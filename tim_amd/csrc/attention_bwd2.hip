@@ -57,13 +57,12 @@ __device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int
 // that lane owns - one Philox call and two exchanges per lane instead of two calls (common.h: 16-bit draws)
 __device__ __forceinline__ void keep_pair(const AttnArgsM& a, uint64_t rowbase, int kb, int g, float (&k0)[4], float (&k1)[4]) {
   const Philox4 r = philox4x32_7(a.seed, a.site, ((rowbase + (uint64_t)kb) >> 3) + (uint64_t)g);
-  const uint32_t s0 = g ? r.x : r.z, s1 = g ? r.y : r.w;
-  const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 32, 64), r1 = (uint32_t)__shfl_xor((int)s1, 32, 64);
-  float own[4], oth[4];
-  drop_mask4_words(g ? r.z : r.x, g ? r.w : r.y, a.thr, a.dscale, own[0], own[1], own[2], own[3]);
-  drop_mask4_words(r0, r1, a.thr, a.dscale, oth[0], oth[1], oth[2], oth[3]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { k0[u] = g ? oth[u] : own[u]; k1[u] = g ? own[u] : oth[u]; }
+  // v_permlane32_swap (x, z) and (y, w): lane g = 0 ends with (own x, partner's x), lane g = 1 with (partner's z, own z) - the
+  // words of counter 0 first and of counter 1 second in both lanes, no select
+  const auto xz = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
+  const auto yw = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
+  drop_mask4_words(xz[0], yw[0], a.thr, a.dscale, k0[0], k0[1], k0[2], k0[3]);
+  drop_mask4_words(xz[1], yw[1], a.thr, a.dscale, k1[0], k1[1], k1[2], k1[3]);
 }
 
 // KS (round 5, fused form only): phase 1 in two halves around one block barrier, so that all EIGHT waves work and no SIMD carries
@@ -185,9 +184,12 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
       const int to = tile_off<128>(row, c);
       *reinterpret_cast<vec8<HT>*>(sS + to) = q8;
       *reinterpret_cast<vec8<HT>*>(sP + to) = d8;
-      float dl = dot8(d8, o8), t = dot8(q8, k8), u = dot8(d8, v8);
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) { dl += __shfl_xor(dl, m, 64); t += __shfl_xor(t, m, 64); u += __shfl_xor(u, m, 64); }
+      const float dl = row16_sum(dot8(d8, o8));
+      float t = 0.f, u = 0.f;
+      if (32 * sw + 31 >= F) {   // (wave-uniform: the sweep holds query rows)
+        t = row16_sum(dot8(q8, k8));
+        u = row16_sum(dot8(d8, v8));
+      }
       float ds_self = 0.f, pt_self = 0.f;
       if (isq) {   // (rows >= F >= 97: never in sweeps 0 .. 2, i.e. always behind the first barrier - sL is complete)
         const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + row) * (uint64_t)a.LP;
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
       const int row = rb * 32 + li;
       const bool valid = row < S;
       const int rowc = valid ? row : S - 1;
-      const float delta = sDelta[row], l = sL[row];
+      const float delta = sDelta[row], l2 = sL[row] * 1.44269504088896341f, c2 = a.scale * 1.44269504088896341f;
       const uint64_t rowbase = (((uint64_t)b * a.H + h) * S + rowc) * (uint64_t)a.LP;
       f32x16_t sc, dp;
 #pragma unroll
@@ -243,8 +245,9 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
           for (int t = 0; t < 4; ++t) {
             const int q = 2 * qp2 + h2, r = 4 * q + t;
             const int key = jb * 32 + 8 * q + 4 * g + t;
-            const float p = key < F ? __expf(sc[r] * a.scale - l) : 0.f;
-            sc[r] = p * (dp[r] * kk2[h2][t] - delta) * a.scale;
+            // p = exp(s scale - lse) as one fma + v_exp_f32 (base 2); dS = p scale (dP keep - delta)
+            const float p = key < F ? __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -l2)) : 0.f;
+            sc[r] = (p * a.scale) * fmaf(dp[r], kk2[h2][t], -delta);
             dp[r] = p * kk2[h2][t];
           }
       }

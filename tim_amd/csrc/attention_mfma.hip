@@ -45,13 +45,12 @@ __device__ __forceinline__ float keep1(const AttnArgsM& a, uint64_t rowbase, int
 // that lane owns - one Philox call and two exchanges per lane instead of two calls (common.h: 16-bit draws)
 __device__ __forceinline__ void keep_pair(const AttnArgsM& a, uint64_t rowbase, int kb, int g, float (&k0)[4], float (&k1)[4]) {
   const Philox4 r = philox4x32_7(a.seed, a.site, ((rowbase + (uint64_t)kb) >> 3) + (uint64_t)g);
-  const uint32_t s0 = g ? r.x : r.z, s1 = g ? r.y : r.w;
-  const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, 32, 64), r1 = (uint32_t)__shfl_xor((int)s1, 32, 64);
-  float own[4], oth[4];
-  drop_mask4_words(g ? r.z : r.x, g ? r.w : r.y, a.thr, a.dscale, own[0], own[1], own[2], own[3]);
-  drop_mask4_words(r0, r1, a.thr, a.dscale, oth[0], oth[1], oth[2], oth[3]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { k0[u] = g ? oth[u] : own[u]; k1[u] = g ? own[u] : oth[u]; }
+  // v_permlane32_swap (x, z) and (y, w): lane g = 0 ends with (own x, partner's x), lane g = 1 with (partner's z, own z) - the
+  // words of counter 0 first and of counter 1 second in both lanes, no select
+  const auto xz = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
+  const auto yw = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
+  drop_mask4_words(xz[0], yw[0], a.thr, a.dscale, k0[0], k0[1], k0[2], k0[3]);
+  drop_mask4_words(xz[1], yw[1], a.thr, a.dscale, k1[0], k1[1], k1[2], k1[3]);
 }
 
 template <int C>

@@ -148,13 +148,28 @@ __device__ __forceinline__ vec8<HT> tr_frag(const char* tile, int kb, int db, in
 // pair_exchange() trades one quad between the two lanes: afterwards g = 0 owns columns 16p .. 16p+7 and g = 1 owns
 // 16p+8 .. 16p+15, i.e. ONE 16-byte bf16 store per lane instead of two 8-byte ones (the store phase of these kernels is
 // bound by the number of store instructions, not by bytes).
+// (gfx950: v_permlane32_swap trades the upper half of one register with the lower half of another - one VALU instruction per
+//  quad element where a select + ds_bpermute + two selects stood)
 __device__ __forceinline__ void pair_exchange(float (&out)[8], float e0, float e1, float e2, float e3, float o0, float o1,
                                               float o2, float o3, int g) {
-  const float s0 = g ? e0 : o0, s1 = g ? e1 : o1, s2 = g ? e2 : o2, s3 = g ? e3 : o3;   // what the partner needs
-  const float r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64), r2 = __shfl_xor(s2, 32, 64),
-              r3 = __shfl_xor(s3, 32, 64);
-  if (g == 0) { out[0] = e0; out[1] = e1; out[2] = e2; out[3] = e3; out[4] = r0; out[5] = r1; out[6] = r2; out[7] = r3; }
-  else { out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3; out[4] = o0; out[5] = o1; out[6] = o2; out[7] = o3; }
+  (void)g;
+  const float e[4] = {e0, e1, e2, e3}, o[4] = {o0, o1, o2, o3};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    // lanes 32 .. 63 of the first operand <-> lanes 0 .. 31 of the second:
+    //   g = 0 lane: (e own, e of the partner)      g = 1 lane: (o of the partner, o own)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(e[u]), __float_as_uint(o[u]), false, false);
+    out[u] = __uint_as_float(r[0]);
+    out[4 + u] = __uint_as_float(r[1]);
+  }
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row (rotations by 8, 4, 2, 1: four v_add_f32_dpp)
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x128, 0xF, 0xF, false));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x124, 0xF, 0xF, false));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x122, 0xF, 0xF, false));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x121, 0xF, 0xF, false));
+  return x;
 }
 template <typename HT>
 __device__ __forceinline__ void store8_h(HT* p, const float (&v)[8]) {
