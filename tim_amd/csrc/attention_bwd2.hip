@@ -65,12 +65,15 @@ __device__ __forceinline__ void keep_pair(const AttnArgsM& a, uint64_t rowbase, 
   drop_mask4_words(xz[1], yw[1], a.thr, a.dscale, k1[0], k1[1], k1[2], k1[3]);
 }
 
-// KS (round 5, fused form only): phase 1 in two halves around one block barrier, so that all EIGHT waves work and no SIMD carries
-// two whole row blocks (S = 155: five 32-row blocks on four SIMDs used to put two of them on one SIMD, three waves idle):
-//   1a  item (row block, key half): S^T / dP^T / dS / P~ of 64 of the 128 keys -> LDS (ten items over the eight waves);
-//   1b  item (row block, head-dim half): dQ = dS K over all keys for 64 of the 128 head-dim columns, dS read back from LDS
-//       in the k-order of tr_frag (two 8-byte reads per fragment) - the same values in the same accumulation order as the
-//       one-wave form, so the results are bit-identical.
+// KS (round 5, fused form only): phase 1 as a pipeline over the 32-row blocks on all EIGHT waves (the one-wave-per-row-block
+// form left three waves idle at S = 155 and read every operand row with one lane per row: 32 cache lines per load instruction).
+//   top      every request in arrival order: K / V tiles, the Q / dO rows of all sweeps by coalesced loads (16 lanes per row; kept
+//            in registers for phase 2), sweep 0's O rows; O / own-key / own-value rows of sweep s + 1 one step ahead
+//   sweep s  Q / dO rows of row block s into the LDS space that will hold its dS / P~; delta, lse, self terms per row
+//   step s   waves 0 - 3: one (row block s, key block) unit each -> dS / P~ (fragments read, LDS-only barrier, same space
+//            written); waves 4 - 7: one (row block s - 1, head-dim block) dQ unit each, dS read back from LDS in tr_frag's k-order
+//            (same values, same accumulation order as the one-wave form); every thread: sweep s + 1
+// DESIGN.md section 5f has the per-phase clocks and what was tried on top.
 template <typename HT, int DH, int NJB, bool FUSED = false, bool KS = false>
 __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv, const HT* __restrict__ o,
                                                      const float* __restrict__ lse, const HT* __restrict__ d_o,
