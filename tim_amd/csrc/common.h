@@ -308,15 +308,21 @@ __device__ __forceinline__ void nf_commit(const float* out_scale, float chk) {
   if (out_scale != nullptr && chk != chk) atomicOr(reinterpret_cast<unsigned*>(const_cast<float*>(out_scale)) + 3, 1u);
 }
 
+// Wave-wide reductions without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: six dependent LDS round trips per
+// reduction): four DPP row rotations leave every 16-lane row's result in all of its lanes, four v_readlane + three VALU ops
+// combine the rows.  Every lane of the wave must be active (as for the shuffles these replace).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<0x128>(v); v += dpp_f<0x124>(v); v += dpp_f<0x122>(v); v += dpp_f<0x121>(v);   // row_ror 8, 4, 2, 1
+  return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, dpp_f<0x124>(v)); v = fmaxf(v, dpp_f<0x122>(v)); v = fmaxf(v, dpp_f<0x121>(v));
+  return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 
 // ----------------------------------------------------------------------------
