@@ -394,13 +394,15 @@ def test_attention_dropout(prec):
 
 
 @pytest.mark.parametrize("prec", H16)
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "1-one-wave-per-row-block", "0"])
 @pytest.mark.parametrize("B,S,F,H,Dh,p", [(3, 155, 100, 2, 128, 0.1), (2, 125, 100, 1, 128, 0.0), (1, 160, 128, 2, 128, 0.1),
-                                          (2, 192, 97, 1, 128, 0.0)])
+                                          (2, 192, 97, 1, 128, 0.0), (2, 129, 128, 1, 128, 0.1), (1, 98, 97, 2, 128, 0.1)])
 def test_attention_backward_fused_and_two_kernel(prec, fused, B, S, F, H, Dh, p, knobs):
-    """the production-shape backward in both forms: rows + keys kernels with the dS / P~ scratch (TIMHIP_ATTN_FUSED=0) and the
-    one-kernel form that keeps dS / P~ in LDS (128-wide heads, 97..128 feature keys, S <= 192); with attention dropout"""
-    knobs(TIMHIP_ATTN_FUSED=fused)
+    """the production-shape backward in its three forms: rows + keys kernels with the dS / P~ scratch (TIMHIP_ATTN_FUSED=0), and the
+    one-kernel form that keeps dS / P~ in LDS (128-wide heads, 97..128 feature keys, S <= 192) with phase 1 as the pipeline over
+    row blocks (default) or one wave per row block (TIMHIP_ATTN_KS=0); with attention dropout.  Shapes: four, five and six row
+    blocks, a last block of one row, no padding keys / 31 padding keys, one query row"""
+    knobs(TIMHIP_ATTN_FUSED=fused[0], TIMHIP_ATTN_KS="0" if "one-wave" in fused else "1")
     _attn_case(prec, B, S, F, H, Dh, p=p)
 
 
