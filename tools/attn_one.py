@@ -1,4 +1,13 @@
-"""Run the MFMA attention fwd/bwd kernels alone (timing + rocprofv3 PMC)."""
+"""Run the MFMA attention fwd / bwd kernels alone at the C2a shape (timing, rocprofv3 PMC, per-phase clocks).
+
+    python tools/attn_one.py [p_drop]
+    ATT_PREC=3         fp16 operands (default 0: bf16)
+    ATT_SETS=8         second timing with the operands out of HBM: that many buffer sets in rotation (162 MB each)
+    TIMHIP_ATTN_KS=0   the fused backward with one wave per row block instead of the pipeline (TIMHIP_ATTN_FUSED=0: two kernels)
+  with TIM_AMD_LIB=tim_amd/libtimhip_tuning.so (make -C tim_amd/csrc TUNING=1), ATT_ABL = sum of
+    1 no scratch stores, 2 no dqkv stores, 4 operand rows from two cached rows (no DRAM traffic),
+    16 shader-clock stamps per block and phase (printed below), 32 / 64 / 128 drop the dQ units / dS units / sweeps 1.. of the pipeline
+"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
