@@ -116,8 +116,67 @@ def det_train_step(model, batch, target, state):
     return {"loss": loss.detach(), "output": output, "offsets": offsets, "labels": labels, "queries": queries, "ious": ious}
 
 
+def make_rec_targets(cfg, B, nv, na, seed, dev):
+    """synthetic labels of a recognition batch in the loader's wire format (sliding_window.py:383-390): verb / noun / action
+    per visual query, class_id per audio query, -1 where a window has fewer queries than the batch maximum (every fifth / fourth
+    slot here: train.py:223-224 masks them by target != -1)"""
+    rs = np.random.RandomState(seed)
+    vc, ac = cfg.num_class[0], cfg.num_class[1]
+    t = {"verb": rs.randint(0, vc[0], (B, nv)), "noun": rs.randint(0, vc[1], (B, nv)), "action": rs.randint(0, vc[2], (B, nv)),
+         "class_id": rs.randint(0, ac, (B, na))}
+    pad_v = rs.rand(B, nv) < 0.2
+    for k in ("verb", "noun", "action"):
+        t[k][pad_v] = -1
+    t["class_id"][rs.rand(B, na) < 0.25] = -1
+    return {k: torch.from_numpy(v.astype(np.int64)).to(dev) for k, v in t.items()}
+
+
+def rec_train_step(model, batch, nv, na, st):
+    """One recognition TRAINING ITERATION as recognition/scripts/train.py:184-366 runs it: time MLP -> mixup of the inputs
+    (utils/mixup.py:4-22: three lerps with a batch permutation) -> encoder -> label-smoothed mixup cross entropy on the four
+    heads (train.py:218-316, one fused launch pair per head: tim_amd/losses.py) + cross-modal dense relative localisation loss
+    (train.py:331-336, lambda 0.3, m = 32) -> backward -> clip_grad_norm_(1.0) (train.py:358) -> AdamW (train.py:66,362; fused,
+    capturable so that the whole iteration replays as one HIP graph) -> operand-copy refresh of the weights at the head of the
+    next step.  lam, the permutation and the DRLoc positions are drawn once per process (a captured step freezes host-side
+    draws anyway; their values do not change the cost of the step).  No GradScaler: the fp16 mode scales its gradient
+    operands on the device (timhip_grad_scale) and the parameter gradients are true-scale fp32."""
+    from tim_amd import losses
+    inner = model.module if hasattr(model, "module") else model
+    opt = st["opt"]
+    opt.zero_grad(set_to_none=True)
+    inner.rt.invalidate_weights()          # the optimizer changed the weights: redo the operand copies (one grouped launch)
+    lam, perm, tgt, tgt_b = st["lam"], st["perm"], st["target"], st["target_b"]
+    te = model(batch["times"], "time_mlp")
+    vis, aud, te = [torch.lerp(t[perm], t, lam) for t in (batch["visual"], batch["audio"], te)]   # lam * t + (1 - lam) * t[perm]
+    (verb, noun, action, audio), feats = model([vis, aud], "encoder", te, nv, na)
+    ce = lambda x, k: losses.mixup_cross_entropy(x, tgt[k].reshape(-1), tgt_b[k].reshape(-1), lam, 0.2)   # noqa: E731
+    loss = (ce(verb, "verb") + ce(noun, "noun") + ce(action, "action")) / 3.0 + 1.0 * ce(audio, "class_id")
+    nf = inner.cfg.num_feats
+    loss = loss + 0.3 * losses.dense_relative_localization_loss_crossmodal(feats[:, :nf], feats[:, nf:], inner, 32, positions=st["pos"])
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(st["params"], 1.0, foreach=True)
+    opt.step()
+    return loss.detach()
+
+
+def make_rec_train_state(model, cfg, B, nv, na, dev, seed=0):
+    inner = model.module if hasattr(model, "module") else model
+    params = list(inner.parameters())
+    g = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(B, generator=g).to(dev)
+    tgt = make_rec_targets(cfg, B, nv, na, seed + 7, dev)
+    nf = cfg.num_feats
+    return {"rec": True, "params": params, "lam": float(np.random.RandomState(seed).beta(0.2, 0.2)) * 0.5 + 0.25, "perm": perm,
+            "target": tgt, "target_b": {k: v[perm] for k, v in tgt.items()},
+            "pos": (torch.randint(nf, (B, 32), generator=g).to(dev), torch.randint(nf, (B, 32), generator=g).to(dev)),
+            # lr 1e-4 / weight decay 1e-4: parser.py:121-131; capturable: the step counter lives on the device
+            "opt": torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, fused=True, capturable=True)}
+
+
 def step_fn(model, batch, nv, na, R):
     inner = model.module if hasattr(model, "module") else model
+    if isinstance(R, dict) and R.get("rec"):     # recognition as the reference's training iteration (losses, clip, AdamW)
+        return rec_train_step(model, batch, nv, na, R)
     if isinstance(R, dict):          # detection as true training: R carries {"target": ..., state}
         return det_train_step(model, batch, R["target"], R)
     plist = inner.__dict__.get("_bench_plist")
@@ -360,7 +419,7 @@ def det_logit_parity(model, cfg, sd_np, dev, B=2):
     return worst, n
 
 
-def secondary_block(workload, B, precision, dev, steps, warmup, det_train=False, graph=False):
+def secondary_block(workload, B, precision, dev, steps, warmup, det_train=False, graph=False, rec_train=False):
     """one more BASELINE.json configuration, same build and mode, measured like the headline (eager steps of the full
     forward + backward on HBM-resident synthetic inputs) plus its logit error against the fp32 oracle"""
     cfg = named_config(workload)
@@ -371,9 +430,18 @@ def secondary_block(workload, B, precision, dev, steps, warmup, det_train=False,
     m, sd_np = build_model(cfg, precision, dev, seed=0)
     m.train(det_train or not det)
     batch = make_batch(cfg, B, 0 if det else nv, na, seed=100, dev=dev)
-    R = {"target": make_det_targets(cfg, B, 6, 5, dev)} if det_train else [None]
-    ms, ms_mean, ms_max = robust_step_ms(lambda: step_fn(m, batch, nv, na, R), steps, max(warmup, 10))
-    err, nlog = (det_logit_parity(m, cfg, sd_np, dev) if det else logit_parity(m, cfg, sd_np, nv, na, dev, B=2))
+    R = {"target": make_det_targets(cfg, B, 6, 5, dev)} if det_train else (make_rec_train_state(m, cfg, B, nv, na, dev) if rec_train else [None])
+    err_first = (logit_parity(m, cfg, sd_np, nv, na, dev, B=2) if rec_train else None)   # (before AdamW moves the weights)
+    ms, ms_mean, ms_max = robust_step_ms(lambda: step_fn(m, batch, nv, na, R), steps, max(warmup, 10 if not rec_train else 30))
+    host_issue = None
+    if rec_train or B < 16:   # host time to ISSUE a step (what bounds the eager loop at small batches / long launch lists)
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for _ in range(5):
+            step_fn(m, batch, nv, na, R)
+        host_issue = (time.perf_counter() - th0) / 5 * 1e3
+        torch.cuda.synchronize()
+    err, nlog = err_first if err_first is not None else (det_logit_parity(m, cfg, sd_np, dev) if det else logit_parity(m, cfg, sd_np, nv, na, dev, B=2))
     qps = B * (nv + na) / ms * 1e3
     out = {"windows_per_gpu": B, "tokens_per_window": cfg.F + cfg.num_queries(nv, na), "ms_per_step": round(ms, 3),
            "interval_queries_per_s": round(qps, 1),
@@ -381,10 +449,13 @@ def secondary_block(workload, B, precision, dev, steps, warmup, det_train=False,
            "max_abs_logit_err": float("%.3g" % err), "parity_sample": "%d outputs of 2 windows, eval mode, vs the fp32 CPU oracle" % nlog,
            "timing": "median of %d per-step HIP-event intervals after %d warm-ups (mean %.3f, max %.3f ms)"
                      % (steps, max(warmup, 10), ms_mean, ms_max)}
+    if host_issue is not None:
+        out["host_issue_ms_per_step"] = round(host_issue, 3)
     if graph:   # the same step as one HIP-graph replay (child process, as for the headline): the host-bound small model's fast path
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--workload", workload, "--batch", str(B),
-               "--precision", precision, "--steps", str(max(steps, 20)), "--warmup", str(warmup)] + (["--det-train"] if det_train else [])
+               "--precision", precision, "--steps", str(max(steps, 20)), "--warmup", str(warmup)] + (["--det-train"] if det_train else []) \
+            + (["--rec-train"] if rec_train else [])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -396,6 +467,16 @@ def secondary_block(workload, B, precision, dev, steps, warmup, det_train=False,
             out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     del m, batch
     return out
+
+
+def timing_stop_families():
+    """-> [(ms, work, launches)] for the GEMM (FLOPs), attention and LayerNorm (algorithmic bytes) launches bracketed since
+    timhip_gemm_timing_start (tim_amd/csrc/timing.hip)"""
+    import ctypes as C
+    from tim_amd import _lib as L
+    ms, wk, nl = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int * 3)()
+    L.call("timhip_timing_stop_families", C.cast(ms, C.c_void_p), C.cast(wk, C.c_void_p), C.cast(nl, C.c_void_p))
+    return [(ms[i], wk[i], nl[i]) for i in range(3)]
 
 
 def robust_step_ms(fn, steps, warmup):
@@ -449,6 +530,10 @@ def main():
     ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--det-train", action="store_true",
                     help="detection workloads (C4): the true training step (train-mode query draw, labelling, focal + DIoU) instead of the inference form")
+    ap.add_argument("--rec-train", action="store_true",
+                    help="recognition workloads: the reference's whole training iteration (mixup, four mixup cross entropies + cross-modal "
+                         "DRLoc, clip_grad_norm_, AdamW) instead of the fixed-cotangent forward + backward the metric is defined on")
+    ap.add_argument("--no-repeat", action="store_true", help="skip the four repeat sets of K steps behind the timed region")
     ap.add_argument("--no-per-shape", action="store_true", help="skip the isolated per-shape GEMM loop (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (parity sample, bf16 mode, C2b)")
     args = ap.parse_args()
@@ -501,6 +586,8 @@ def main():
         run_model = DataParallel(model, wire_dtype=wire, force=force_dp, buckets_per_exchange=int(os.environ.get("TIM_AMD_DP_BUCKETS", "4")))
     batch = make_batch(cfg, B, 0 if detection else nv, na, seed=100 + rank, dev=dev)  # each rank its own shard of windows
     R = {"target": make_det_targets(cfg, B, 6, 5 + rank, dev)} if (detection and args.det_train) else [None]
+    if args.rec_train and not detection:
+        R = make_rec_train_state(model, cfg, B, nv, na, dev, seed=rank)
 
     def barrier():
         if dp_on:
@@ -551,6 +638,7 @@ def main():
                          % (getattr(run_model, "collective", None), "gloo" if share else "RCCL"))
     eager = None
     live = None
+    fam = None
     if mode == "graph":
         # the same step issued eagerly, right BEFORE the capture and the timed region: its wall-clock rate and host issue time (the
         # robustness margin the replay buys), and - in its last step - the per-launch HIP events of the roofline: a replayed graph
@@ -565,24 +653,22 @@ def main():
         for i in range(ne):
             if i == ne - 1 and rank == 0 and not args.no_roofline:
                 from tim_amd import _lib as L
-                L.call("timhip_gemm_timing_start", 256, 1.0e10)
+                L.call("timhip_gemm_timing_start", 512, 1.0e10)
                 live = True
             step_fn(run_model, batch, nv, na, R)
         te_issue = time.perf_counter() - te0
         torch.cuda.synchronize()
         eager = {"ms_per_step": round((time.perf_counter() - te0) / ne * 1e3, 3), "host_issue_ms_per_step": round(te_issue / ne * 1e3, 3),
-                 "steps": ne, "launches_per_step": 125 if args.workload == "C2a" else None}
+                 "steps": ne}
         if live:
-            import ctypes as C
-            ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int(0)
-            L.call("timhip_gemm_timing_stop", C.byref(ms_), C.byref(fl_), C.byref(n_))
-            live = (ms_.value, fl_.value, n_.value)
+            fam = timing_stop_families()
+            live = fam[0]
     gstep = None
     graph_note = None
     if mode == "graph":
         try:
             from tim_amd.graph import GraphedStep
-            gstep = GraphedStep(run_model, lambda: step_fn(run_model, batch, nv, na, R))
+            gstep = GraphedStep(run_model, lambda: step_fn(run_model, batch, nv, na, R), count_nodes=True)
         except Exception as e:  # noqa: BLE001  (a runtime that refuses the capture: the eager steps are timed, and the line says so)
             gstep, mode = None, "eager"
             graph_note = "HIP-graph capture failed (%s: %s): eager steps timed" % (type(e).__name__, str(e)[:160])
@@ -604,7 +690,7 @@ def main():
             # roofline: HIP events around every encoder-layer GEMM launch (>= 1e10 FLOPs: excludes heads / embedders) of the
             # LAST timed step, recorded on the streams the kernels are launched on (timhip_gemm_timing_*)
             from tim_amd import _lib as L
-            L.call("timhip_gemm_timing_start", 256, 1.0e10)
+            L.call("timhip_gemm_timing_start", 512, 1.0e10)
             live = True
         run_step()
     t_enqueue = time.perf_counter() - t0   # host time to ISSUE the K steps (the GPU may still be running them)
@@ -619,8 +705,24 @@ def main():
     from tim_amd import _lib as L
     ms_, fl_, n_ = C.c_double(0), C.c_double(0), C.c_int(0)
     if live is True:
-        L.call("timhip_gemm_timing_stop", C.byref(ms_), C.byref(fl_), C.byref(n_))
-        live = (ms_.value, fl_.value, n_.value)
+        fam = timing_stop_families()
+        live = fam[0]
+    # the same K steps four more times (same barriers, same step): the line carries its own spread.  `value` / `ms_per_step`
+    # stay the FIRST set - the contract's timed region; `repeat_ms` lists all five, `median_ms` their median
+    repeat_ms = [dt / args.steps * 1e3]
+    for _ in range(0 if args.no_repeat else 4):
+        barrier()
+        tr0 = time.perf_counter()
+        for _i in range(args.steps):
+            run_step()
+        barrier()
+        dtr = time.perf_counter() - tr0
+        if dp_on:
+            import torch.distributed as dist
+            t = torch.tensor([dtr], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtr = t.item()
+        repeat_ms.append(dtr / args.steps * 1e3)
     comm = None
     if dp_on:
         # what the gradient exchange costs the step: (a) the same steps with the exchange switched off (every rank, same
@@ -710,6 +812,7 @@ def main():
         "metric": "interval-queries/sec (fwd+bwd), d=512 L=6 EPIC-100 window",
         "value": round(value, 1), "unit": "interval-queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "repeat_ms": [round(x, 3) for x in repeat_ms], "median_ms": round(sorted(repeat_ms)[len(repeat_ms) // 2], 3),
         "host_issue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "fp16"}.get(args.precision, "f32"),
         "data": "synthetic",
@@ -730,8 +833,28 @@ def main():
         pass
     if force_dp:
         out["forced_one_rank_dp"] = "TIM_AMD_BENCH_FORCE_DP=1: the data-parallel path on a one-rank RCCL group (every collective a copy) - a test mode, not a measurement"
+    if gstep is not None and getattr(gstep, "kernel_nodes", None) is not None:
+        # counted, not assumed: the kernel nodes of the captured step (hipGraphGetNodes on the graph torch captured)
+        out["launches_per_step"] = {"kernel_nodes": gstep.kernel_nodes, "all_nodes": gstep.nodes,
+                                    "source": "hipGraphGetNodes / hipGraphNodeGetType on the captured step"}
+        if eager is not None:
+            eager["launches_per_step"] = gstep.kernel_nodes
     if eager is not None:
         out["eager"] = eager
+    if fam is not None and (fam[1][2] or fam[2][2]):
+        # attention and LayerNorm launches of the SAME bracketed eager step as the roofline's GEMM events (HIP events on the launch
+        # stream; each bracket includes the ~5 us between an event and its kernel, like the GEMM ones)
+        gem, att, lnf = fam
+        tot_ms = dt / args.steps * 1e3
+        out["non_gemm"] = {
+            "attention": {"us_per_step": round(att[0] * 1e3, 1), "launches": att[2],
+                          "algorithmic_TBps": round(att[1] / att[0] / 1e9, 2) if att[0] > 0 else None},
+            "layernorm": {"us_per_step": round(lnf[0] * 1e3, 1), "launches": lnf[2],
+                          "algorithmic_TBps": round(lnf[1] / lnf[0] / 1e9, 2) if lnf[0] > 0 else None},
+            "gemm_us_per_step": round(gem[0] * 1e3, 1), "gemm_launches": gem[2],
+            "non_gemm_us_per_step": round((tot_ms - gem[0]) * 1e3, 1),
+            "note": "HIP-event brackets inside one eager step (attention: qkv / o / dO / dqkv bytes; LayerNorm: rows read + written, "
+                    "all LayerNorm launches incl. embedders and time MLP); non_gemm_us_per_step = timed ms_per_step - the GEMM brackets"}
     if comm is not None:
         out["comm"] = comm
     if fwd_ms:
@@ -837,6 +960,12 @@ def main():
         if args.workload == "C2a":
             sec_steps = max(5, args.steps // 2)
             for key, wl, b_, kw, desc in (
+                    ("c2a_b8", "C2a", 8, {"graph": True},
+                     "C2a at 8 windows per GPU: the reference recipe (global batch 64, utils/parser.py:87) on 8 GPUs - datasets/loader.py:48 "
+                     "divides the batch by the GPU count (M = 1240 rows); fixed-cotangent forward + backward like the headline"),
+                    ("c2a_train", "C2a", B, {"graph": True, "rec_train": True},
+                     "C2a, the reference's TRAINING ITERATION (recognition/scripts/train.py:184-366): time MLP -> mixup -> encoder -> "
+                     "mixup cross entropy x 4 + cross-modal DRLoc -> backward -> clip_grad_norm_(1.0) -> AdamW(fused) -> weight refresh"),
                     ("c2b", "C2b", B, {"graph": True}, "C2b: 75+75 feature tokens, 15+10 queries (S = 205), train-mode dropout"),
                     ("c1", "C1", B, {"graph": True}, "C1: visual-only, d_model 256, 2 layers, 4 heads, 50 tokens + 3 x 10 queries (S = 80), train-mode dropout"),
                     ("c3", "C3", B, {"graph": True}, "C3: Perception Test A+V recognition, 50+50 tokens, 15+10 queries, dropouts 0.1"),

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TIMHIP_VERSION 5   /* 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs, timhip_det_side_loss_{fwd,bwd}, timhip_sigmoid_bwd_rows, timhip_time_l1_fwd_split3, timhip_gather_split3_ranges, TIMHIP_EPI_RELU_SPLIT3_T, timhip_layernorm_{fwd,bwd}2, timhip_cast_rows_pair; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
+#define TIMHIP_VERSION 6   /* 6 (round 6): timhip_timing_stop_families; 5 (round 5): timhip_assemble_{fwd,bwd}_p (token / modality vectors by pointer), timhip_dx_init_slabs, timhip_det_side_loss_{fwd,bwd}, timhip_sigmoid_bwd_rows, timhip_time_l1_fwd_split3, timhip_gather_split3_ranges, TIMHIP_EPI_RELU_SPLIT3_T, timhip_layernorm_{fwd,bwd}2, timhip_cast_rows_pair; 4 (round 4): 8-word timhip_grad_scale block + non-finite flag, TIMHIP_DESC_STREAM16*, timhip_dx_init, timhip_reload_env */
 
 enum {
   TIMHIP_OK = 0,
@@ -158,6 +158,10 @@ int timhip_version(void);
 /* The launchers' A/B knobs (TIMHIP_* environment variables, tim_amd/csrc/common.h: TimKnobs) are read once, at the first
  * launch.  Test hook: read them again after changing the environment inside a process. */
 void timhip_reload_env(void);
+/* ABI 6 (tests / tools): the row tile of the eight-phase NT kernel (gemm_nt_p8_kernel: 256 x 256 / 320 x 256 tiles for the shapes
+ * that run more than one round of 160 x 256 tiles) a plain timhip_gemm_nt launch of this epilogue and shape takes - 8 (256 rows),
+ * 10 (320 rows) or 0 (another kernel); follows TIMHIP_GEMM_P8 (0 off, 1 by shape, 8 / 10 forced). */
+int timhip_gemm_p8_choice(int epi, int M, int N, int K);
 /* bit 0: the library was built with TUNING=1 (carries the measured-slower kernel variants and the ablation hooks) */
 int timhip_build_flags(void);
 const char* timhip_strerror(int code);
@@ -612,6 +616,10 @@ int timhip_window_times(const float* v_feat_times, int v_ld, const int64_t* v_ro
  * durations [ms], the summed FLOPs and the number of launches.  Not thread-safe against concurrent start/stop. */
 int timhip_gemm_timing_start(int capacity, double min_flops);
 int timhip_gemm_timing_stop(double* total_ms, double* total_flops, int* launches);
+/* ABI 6: the same stop, per kernel family - [0] the GEMM launches (work = FLOPs), [1] the attention launches, [2] the LayerNorm
+ * launches (work = their algorithmic bytes: operand rows read + rows written); each array has three entries.  While armed the
+ * attention / LayerNorm launches are bracketed like the GEMMs (no min_flops filter). */
+int timhip_timing_stop_families(double* ms3, double* work3, int* launches3);
 
 #ifdef __cplusplus
 }

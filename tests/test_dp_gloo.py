@@ -183,6 +183,10 @@ def _choice_worker(rank, world, port, q, mode):
             DP.DataParallel._preflight = refuse
         if mode == "env" and rank == 0:
             os.environ["TIM_AMD_DP_COLLECTIVE"] = "allreduce"
+        if mode == "invalid_env" and rank == 0:
+            # an invalid value on rank 0 alone: a refusal like any other (the whole group lands on all_reduce); rank 0 must not
+            # raise out of the constructor on its own afterwards, with its peers inside broadcast_parameters()
+            os.environ["TIM_AMD_DP_COLLECTIVE"] = "ring_of_fire"
         if mode == "raise":
             def broken(*a, **k):
                 raise RuntimeError("forced: backend has no all_to_all")
@@ -243,7 +247,7 @@ def _choice_worker(rank, world, port, q, mode):
         q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize("mode", ["preflight", "env", "raise", "wrong", "step_error", "rs_on_gloo", "mixed"])
+@pytest.mark.parametrize("mode", ["preflight", "env", "invalid_env", "raise", "wrong", "step_error", "rs_on_gloo", "mixed"])
 def test_collective_choice_is_collective(mode):
     """tim_amd/dp.py:_choose_collective - the all-to-all -> all-reduce fallback is decided once, by the whole group: a refusal,
     an exception or a wrong probe result on ONE rank moves EVERY rank to all_reduce before a step runs; after construction

@@ -513,6 +513,36 @@ def test_gemm_pingpong_row_tile_forced(M, N, K, tmw, knobs):
     _check_layer_gemm_epilogues("fp16", M, N, K)
 
 
+@pytest.mark.parametrize("prec", H16)
+@pytest.mark.parametrize("tm", [8, 10])
+@pytest.mark.parametrize("M,N,K", [(9920, 3072, 1024), (9920, 2048, 1024), (9925, 2048, 192), (3000, 512, 128), (7984, 3072, 1024),
+                                   (300, 256, 64 * 5), (13120, 1024, 2048)])
+def test_gemm_eight_phase_kernel(prec, M, N, K, tm, knobs):
+    """gemm_nt_p8_kernel (round 6): 256 x 256 (TM = 8) and 320 x 256 (TM = 10) tiles on the eight-phase schedule - four quadrant
+    phases per contraction step, half-tiles restaged one phase after their last fragment read, one counted vmcnt per step -
+    FORCED (TIMHIP_GEMM_P8 = 8 / 10) on the layer's multi-round shapes, on row counts neither tile divides (ragged last panel: 9925,
+    7984, 300 rows), one / two rounds of tiles, 2 .. 32 contraction steps: the three epilogues it carries (16-bit store + bias,
+    GELU + dropout with two outputs, multiply by the saved factor) against fp64, the others through their usual kernels"""
+    knobs(TIMHIP_GEMM_P8=str(tm))
+    for epi in (L.EPI_STORE_T, L.EPI_GELU_DROP_G2, L.EPI_MULAUX_T):
+        assert L.load().timhip_gemm_p8_choice(epi, M, N, K) == tm     # really this kernel
+    assert L.load().timhip_gemm_p8_choice(L.EPI_DROP_RES_F32, M, N, K) == 0
+    _check_layer_gemm_epilogues(prec, M, N, K)
+
+
+def test_gemm_eight_phase_choice(knobs):
+    """which shapes take it by themselves (TIMHIP_GEMM_P8=1): C2a's three multi-round products - N = 3072 on 256 rows (468 tiles =
+    1.83 rounds), N = 2048 on 320 rows (248 tiles = one round) - and nothing that fits one round of 160 x 256 tiles"""
+    knobs(TIMHIP_GEMM_P8="1")
+    ch = L.load().timhip_gemm_p8_choice
+    assert ch(L.EPI_STORE_T, 9920, 3072, 1024) == 8
+    assert ch(L.EPI_GELU_DROP_G2, 9920, 2048, 1024) == 10 and ch(L.EPI_MULAUX_T, 9920, 2048, 1024) == 10
+    assert ch(L.EPI_STORE_T, 9920, 1024, 3072) == 0 and ch(L.EPI_STORE_T, 1240, 3072, 1024) == 0
+    assert ch(L.EPI_STORE_T, 9920, 3072, 64) == 0          # one contraction step: the two-buffer prologue needs two
+    knobs(TIMHIP_GEMM_P8="0")
+    assert ch(L.EPI_STORE_T, 9920, 3072, 1024) == 0
+
+
 @pytest.mark.tuning
 @pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("M,N,K", _PP_SHAPES)
@@ -750,13 +780,16 @@ def test_cast_rows_pair_is_two_cast_rows(prec):
     assert not torch.equal(got[0][:, :24], got[1][:, :24])
 
 
+@pytest.mark.parametrize("R", [160, 8000])
 @pytest.mark.parametrize("prec", ["fp16", "fp32"])
-def test_layernorm_pair_is_two_layernorms(prec):
+def test_layernorm_pair_is_two_layernorms(prec, R):
     """timhip_layernorm_fwd2 / _bwd2: two LayerNorms (GELU in front, as the modality embedders) over stacked rows with a second
     parameter set from the split row on - outputs, statistics, operand-dtype gradients and both parameter-gradient pairs equal two
-    separate launches (the parameter gradients up to the order of their atomics)"""
+    separate launches (the parameter gradients up to the order of their atomics).  R = 8000 (B = 160 windows of 50 feature tokens,
+    16000 stacked rows): past 12288 rows the backward's balanced-round choice is 24 rows per block, which does not divide 8000 -
+    the launch falls back to 16-row blocks instead of refusing (round-5 advisor finding)"""
     rt = Runtime(prec)
-    R, d = 160, 512
+    d = 512
     u = rnd(2 * R, d, seed=1).to(DEV)
     g = rnd(2 * R, d, seed=2).to(DEV)
     ws = [(1.0 + 0.1 * rnd(d, seed=3 + i)).to(DEV) for i in range(2)]
@@ -782,10 +815,10 @@ def test_layernorm_pair_is_two_layernorms(prec):
     torch.cuda.synchronize()
     assert torch.equal(dy_w, dy_g)
     for a, b in zip(dgw, dgg):
-        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
-    assert L.load().timhip_layernorm_bwd2(rt.prec, L.ptr(g), d, L.ptr(u), d, L.ptr(st_g), 2 * R, d, 2, L.ptr(ws[0]), R + 8, L.ptr(ws[1]),
+        assert (a - b).abs().max().item() <= (1e-5 if R < 1000 else 1e-4) * a.abs().max().item()
+    assert L.load().timhip_layernorm_bwd2(rt.prec, L.ptr(g), d, L.ptr(u), d, L.ptr(st_g), 2 * R, d, 2, L.ptr(ws[0]), R + 2, L.ptr(ws[1]),
                                           None, 0, L.ptr(dy_g), d, L.ptr(dgg[0]), L.ptr(dgg[1]), L.ptr(dgg[2]), L.ptr(dgg[3]), None,
-                                          st()) != 0      # the halves must meet at a multiple of the 16-row blocks
+                                          st()) != 0      # the halves must meet at a multiple of 4 rows (one row per wave and pass)
 
 
 @pytest.mark.parametrize("prec", H16)

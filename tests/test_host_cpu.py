@@ -258,3 +258,10 @@ def test_gradient_bucket_layout_is_cached_and_consistent():
         # consecutive buckets are contiguous
         for a, b in zip(lay.order, lay.order[1:]):
             assert lay.bucket[a][0] + lay.bucket[a][1] == lay.bucket[b][0]
+    # a parameter replaced under the same name with another size (a resized head) must not meet the cached layout
+    i = names.index("cls_head.fc_visual_verb.weight")
+    params2 = list(params)
+    params2[i] = torch.nn.Parameter(torch.zeros(params[i].shape[0] + 3, params[i].shape[1]))
+    gb2 = m._alloc_grad_buckets(names, params2, torch.device("cpu"), layer_overwrite=True)
+    assert gb2.views[names[i]].shape == params2[i].shape
+    assert gb2.base.numel() >= gb.base.numel()

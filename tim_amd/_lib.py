@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TIM_AMD_LIB") or os.path.join(_HERE, "libtimhip.so")   # (TIM_AMD_LIB: an A/B build of the library, tools only)
 
-ABI_VERSION = 5   # include/timhip.h: TIMHIP_VERSION
+ABI_VERSION = 6   # include/timhip.h: TIMHIP_VERSION
 PREC_BF16, PREC_BF16X3, PREC_FP32, PREC_F16 = 0, 1, 2, 3
 PRECISIONS = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp32": PREC_FP32, "fp16": PREC_F16}
 H16 = (PREC_BF16, PREC_F16)   # 16-bit operand storage (the MFMA GEMM / attention / transposing weight-gradient kernels)
@@ -140,6 +140,7 @@ _SIGS = {
     "timhip_window_times": (C.c_int, [vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, f32, vp, vp]),
     "timhip_gemm_timing_start": (C.c_int, [i32, C.c_double]),
     "timhip_gemm_timing_stop": (C.c_int, [vp, vp, vp]),
+    "timhip_timing_stop_families": (C.c_int, [vp, vp, vp]),
     "timhip_drloc_gather": (C.c_int, [i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp, i32, vp]),
     "timhip_drloc_scatter_add": (C.c_int, [vp, i32, vp, vp, C.c_int64, C.c_int64, i32, i32, i32, vp, vp, i32, vp]),
     "timhip_scatter_rows_add": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
@@ -158,6 +159,7 @@ _SIGS = {
     "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),
     "timhip_reload_env": (None, []),
     "timhip_build_flags": (C.c_int, []),
+    "timhip_gemm_p8_choice": (C.c_int, [i32, i32, i32, i32]),
     "timhip_dp_reduce": (C.c_int, [i32, vp, i32, C.c_longlong, f32, vp, vp]),
     "timhip_split3_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "timhip_label_queries": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),

@@ -167,6 +167,7 @@ void read_knobs(TimKnobs& k) {
   k.ln_rpb_small = env_int("TIMHIP_LN_RPB_SMALL", 0);
   k.gemm_pp_min = env_int("TIMHIP_GEMM_PP_MIN_TILES", 192);
   k.attn_ks = env_int("TIMHIP_ATTN_KS", 1);
+  k.gemm_p8 = env_int("TIMHIP_GEMM_P8", 0);
 }
 }  // namespace
 const TimKnobs& tim_knobs() {
@@ -183,6 +184,7 @@ extern "C" {
 
 int timhip_version(void) { return TIMHIP_VERSION; }
 void timhip_reload_env(void) { g_knobs_state.store(0, std::memory_order_release); (void)tim_knobs(); }
+int timhip_gemm_p8_choice(int epi, int M, int N, int K) { return tim_gemm_p8_choice(epi, M, N, K); }
 int timhip_build_flags(void) {
 #ifdef TIMHIP_TUNING
   return 1;

@@ -252,6 +252,8 @@ int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hi
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse) return TIMHIP_EINVAL;
+  // (bench.py's non-GEMM brackets: qkv read, o written, in the operand type)
+  TimGemmScope timing((double)d.B * d.S * d.E * 4 * (h16_storage(d.precision) ? 2 : 4), s, 1);
   if (h16_storage(d.precision) && !(d.reserved & 1)) {  // reserved bit 0: force the fp32-arithmetic kernels
     rc = tim_attention_fwd_mfma(d, qkv, o, lse, s);
     if (rc != TIMHIP_EUNSUPPORTED) return rc;
@@ -283,6 +285,8 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse || !d_o || !dqkv || !ws) return TIMHIP_EINVAL;
+  // (qkv, o, dO read; dqkv written)
+  TimGemmScope timing((double)d.B * d.S * d.E * 8 * (h16_storage(d.precision) ? 2 : 4), s, 1);
   if (h16_storage(d.precision) && !(d.reserved & 1)) {
     if (!(d.reserved & 2)) {  // reserved bit 1: force the single-kernel MFMA backward
       rc = tim_attention_bwd2_mfma(d, qkv, o, lse, d_o, dqkv, ws, ws_bytes, s);

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
   ATT_STAMP(0);
   // key-split form: this thread's 16-byte chunks of the Q / dO rows (row (tid >> 4) + 32 sw, chunk tid & 15) - requested before
   // the K / V staging, written to LDS by phase 0, and kept in registers for phase 2 (which wants exactly these chunks again)
-  constexpr int NSW = (FUSED && KS) ? 6 : 1;   // S <= 192 (fused_fits)
+  constexpr int NSW = (FUSED && KS) ? 6 : 1;   // row sweeps of 32 (the key-split form fits S <= 160 = 5 sweeps: fused_fits; 6 keeps XU below in step)
   constexpr int NKV = (FUSED && KS) ? 4 : 1;   // 128 key rows / 32
   vec8<HT> qv[NSW], dv[NSW], kst[NKV], vst[NKV];
   vec8<HT> ov, kv, vv;   // one sweep's O / own-key / own-value chunks: requested one pipeline step ahead of their use
@@ -739,11 +739,13 @@ static inline int rows_waves(int S) {
   return n;
 }
 
-// fused form: DH = 128, 97..128 feature keys, K / V / dS / P~ within the 160 KB of LDS (S <= 192)
-static inline bool fused_fits(const TimDesc& d) {
+// fused form: DH = 128, 97..128 feature keys, K / V / dS / P~ within the 160 KB of LDS: S <= 192 for the one-wave-per-row-block
+// form; the key-split pipeline (KS) keeps 12 bytes of per-row scalars more and fits S <= 160
+static inline bool fused_fits(const TimDesc& d, bool ks) {
   if (tim_knobs().attn_fused == 0) return false;
   const int SP = (d.S + 31) & ~31;
-  return d.E / d.H == 128 && (d.F + 31) / 32 == 4 && (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 + (size_t)SP * 12 <= 160 * 1024;
+  return d.E / d.H == 128 && (d.F + 31) / 32 == 4 &&
+         (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 + (ks ? (size_t)SP * 12 : 0) <= 160 * 1024;
 }
 
 template <typename HT, bool KS>
@@ -795,12 +797,13 @@ size_t tim_attention_bwd2_ws(const TimDesc& d) {
 int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                             void* dqkv, void* ws, size_t ws_bytes, hipStream_t s) {
   if (!h16_storage(d.precision) || (d.E % 8) != 0 || d.B * d.H > 65535) return TIMHIP_EUNSUPPORTED;
-  if (fused_fits(d)) {
+  const bool ks_ok = tim_knobs().attn_ks != 0 && fused_fits(d, true);
+  if (ks_ok || fused_fits(d, false)) {   // (160 < S <= 192: the key-split form does not fit, the plain fused form still does)
     void* stamps = nullptr;   // (tuning builds, abl bit 16: per-block phase stamps into the caller's workspace, 64 B per block)
 #ifdef TIMHIP_TUNING
     if (((d.reserved >> 8) & 16) && ws && ws_bytes >= (size_t)d.B * d.H * 64) stamps = ws;
 #endif
-    if (tim_knobs().attn_ks != 0) DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, true>(d, qkv, o, lse, d_o, dqkv, stamps, s)));
+    if (ks_ok) DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, true>(d, qkv, o, lse, d_o, dqkv, stamps, s)));
     DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, false>(d, qkv, o, lse, d_o, dqkv, stamps, s)));
   }
   if (!ws || ws_bytes < tim_attention_bwd2_ws(d)) return TIMHIP_EUNSUPPORTED;

@@ -295,6 +295,7 @@ struct TimKnobs {
   int gemm_tmw;       // TIMHIP_GEMM_TMW     5 / 4: force the 160- / 128-row tile of the loader-wave NT kernels (0: by shape)
   int attn_ks;        // TIMHIP_ATTN_KS      0: fused attention backward with the one-wave-per-row-block phase 1 (default 1: key-split)
   int gemm_pp_min;    // TIMHIP_GEMM_PP_MIN_TILES  fewest 160 x 256 tiles the one-block-per-CU NT kernels are used for (default 192)
+  int gemm_p8;        // TIMHIP_GEMM_P8      eight-phase 256 / 320 x 256 tiles for the multi-round NT shapes: 0 off, 1 by shape, 8 / 10 forced
 };
 const TimKnobs& tim_knobs();
 
@@ -403,7 +404,7 @@ __device__ __forceinline__ void glds_wait() {
 // ----------------------------------------------------------------------------
 // timing.hip: brackets a GEMM-family launch with HIP events while timhip_gemm_timing_start() is armed (bench.py roofline)
 struct TimGemmScope {
-  TimGemmScope(double flops, hipStream_t s);
+  TimGemmScope(double flops, hipStream_t s, int family = 0);   // family 1: attention, 2: LayerNorm (work = algorithmic bytes)
   ~TimGemmScope();
   int slot;
   hipStream_t stream;
@@ -414,6 +415,7 @@ int tim_gemm_nt(int precision, int epi, const void* A, int lda, const void* B, i
 int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, hipStream_t s);
 // gemm_pp.hip: the one-block-per-CU ping-pong kernel for the encoder-layer shapes (epi_dev: the caller's EpiDev)
 bool tim_gemm_pp_wins(int M, int N, int K, int splitk);
+int tim_gemm_p8_choice(int epi, int M, int N, int K);   // gemm_pp.hip: 8 / 10 = the eight-phase kernel's row tile for this launch, 0 = not taken
 // gemm_pp.hip: out-projection / linear2 with the LayerNorm that follows fused into the epilogue (gemm_nt_ldln_kernel)
 struct TimLnFuse {
   void* xt; int ldt; float* xf; int ldx; float* stats; const float* g; const float* b;            // LayerNorm outputs / parameters

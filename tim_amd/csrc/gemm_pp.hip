@@ -46,7 +46,8 @@ __device__ __forceinline__ void pp_wait_lds() { asm volatile("s_waitcnt lgkmcnt(
 // store (8-wave kernel, 256 VGPRs per wave); 2 = a two-deep ring refilled after each block's stores (12-wave kernel, 168 VGPRs).
 struct PpNoSync { __device__ __forceinline__ void operator()() const {} };
 // AFTER: called after every 16-row block (the dual-group kernel keeps its barrier cadence there; default: nothing)
-template <typename HT, int EPI, int TMW, int PFD = TMW, typename AFTER = PpNoSync>
+// PFA (round 6): the same ring depth for the 16-bit aux rows (default: all row blocks before the first store, as before)
+template <typename HT, int EPI, int TMW, int PFD = TMW, typename AFTER = PpNoSync, int PFA = TMW>
 __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc)[PP_TNW][TMW], int mw0, int nw0, int M, int N,
                                             float* ep, int lane, AFTER after = AFTER{}) {
   constexpr int EP_COLS = 64, EP_LD = EP_COLS + 4, CPR = EP_COLS / 4, OPR = EP_COLS / 8, RBS = 16;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
   constexpr bool PRE_AUX = (EPI == TIMHIP_EPI_DGELU_T || EPI == TIMHIP_EPI_DRELU_T || EPI == TIMHIP_EPI_MULAUX_T);
   float4 rbuf[PFD][PRE_RES ? NITQ : 1];
   float2 sbuf[PFD][PRE_RES ? NITQ : 1];
-  vec8<HT> abuf[TMW][PRE_AUX ? NITO : 1];
+  vec8<HT> abuf[PFA][PRE_AUX ? NITO : 1];
   const bool pre_res = PRE_RES && e.vec && e.res != nullptr;
   const bool pre_ln = pre_res && EPI == TIMHIP_EPI_DROP_RES_F32 && e.ln_stats != nullptr;
   const bool pre_aux = PRE_AUX && e.vec8;
@@ -94,19 +95,23 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
       }
     }
   };
-  static_for<TMW>([&](auto jc) {
+  auto fetch_aux = [&](auto jc) {   // row block j -> ring entry j % PFA
     constexpr int j = decltype(jc)::value;
-    if constexpr (j < PFD) fetch_res(jc);
     if constexpr (PRE_AUX) {
       if (pre_aux) {
 #pragma unroll
         for (int it = 0; it < NITO; ++it) {
           const int idx = it * 64 + lane;
           const int m = mw0 + j * RBS + idx / OPR, n = nw0 + (idx % OPR) * 8;
-          if (m < M && n + 7 < N) abuf[j][it] = __builtin_nontemporal_load(reinterpret_cast<const vec8<HT>*>((const HT*)e.aux + (size_t)m * e.ldaux + n));
+          if (m < M && n + 7 < N) abuf[j % PFA][it] = __builtin_nontemporal_load(reinterpret_cast<const vec8<HT>*>((const HT*)e.aux + (size_t)m * e.ldaux + n));
         }
       }
     }
+  };
+  static_for<TMW>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < PFD) fetch_res(jc);
+    if constexpr (j < PFA) fetch_aux(jc);
   });
   // per-lane constants: the lane's output columns are the same in every chunk it handles
   float4 bias8[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, bias4 = bias8[0];
@@ -148,7 +153,7 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
         const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 8 + 4);
         const int m = mw0 + j * RBS + row, n = nw0 + ch * 8;
         if (m < M && n + 7 < N) {
-          epi_oct<EPI, HT>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j][PRE_AUX ? it : 0], pre_b8, bias8[0], bias8[1]);
+          epi_oct<EPI, HT>(e, m, n, N, lo, hi, mbyte[j][it], pre_aux, abuf[j % PFA][PRE_AUX ? it : 0], pre_b8, bias8[0], bias8[1]);
         } else if (m < M) {
           if (n < N) epi_quad<EPI, HT>(e, m, n, N, lo.x, lo.y, lo.z, lo.w);
           if (n + 4 < N) epi_quad<EPI, HT>(e, m, n + 4, N, hi.x, hi.y, hi.z, hi.w);
@@ -167,6 +172,7 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
       }
     }
     if constexpr (j + PFD < TMW) fetch_res(std::integral_constant<int, j + PFD>{});   // refill this block's ring entry
+    if constexpr (j + PFA < TMW) fetch_aux(std::integral_constant<int, j + PFA>{});
     pp_wait_lds();   // reads done before the next row block overwrites the region
     after();
   });
@@ -746,6 +752,206 @@ __global__ __launch_bounds__(768) void gemm_nt_ldp_kernel(const HT* __restrict__
   }
 }
 
+// ---- eight-phase form (gemm_nt_p8_kernel, round 6): 256 x 256 / 320 x 256 tiles for the multi-round shapes ---------------------
+// The three products of a layer that run two or three rounds of 160 x 256 tiles (in-projection forward N = 3072; linear1 forward
+// and linear2's input gradient N = 2048) were the slowest of the eight (920 - 940 TFLOP/s with plain stores against 950 - 1200 for
+// the one-round shapes; hipBLASLt's 256 x 256 macro tile reached 1090 on the in-projection): every extra tile of a block's walk
+// costs an epilogue the matrix pipes sit out, and a 160-row tile stages 98 FLOP per byte.  This kernel gives them ONE tile per CU
+// and round again: 320 x 256 (N = 2048: 31 x 8 = 248 tiles, 142 FLOP per staged byte) or 256 x 256 (N = 3072: 39 x 12 = 468
+// tiles = 1.83 rounds, 128 FLOP per byte), on the schedule of cdna_hip_programming.md section 5 ("the 256^2 8-phase template"):
+//   * 8 waves = 2 (M) x 4 (N), wave tile 16 TM x 64 (TM = 8 / 10 MFMA row tiles; 128 / 160 accumulator registers), NO loader
+//     waves (their 168-register budget cannot hold the accumulators);
+//   * a contraction step (64 deep) is FOUR phases, one quadrant of the wave tile each - (rows 0, cols 0) (0, 1) (1, 1) (1, 0) - so
+//     that consecutive phases share one operand's fragments: 12 / 4 / TM / 4 ds_read_b128 feed 2 TM MFMAs per phase;
+//   * each phase: [fragment reads; ONE half-tile of LDS-DMA pieces (2 - 3 per wave); lgkmcnt(0)] barrier [MFMAs] barrier; the two
+//     waves of a SIMD run one barrier apart (waves 4 - 7 behind waves 0 - 3), so a SIMD's matrix pipe always has a wave in its MFMA
+//     segment while the partner reads / issues;
+//   * LDS: two contraction-step buffers of (BM + 256) x 128 B (128 / 144 KiB).  A step's tile is staged as four half-tiles
+//     (A rows of row-quadrant 0 / 1, B rows of column-quadrant 0 / 1) into the space whose last fragment read is ONE phase old:
+//       phase 1 of step t: B0 of step t + 1 -> other buffer;  phases 2 / 3 / 4: A0 / B1 / A1 of step t + 2 -> this buffer;
+//     ONE counted wait per step (phase 4: vmcnt = the three newest half-tiles stay in flight) - the DMA stream is never drained.
+// Hazards (segment = the code between two barriers; group 0 reads in segment 2p and multiplies in 2p + 1, group 1 one later):
+//   WAR  every fragment read of phase p is complete (lgkmcnt(0) BEFORE the barrier) by the end of segment 2p + 1; the earliest
+//        DMA piece into that space is issued in phase p + 1's read segment: 2p + 2 (group 0) / 2p + 3 (group 1).
+//   RAW  the counted wait of phase 4 sits before that phase's first barrier in both groups (segments 2p, 2p + 1); the data is
+//        first read in the next phase (segments 2p + 2, 2p + 3), i.e. behind a barrier every waiting wave has passed.
+template <int TM, int G> struct P8Share {
+  static_assert(TM == 8 || TM == 10, "half-tile tables: the 256- and the 320-row tile");
+  static constexpr int NA = TM == 8 ? 2 : (G == 0 ? 3 : 2);   // A half-tile = 2 TM pieces of 1 KiB: 16 = 8 x 2, 20 = 4 x 3 + 4 x 2
+  static constexpr int NB = 2;                                 // B half-tile = 16 pieces
+};
+struct P8Tab { uint32_t offA[2][3], offB[2][2]; int dstA[2][3], dstB[2][2]; };
+
+template <typename HT, int TM, int G>
+__device__ __forceinline__ void p8_mainloop(const HT* __restrict__ A, const HT* __restrict__ B, int nk, const char* lds, uint32_t lds0,
+                                            const P8Tab& tb, int a_frag, int b_frag, int c0, int c1, f32x4_t (&acc)[PP_TNW][TM]) {
+  constexpr int BM = 32 * TM, KT = (BM + PP_BN) * PP_ROWB, HM = TM / 2;
+  constexpr int NA = P8Share<TM, G>::NA, NB = P8Share<TM, G>::NB;
+  auto stage_a = [&](int kt, uint32_t buf, int h) {
+    const void* g = uniform_ptr(reinterpret_cast<const char*>(A) + (size_t)kt * PP_ROWB);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) glds16_s(g, tb.offA[h][i], buf + tb.dstA[h][i]);
+  };
+  auto stage_b = [&](int kt, uint32_t buf, int h) {
+    const void* g = uniform_ptr(reinterpret_cast<const char*>(B) + (size_t)kt * PP_ROWB);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) glds16_s(g, tb.offB[h][i], buf + tb.dstB[h][i]);
+  };
+  // prologue: steps 0 and 1 whole
+  stage_a(0, lds0, 0); stage_b(0, lds0, 0); stage_b(0, lds0, 1); stage_a(0, lds0, 1);
+  if (nk > 1) { stage_a(1, lds0 + KT, 0); stage_b(1, lds0 + KT, 0); stage_b(1, lds0 + KT, 1); stage_a(1, lds0 + KT, 1); }
+  glds_wait<0>();
+  pp_barrier();
+  if constexpr (G == 1) pp_barrier();   // one segment behind group 0 from here on
+
+  vec8<HT> xa[HM][2], wb[2][2];
+  auto read_a = [&](const char* bb, int qm) {
+#pragma unroll
+    for (int i = 0; i < HM; ++i) {
+      xa[i][0] = *reinterpret_cast<const vec8<HT>*>(bb + a_frag + (qm * 8 * TM + i * 16) * PP_ROWB + c0);
+      xa[i][1] = *reinterpret_cast<const vec8<HT>*>(bb + a_frag + (qm * 8 * TM + i * 16) * PP_ROWB + c1);
+    }
+  };
+  auto read_b = [&](const char* bb, int qn) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      wb[j][0] = *reinterpret_cast<const vec8<HT>*>(bb + b_frag + (qn * 32 + j * 16) * PP_ROWB + c0);
+      wb[j][1] = *reinterpret_cast<const vec8<HT>*>(bb + b_frag + (qn * 32 + j * 16) * PP_ROWB + c1);
+    }
+  };
+  auto mma = [&](auto qm_c, auto qn_c) {
+    constexpr int qm = decltype(qm_c)::value, qn = decltype(qn_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < HM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[2 * qn + j][qm * HM + i] = mfma16x16<HT>(wb[j][kh], xa[i][kh], acc[2 * qn + j][qm * HM + i]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    const char* bb = lds + b * KT;
+    const uint32_t cur = lds0 + b * KT, oth = lds0 + (b ^ 1) * KT;
+    const bool s1 = t >= 1 && t + 1 < nk, s2 = t + 2 < nk;
+    // phase 1: quadrant (0, 0)
+    read_b(bb, 0); read_a(bb, 0);
+    if (s1) stage_b(t + 1, oth, 0);
+    pp_wait_lds(); pp_barrier();
+    mma(I0{}, I0{});
+    pp_barrier();
+    // phase 2: quadrant (0, 1) - A fragments kept
+    read_b(bb, 1);
+    if (s2) stage_a(t + 2, cur, 0);
+    pp_wait_lds(); pp_barrier();
+    mma(I0{}, I1{});
+    pp_barrier();
+    // phase 3: quadrant (1, 1) - B fragments kept
+    read_a(bb, 1);
+    if (s2) stage_b(t + 2, cur, 1);
+    pp_wait_lds(); pp_barrier();
+    mma(I1{}, I1{});
+    pp_barrier();
+    // phase 4: quadrant (1, 0) - A fragments kept; the step's one counted wait: B0 of step t + 1 (and everything older) has landed
+    read_b(bb, 0);
+    if (s2) { stage_a(t + 2, cur, 1); glds_wait<2 * NA + NB>(); } else { glds_wait<0>(); }
+    pp_wait_lds(); pp_barrier();
+    mma(I1{}, I0{});
+    pp_barrier();
+  }
+  if constexpr (G == 0) pp_barrier();   // as many barriers as group 1
+}
+
+template <typename HT, int EPI, int TM>
+__global__ __launch_bounds__(512) void gemm_nt_p8_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
+                                                         int M, int N, int K, EpiDev e) {
+  constexpr int BM = 32 * TM, A_BYTES = BM * PP_ROWB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][A tile BM x 128 B | B tile 256 x 128 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (N + PP_BN - 1) / PP_BN, tiles_m = (M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * PP_BN;
+  // this wave's DMA pieces of the four half-tiles: piece q of an A half = 8 rows at (q / TM) * 16 TM + h * 8 TM + (q % TM) * 8,
+  // of a B half at (q / 4) * 64 + h * 32 + (q % 4) * 8; lane -> (row, 16-byte chunk), the chunk swizzled on the SOURCE side
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  const int na = TM == 8 ? 2 : (wr == 0 ? 3 : 2);
+  const int qa0 = TM == 8 ? 2 * wave : (wr == 0 ? 3 * wave : 12 + 2 * (wave - 4));
+  P8Tab tb;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int q = qa0 + (i < na ? i : 0);
+      const int r0 = (q / TM) * 16 * TM + h * 8 * TM + (q % TM) * 8, row = r0 + lrow;
+      const int c = (lchunk ^ kswz<64>(row)) * 8;
+      tb.offA[h][i] = (uint32_t)(((size_t)min(m0 + row, M - 1) * lda + c) * 2);
+      tb.dstA[h][i] = r0 * PP_ROWB;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = 2 * wave + i;
+      const int r0 = (q / 4) * 64 + h * 32 + (q % 4) * 8, row = r0 + lrow;
+      const int c = (lchunk ^ kswz<64>(row)) * 8;
+      tb.offB[h][i] = (uint32_t)(((size_t)min(n0 + row, N - 1) * ldb + c) * 2);
+      tb.dstB[h][i] = A_BYTES + r0 * PP_ROWB;
+    }
+  }
+  // fragment reads: lane -> (row = lane & 15 of a 16-row tile, 16-byte chunk 4 half + (lane >> 4)), swizzled like the stage
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  const int c0 = (fk ^ sw) << 4, c1 = ((fk + 4) ^ sw) << 4;
+  const int a_frag = (wr * 16 * TM + frow) * PP_ROWB;
+  const int b_frag = A_BYTES + (wc * 64 + frow) * PP_ROWB;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  f32x4_t acc[PP_TNW][TM];
+#pragma unroll
+  for (int i = 0; i < PP_TNW; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nk = K / 64;
+  if (wr == 0) p8_mainloop<HT, TM, 0>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+  else p8_mainloop<HT, TM, 1>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+  __syncthreads();   // every wave is done with the buffers: they become the epilogue's transposition space
+  float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
+  pp_epilogue<HT, EPI, TM, 2, PpNoSync, 2>(e, acc, m0 + wr * 16 * TM, n0 + wc * 64, M, N, ep, lane);
+}
+
+template <typename HT, int EPI, int TM>
+void launch_p8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const EpiDev& e, hipStream_t s) {
+  constexpr int BM = 32 * TM;
+  const size_t shmem = (size_t)2 * (BM + PP_BN) * PP_ROWB;
+  static PerDeviceOnce attr_set;
+  if (attr_set.first())
+    (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<HT, EPI, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<HT, EPI, TM>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+}
+
+// Which shapes: the ones that run MORE than one round of 160 x 256 tiles, when one of the two big tiles fills its rounds to at
+// least 85 % (useful tile area / (rounds x 256 CUs)).  C2a, M = 9920: N = 3072 -> 256 rows (0.91), N = 2048 -> 320 rows (0.97),
+// N = 1024 stays on the one-round 160-row kernel.  TIMHIP_GEMM_P8 = 0: off; 1: by shape; 8 / 10: that tile for every legal shape (tests)
+static int p8_choice(int epi, int M, int N, int K, const EpiDev& e) {
+  const int kn = tim_knobs().gemm_p8;
+  if (kn == 0 || e.a_wrap != 0 || K % 64 || K < 128 || N % PP_BN || M < 1) return 0;
+  if (epi != TIMHIP_EPI_STORE_T && epi != TIMHIP_EPI_GELU_DROP_G2 && epi != TIMHIP_EPI_MULAUX_T) return 0;
+  if (kn == 8 || kn == 10) return kn;
+  const long long t160 = (long long)((M + 159) / 160) * (N / PP_BN);
+  if (t160 <= 256) return 0;
+  auto fill = [&](int bm) {
+    const long long tiles = (long long)((M + bm - 1) / bm) * (N / PP_BN), rounds = (tiles + 255) / 256;
+    return (double)M * N / ((double)bm * PP_BN) / (double)(rounds * 256);
+  };
+  const double f8 = fill(256), f10 = fill(320);
+  if (f10 >= f8 && f10 >= 0.85) return 10;
+  if (f8 >= 0.85) return 8;
+  return 0;
+}
+
 // ---- residual + LayerNorm fused into the epilogue (gemm_nt_ldln_kernel, round 3) ---------------------------
 // out-projection / linear2 of an encoder layer: y = res + dropout(A B^T + bias) AND LayerNorm(y) in ONE launch, for N = the
 // LayerNorm width <= 1024 at M a multiple of 160 (one round of tiles: every block co-resident).  A 160 x 256 tile holds a
@@ -1323,6 +1529,12 @@ static bool tim_gemm_dg_ok(int M, int N, int K, const EpiDev& e) {
 
 #endif
 
+// (tests / tools: which row tile of the eight-phase kernel a plain launch of this shape and epilogue would take - 8, 10 or 0)
+int tim_gemm_p8_choice(int epi, int M, int N, int K) {
+  EpiDev e{};
+  return p8_choice(epi, M, N, K, e);
+}
+
 int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K, const void* epi_dev,
                    hipStream_t s) {
   const EpiDev& e = *reinterpret_cast<const EpiDev*>(epi_dev);
@@ -1351,6 +1563,17 @@ int tim_gemm_nt_pp(int precision, int epi, const void* A, int lda, const void* B
   }
 plain:
 #endif
+  if (const int tm8 = p8_choice(epi, M, N, K, e)) {
+    switch (epi) {
+#define CASE(X) case X: DISPATCH_H16(precision, (tm8 == 8 ? launch_p8<HT, X, 8>(A, lda, B, ldb, M, N, K, e, s) : launch_p8<HT, X, 10>(A, lda, B, ldb, M, N, K, e, s))); break;
+      CASE(TIMHIP_EPI_STORE_T)
+      CASE(TIMHIP_EPI_GELU_DROP_G2)
+      CASE(TIMHIP_EPI_MULAUX_T)
+#undef CASE
+      default: return TIMHIP_EUNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+  }
   switch (epi) {
 #define CASE(X) case X: DISPATCH_H16(precision, (tall ? launch_pp<HT, X, 5>(A, lda, B, ldb, M, N, K, e, s) : launch_pp<HT, X, 4>(A, lda, B, ldb, M, N, K, e, s))); break;
     CASE(TIMHIP_EPI_STORE_T)

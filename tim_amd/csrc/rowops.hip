@@ -1239,6 +1239,8 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
                       uint8_t* mask_out, int mask_cols, float mask_p, uint64_t mask_seed, uint32_t mask_site,
                       const uint32_t* run_if, int split_row, const float* w2, const float* b2) {
   if (!y || !w || !b || rows <= 0) return TIMHIP_EINVAL;
+  // (bench.py's non-GEMM brackets: fp32 rows read; fp32 and / or operand-type rows written)
+  TimGemmScope timing((double)rows * cols * (4 + (xf ? 4 : 0) + (xt ? (f32_storage(precision) ? 4 : 2) : 0)) + (mask_out ? (double)rows * mask_cols / 8 : 0.0), s, 2);
   LnSplit sp{0x7fffffff, nullptr, nullptr, nullptr, nullptr};
   if (split_row > 0 && split_row < rows) {
     if (!w2 || !b2 || (((uintptr_t)w2 | (uintptr_t)b2) & 15)) return TIMHIP_EINVAL;
@@ -1291,18 +1293,28 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
                       hipStream_t s, bool defer_colsum, const float* t_scale, const void* addt, int ldadd,
                       const float* add_scale, int stream16, int split_row, const float* w2, float* dgamma2, float* dbeta2) {
   if (!dx || !y || !stats || !w || rows <= 0) return TIMHIP_EINVAL;
+  // (gradient rows + pre-norm rows read, the 16-bit addend if any; fp32 and / or operand-type gradient rows written)
+  TimGemmScope timing((double)rows * cols * (8 + (addt ? 2 : 0) + (dyf ? 4 : 0) + (dyt ? (f32_storage(precision) ? 4 : 2) : 0)), s, 2);
   LnSplit sp{0x7fffffff, nullptr, nullptr, nullptr, nullptr};
-  if (split_row > 0 && split_row < rows) {   // (per block: the halves must meet at a multiple of the block's rows, no partials)
-    const int rpb_ = (!partial_ws && tim_knobs().ln_rpb_small >= 4) ? tim_knobs().ln_rpb_small / 4 * 4 : ln_bwd_rows_per_block(rows);
-    if (!w2 || partial_ws || split_row % rpb_) return TIMHIP_EINVAL;
-    sp.row = split_row; sp.w2 = w2; sp.dg2 = dgamma2; sp.db2 = dbeta2;
-  }
   if (stream16 && (act != 0 || !h16_storage(precision) || !add_scale || !t_scale)) return TIMHIP_EUNSUPPORTED;
   if (cols % 4 || cols > 256 * LN_MAXV_MAX || ldy % 4 || lddx % 4 || (dyf && lddy % 4) || (dyt && ldt % 4) || (addt && ldadd % 4))
     return TIMHIP_EUNSUPPORTED;
   int rpb = ln_bwd_rows_per_block(rows);
   // launches that end in atomics on dgamma / dbeta (no partials: the time MLP's and the embedders' LayerNorms): A/B knob of their own
   if (!partial_ws && tim_knobs().ln_rpb_small >= 4) rpb = tim_knobs().ln_rpb_small / 4 * 4;
+  if (split_row > 0 && split_row < rows) {
+    // a block takes its parameter set from its first row: the halves must meet at a multiple of the block's rows (no partials).
+    // The balanced-round choice above grows with the row count (20, 24, 28 ... rows per block past 12288 rows) and the knobs
+    // change it: where it does not divide the split row, fall back to the largest multiple of 4 up to 16 that does (round-5
+    // advisor finding: B >= 160 windows of 50 feature tokens used to be refused here, in the BACKWARD of a forward that ran)
+    if (!w2 || partial_ws) return TIMHIP_EINVAL;
+    if (split_row % rpb) {
+      rpb = 0;
+      for (int c = 16; c >= 4 && !rpb; c -= 4) if (split_row % c == 0) rpb = c;
+      if (!rpb) return TIMHIP_EINVAL;
+    }
+    sp.row = split_row; sp.w2 = w2; sp.dg2 = dgamma2; sp.db2 = dbeta2;
+  }
   dim3 grid((rows + rpb - 1) / rpb);
   const size_t shmem = (size_t)4 * 2 * cols * sizeof(float);
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;

@@ -90,6 +90,7 @@ class DataParallel(nn.Module):
         self._want = collective     # None: environment, then the default for the wire dtype / backend (_preferred)
         self.collective = "a2a"     # "rs_ag" | "a2a" | "allreduce": agreed by the whole group in _choose_collective, never changed afterwards
         self._why = ""
+        self._wanted = None
         rt = module.rt
         rt.bucket_hook = self._on_bucket
         rt.finish_hook = self._on_encoder_done
@@ -102,10 +103,13 @@ class DataParallel(nn.Module):
                 self._hook_handles.append(p.register_post_accumulate_grad_hook(self._on_small_grad))
             dev = next(module.parameters()).device
             self.collective = self._choose_collective(dev)
-            if self.collective == "allreduce" and self.rank == 0 and self._preferred() != "allreduce":
+            # (the preference is NOT re-evaluated here: an invalid collective= / TIM_AMD_DP_COLLECTIVE value raised inside
+            #  _choose_collective, was counted as a refusal by the whole group, and raising now on rank 0 alone would leave
+            #  the peers inside broadcast_parameters() - round-5 advisor finding)
+            if self.collective == "allreduce" and self.rank == 0 and self._wanted != "allreduce":
                 import warnings
                 warnings.warn("tim_amd.dp: the group agreed on plain all_reduce for the gradient exchange (%s)"
-                              % (self._why or "a peer refused the %s path" % self._preferred()))
+                              % (self._why or "a peer refused the %s path" % self._wanted))
             if broadcast_parameters:
                 self.broadcast_parameters()
 
@@ -214,8 +218,9 @@ class DataParallel(nn.Module):
         W = self.world
         n = 64 * W + 24                      # not a multiple of 8 W: the staged (padded) form; 64 W alone = the zero-copy form
         want = "allreduce"
+        self._wanted = None                  # what THIS rank asked for (None: its preference itself was invalid), kept for the warning
         try:
-            want = self._preferred()
+            want = self._wanted = self._preferred()
             ok = bool(self._preflight())
             if ok:
                 # everything the probe allocates is allocated HERE, before the first collective: a rank-local failure (out of

@@ -35,14 +35,35 @@ import torch
 from . import functional as F
 
 
+def _count_graph_nodes(raw_graph):
+    """(all nodes, kernel nodes) of a captured hipGraph_t (an integer handle as torch's `raw_cuda_graph()` returns it)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    n = C.c_size_t(0)
+    g = C.c_void_p(int(raw_graph))
+    if hip.hipGraphGetNodes(g, None, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    arr = (C.c_void_p * n.value)()
+    if hip.hipGraphGetNodes(g, arr, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    kernels = 0
+    for i in range(n.value):
+        t = C.c_int(-1)
+        if hip.hipGraphNodeGetType(C.c_void_p(arr[i]), C.byref(t)) == 0 and t.value == 0:   # hipGraphNodeTypeKernel = 0
+            kernels += 1
+    return int(n.value), kernels
+
+
 class GraphedStep:
     """Capture `fn()` - a closure over static input tensors - once and replay it.
 
     fn      callable without arguments running forward + backward (+ anything else that is capturable) of `model`
     warmup  eager runs on a side stream before capture (allocator warm-up, weight copies, gradient buckets)
+    count_nodes  keep the captured hipGraph until it has been walked: `kernel_nodes` / `nodes` = the launches of one step,
+            counted (hipGraphGetNodes + hipGraphNodeGetType), not assumed (bench.py's `launches_per_step`)
     """
 
-    def __init__(self, model, fn, warmup=3):
+    def __init__(self, model, fn, warmup=3, count_nodes=False):
         inner = model.module if hasattr(model, "module") else model
         if getattr(model, "active", False) and getattr(model, "collective", None) == "a2a":
             # all_to_all_single is send / receive pairs underneath; captured, they hang or crash hipStreamEndCapture on this
@@ -65,7 +86,11 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         n_before = len(self.rt._gs_captured)   # (blocks of an earlier bare capture stay with the runtime)
-        self.graph = torch.cuda.CUDAGraph()
+        self.kernel_nodes = self.nodes = None
+        try:
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True) if count_nodes else torch.cuda.CUDAGraph()
+        except TypeError:   # (a torch without keep_graph: no count)
+            self.graph, count_nodes = torch.cuda.CUDAGraph(), False
         self.rt.invalidate_weights()  # the cast of every weight is part of the captured step
         # With a process group alive, RCCL's watchdog thread polls the events of the warm-up steps' collectives while this thread
         # captures; under the default (global) capture mode that hipEventQuery is an error on the OTHER thread ("operation not
@@ -80,6 +105,12 @@ class GraphedStep:
             pass
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.out = fn()
+        if count_nodes:
+            try:
+                self.nodes, self.kernel_nodes = _count_graph_nodes(self.graph.raw_cuda_graph())
+            except Exception:  # noqa: BLE001  (the count is a report, never a reason to lose the step)
+                self.nodes = self.kernel_nodes = None
+            self.graph.instantiate()
         # the gradient-scale blocks (non-finite flags) of the captured backward passes live and die with this object
         self._gs_blocks = self.rt.adopt_captured(since=n_before)
         # the gradient tensors the captured backward writes: re-attached on every replay, so eager steps in between (which

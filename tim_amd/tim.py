@@ -206,6 +206,7 @@ class _BucketLayout:
                 self.zero.append((st, n))
             elif n > sizes[b]:
                 self.zero.append((st + sizes[b], n - sizes[b]))
+        self.numels = tuple(p.numel() for p in params)
         self.param = []                  # per parameter, in `names` order: (name, bucket, start, numel, shape)
         off = {b: 0 for b in sizes}
         for n, p in zip(names, params):
@@ -463,7 +464,11 @@ class TIM(nn.Module):
     def _alloc_grad_buckets(self, names, params, dev, layer_overwrite=False, extra_zero=()):
         key = (bool(layer_overwrite), id(names), len(names))     # (`names`: the model's persistent parameter-name list)
         lay = self.__dict__.setdefault("_bucket_layouts", {}).get(key)
-        if lay is None or lay.param[0][0] != names[0] or lay.param[-1][0] != names[-1]:   # (an id reused by another list)
+        # revalidated by the names at both ends (an id reused by another list) AND by every parameter's element count: a head
+        # resized or replaced in place under the same name must not meet a stale layout - the kernels write through raw
+        # pointers into these views (round-5 advisor finding).  ~100 numel() calls: 10 us per backward pass.
+        numels = tuple(p.numel() for p in params)
+        if lay is None or lay.param[0][0] != names[0] or lay.param[-1][0] != names[-1] or lay.numels != numels:
             lay = self._bucket_layouts[key] = _BucketLayout(names, params, self._bucket_of, layer_overwrite)
         return _GradBuckets(self.rt, names, params, dev, self._bucket_of, layer_overwrite, extra_zero, layout=lay)
 
