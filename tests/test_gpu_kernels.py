@@ -536,7 +536,10 @@ def test_gemm_eight_phase_choice(knobs):
     knobs(TIMHIP_GEMM_P8="1")
     ch = L.load().timhip_gemm_p8_choice
     assert ch(L.EPI_STORE_T, 9920, 3072, 1024) == 8
-    assert ch(L.EPI_GELU_DROP_G2, 9920, 2048, 1024) == 10 and ch(L.EPI_MULAUX_T, 9920, 2048, 1024) == 10
+    assert ch(L.EPI_GELU_DROP_G2, 9920, 2048, 1024) == 10 and ch(L.EPI_MULAUX_T, 9920, 2048, 1024) == 0   # (measured: no gain with that epilogue)
+    knobs(TIMHIP_GEMM_P8="2")
+    assert ch(L.EPI_MULAUX_T, 9920, 2048, 1024) == 10
+    knobs(TIMHIP_GEMM_P8="1")
     assert ch(L.EPI_STORE_T, 9920, 1024, 3072) == 0 and ch(L.EPI_STORE_T, 1240, 3072, 1024) == 0
     assert ch(L.EPI_STORE_T, 9920, 3072, 64) == 0          # one contraction step: the two-buffer prologue needs two
     knobs(TIMHIP_GEMM_P8="0")

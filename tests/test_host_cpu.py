@@ -91,7 +91,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.exported_symbols())
-    assert lib.timhip_version() == _lib.ABI_VERSION == 5
+    assert lib.timhip_version() == _lib.ABI_VERSION == 6
     assert lib.timhip_strerror(-3).decode().startswith("workspace")
 
 

@@ -934,12 +934,16 @@ void launch_p8(const void* A, int lda, const void* B, int ldb, int M, int N, int
 
 // Which shapes: the ones that run MORE than one round of 160 x 256 tiles, when one of the two big tiles fills its rounds to at
 // least 85 % (useful tile area / (rounds x 256 CUs)).  C2a, M = 9920: N = 3072 -> 256 rows (0.91), N = 2048 -> 320 rows (0.97),
-// N = 1024 stays on the one-round 160-row kernel.  TIMHIP_GEMM_P8 = 0: off; 1: by shape; 8 / 10: that tile for every legal shape (tests)
+// N = 1024 stays on the one-round 160-row kernel.  TIMHIP_GEMM_P8 = 0: off; 1 (default): by shape, the 16-bit store and the GELU
+// epilogue; 2: by shape, also the multiply-by-saved-factor epilogue (linear2's input gradient: measured 40.2 against 46.8 us
+// with a plain store but 53.3 against 52.6 with its epilogue - 80 MB of aux rows and results leave through 8 waves instead of
+// 12 - profiles/r06_b_p8_ab.txt); 8 / 10: that tile for every legal shape and all three epilogues (tests)
 static int p8_choice(int epi, int M, int N, int K, const EpiDev& e) {
   const int kn = tim_knobs().gemm_p8;
   if (kn == 0 || e.a_wrap != 0 || K % 64 || K < 128 || N % PP_BN || M < 1) return 0;
   if (epi != TIMHIP_EPI_STORE_T && epi != TIMHIP_EPI_GELU_DROP_G2 && epi != TIMHIP_EPI_MULAUX_T) return 0;
   if (kn == 8 || kn == 10) return kn;
+  if (epi == TIMHIP_EPI_MULAUX_T && kn != 2) return 0;
   const long long t160 = (long long)((M + 159) / 160) * (N / PP_BN);
   if (t160 <= 256) return 0;
   auto fill = [&](int bm) {
