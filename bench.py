@@ -881,12 +881,17 @@ def main():
         traffic = None  # HBM-side bytes per launch of the GEMM kernels, from the committed rocprofv3 PMC passes
         tnote = "no PMC summary committed for this configuration"
         try:
-            tfile = [f for f in ("r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            tfile = [f for f in ("r06_d_pmc_traffic.json", "r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
             if args.precision in ("bf16", "fp16") and args.workload == "C2a" and B == 64:
                 ntk, tnk = tj.get("gemm_nt_ld_kernel", tj.get("gemm_nt_pp_kernel")), tj.get("wgrad_ld_kernel", tj.get("wgrad_pp_kernel"))   # 8 NT + 1 grouped TN launch per layer
-                if "gemm_nt_ldp_kernel" in tj:   # three of a layer's eight NT launches (in-proj forward, linear1, linear2 dgrad) walk their tiles
-                    ntk = dict(ntk, bytes_per_launch=(5 * ntk["bytes_per_launch"] + 3 * tj["gemm_nt_ldp_kernel"]["bytes_per_launch"]) / 8.0)
+                # (of a layer's eight NT launches five run one round of tiles - gemm_nt_ld - and three are multi-round: the tile walk
+                #  gemm_nt_ldp and, from round 6, the eight-phase gemm_nt_p8 for two of them)
+                multi = [tj[k] for k in ("gemm_nt_ldp_kernel", "gemm_nt_p8_kernel") if k in tj]
+                if multi:
+                    w = [m.get("launches", 1) for m in multi]
+                    mb = sum(m["bytes_per_launch"] * wi for m, wi in zip(multi, w)) / max(sum(w), 1)
+                    ntk = dict(ntk, bytes_per_launch=(5 * ntk["bytes_per_launch"] + 3 * mb) / 8.0)
                 traffic = round((8 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 9.0)
                 tnote = ("CITED, not measured in this run: average fabric-side bytes per GEMM launch from the committed rocprofv3 PMC "
                          "passes of this command on the builder's box (FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
@@ -901,7 +906,7 @@ def main():
                            "algorithmic_bytes_per_launch": round(alg_avg),
                            "traffic_note": tnote + "; algorithmic bytes average %.0f MB per launch (NT %.0f MB on average, grouped "
                                            "TN %.1f MB)" % (alg_avg / 1e6, sum(alg_nt) / 8e6, alg_tn / 1e6),
-                           "kernel": "MFMA GEMM family: gemm_nt_ld_kernel / gemm_nt_ldp_kernel (loader waves + L2 prefetch, one tile per block / a walk of 2-4 tiles; gemm_nt_pp_kernel with TIMHIP_GEMM_LD=0) / gemm_nt_%s_kernel (8 launches per layer) + the grouped TN weight-"
+                           "kernel": "MFMA GEMM family: gemm_nt_ld_kernel (160 x 256 tiles, loader waves + L2 prefetch: the one-round shapes) / gemm_nt_p8_kernel (round 6: 256 / 320 x 256 tiles on the eight-phase schedule for the in-projection and linear1 forward; TIMHIP_GEMM_P8=0: the tile walk gemm_nt_ldp_kernel) / gemm_nt_%s_kernel (8 launches per layer) + the grouped TN weight-"
                                      "gradient launch (wgrad_ld_kernel: the layer's 4 weight gradients as one grid) = the "
                                      "72 GEMMs of the 6 encoder layers fwd+bwd in 54 launches, 2*M*N*K algorithmic FLOPs each; `achieved` = sum FLOPs / sum of their HIP-event durations inside "
                                      "the last timed step, events recorded on the stream each kernel is launched on (default: the "

@@ -126,6 +126,10 @@ typedef struct TimDesc {
 #define TIMHIP_DESC_STREAM16 0x10000
 #define TIMHIP_DESC_STREAM16_IN 0x20000
 #define TIMHIP_DESC_STREAM16_OUT 0x40000
+/* ABI 6: the layer's saved block carries the keep-bits of its attention dropout (TIMHIP_SAVED_ATTN_KEEP_BITS), drawn ahead of the
+ * layer by timhip_attn_keep_bits(): the attention forward and the fused attention backward read them instead of running Philox
+ * for every (row, key) in both directions.  Set on the forward AND the backward desc of a step, or on neither. */
+#define TIMHIP_DESC_ATTN_KEEP_BITS 0x80000
 
 /* One encoder layer.  *_op are operand-dtype working copies made by timhip_prepare_weights:
  * w (as stored, [N,K]) and wt (transposed, [K,N]).  Biases and LayerNorm parameters are the
@@ -175,7 +179,7 @@ size_t timhip_layer_workspace_bytes(const TimDesc* d);
  * keep-bits [M, FF/8] bytes that LayerNorm-1 draws (bit c%8 of byte [r*FF/8 + c/8] = element (r,c) kept; only written when
  * p_drop > 0). */
 enum { TIMHIP_SAVED_QKV = 0, TIMHIP_SAVED_O = 1, TIMHIP_SAVED_Y1 = 2, TIMHIP_SAVED_X1T = 3, TIMHIP_SAVED_H = 4,
-       TIMHIP_SAVED_Y2 = 5, TIMHIP_SAVED_FFN_KEEP_BITS = 6 };
+       TIMHIP_SAVED_Y2 = 5, TIMHIP_SAVED_FFN_KEEP_BITS = 6, TIMHIP_SAVED_ATTN_KEEP_BITS = 7 };
 int timhip_layer_saved_field(const TimDesc* d, int field, size_t* offset, size_t* bytes);
 
 /* ---------------------------------------------------------------- weights ---- */
@@ -318,6 +322,14 @@ int timhip_layernorm_bwd2(int precision, const float* dx, int lddx, const float*
 /* structured attention over qkv[B*S, 3E] (T): token i attends to the F feature tokens and to
  * itself.  o[B*S,E] (T), lse[B,H,S] fp32. */
 int timhip_attention_fwd(const TimDesc* d, const void* qkv, void* o, float* lse, void* stream);
+/* ABI 6: keep-bits of the attention dropout of `nlayers` encoder layers in ONE launch, written into the layers' saved blocks
+ * (saved[l] = the block timhip_layer_fwd of layer l will fill; field TIMHIP_SAVED_ATTN_KEEP_BITS: per (window, head, token row)
+ * two 64-bit words, word g bit 4 c + t = key 8 c + 4 g + t kept, keys 0 .. 127 - the order in which the MFMA attention
+ * kernels' lanes own keys).  The same Philox stream as the kernels' own draws (seed d->seed, site of layer l, element
+ * ((b H + h) S + s) LP + key, LP = F + 1 rounded up to 8): results are bit-identical with and without the flag.
+ * TIMHIP_EUNSUPPORTED (the caller leaves TIMHIP_DESC_ATTN_KEEP_BITS off): everything but 16-bit precisions with 128-wide heads and
+ * 97 .. 128 feature keys (the geometry whose kernels read the bits), and evaluation mode (p_drop = 0). */
+int timhip_attn_keep_bits(const TimDesc* d, int nlayers, void* const* saved, void* stream);
 int timhip_attention_bwd(const TimDesc* d, const void* qkv, const void* o, const float* lse,
                          const void* d_o, void* dqkv, void* workspace, size_t workspace_bytes,
                          void* stream);

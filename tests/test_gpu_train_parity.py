@@ -176,6 +176,53 @@ def test_layer_forward_keep_bits_and_sites(prec):
         assert (h[mk == 1] != 0).float().mean().item() > 0.99, l   # gelu(u) is exactly 0 only at u = 0 (or fp16 underflow)
 
 
+def test_attention_keep_bits_are_the_mask(monkeypatch):
+    """round 6: timhip_attn_keep_bits draws the attention dropout of every layer ahead of the stack, into the layers' saved blocks
+    (two 64-bit words per (window, head, token row); word g, bit 4 c + t = key 8 c + 4 g + t).  (a) the words are
+    timhip_dropout_mask's statement of the site, bit for bit, for two layers in one launch; (b) the C2a model's training step
+    with the bits (the default) and with the kernels drawing their own masks (TIM_AMD_ATTN_KEEP_BITS=0) gives IDENTICAL logits
+    and parameter gradients - the forward and the fused backward read the same decisions they used to compute."""
+    cfg = named_config("C2a")
+    B, S, F, Hh, E = 3, 155, cfg.F, cfg.nhead, cfg.E
+    seed, p = 0x1D2C3B4A5968, cfg.enc_dropout
+    desc = L.TimDesc(B, S, F, cfg.d_model, E, Hh, cfg.FF, L.PREC_F16, p, seed, 0, 0, None)
+    nb = L.load().timhip_layer_saved_bytes(C.byref(desc))
+    saved = [torch.zeros(nb, dtype=torch.uint8, device=DEV) for _ in range(2)]
+    L.call("timhip_attn_keep_bits", C.byref(desc), 2, (C.c_void_p * 2)(*[t.data_ptr() for t in saved]), st())
+    off, nbytes = C.c_size_t(), C.c_size_t()
+    L.call("timhip_layer_saved_field", C.byref(desc), L.SAVED_ATTN_KEEP_BITS, C.byref(off), C.byref(nbytes))
+    rows, LP = B * Hh * S, (F + 1 + 7) // 8 * 8
+    assert nbytes.value == rows * 16
+    for l in range(2):
+        words = saved[l][off.value:off.value + nbytes.value].cpu().numpy().view(np.uint64).reshape(rows, 2)
+        mk = keep_mask(seed, L.layer_site(l, L.SITE_L_ATTN), p, rows, LP).numpy()
+        for k in range(F):   # (keys F .. : the self slot and the padding - drawn by the kernels themselves / never used)
+            c, e = k >> 3, k & 7
+            got = (words[:, e >> 2] >> np.uint64(4 * c + (e & 3))) & np.uint64(1)
+            assert np.array_equal(got.astype(np.uint8), mk[:, k]), (l, k)
+    assert not np.array_equal(saved[0][off.value:off.value + 64].cpu().numpy(), saved[1][off.value:off.value + 64].cpu().numpy())
+    desc32 = L.TimDesc(B, S, F, cfg.d_model, E, Hh, cfg.FF, L.PREC_FP32, p, seed, 0, 0, None)
+    assert L.load().timhip_attn_keep_bits(C.byref(desc32), 2, (C.c_void_p * 2)(*[t.data_ptr() for t in saved]), st()) == L.EUNSUPPORTED
+    # (b) the model, both ways
+    nv, na, Bm = 15, 10, 2
+    sd, inp = H.synth_torch(cfg, Bm, nv, na, seed=2, dtype=torch.float32)
+    with torch.no_grad():
+        o_eval = H.named_outputs(*O.forward(sd, cfg, inp["visual"], inp["audio"], inp["times"], nv, na))
+    R = H.cotangents(cfg, Bm, nv, na, o_eval, seed=2, dtype=torch.float32)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TIM_AMD_ATTN_KEEP_BITS", flag)
+        res[flag] = run_train(build(cfg, "fp16", sd), inp, nv, na, R)
+    assert res["1"]["seed"] == res["0"]["seed"]
+    for k in res["1"]["outs"]:
+        assert torch.equal(res["1"]["outs"][k], res["0"]["outs"][k]), k
+    for k in res["1"]["grads"]:   # (a few gradients end in atomics - cls tokens, embedder LayerNorms: equal up to their summation order)
+        a_, b_ = res["1"]["grads"][k], res["0"]["grads"][k]
+        assert (a_ - b_).abs().max().item() <= 2e-6 * max(b_.abs().max().item(), 1e-30), k
+    assert torch.equal(res["1"]["grads"]["transformer_encoder.layers.0.self_attn.in_proj_weight"],
+                       res["0"]["grads"]["transformer_encoder.layers.0.self_attn.in_proj_weight"])
+
+
 # ------------------------------------------------------------------------------------------------
 # (b) whole model in .train() against the oracle fed with the same masks
 # ------------------------------------------------------------------------------------------------

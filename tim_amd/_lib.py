@@ -26,7 +26,7 @@ def layer_site(layer, which):
     return 16 + 8 * layer + which
 
 
-SAVED_QKV, SAVED_O, SAVED_Y1, SAVED_X1T, SAVED_H, SAVED_Y2, SAVED_FFN_KEEP_BITS = range(7)   # timhip_layer_saved_field
+SAVED_QKV, SAVED_O, SAVED_Y1, SAVED_X1T, SAVED_H, SAVED_Y2, SAVED_FFN_KEEP_BITS, SAVED_ATTN_KEEP_BITS = range(8)   # timhip_layer_saved_field
 
 vp, i32, u32, u64, f32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
 
@@ -53,6 +53,8 @@ class TimLayerGrads(C.Structure):
 DESC_ATTN_FP32, DESC_ATTN_BWD_ONE_KERNEL, DESC_WGRAD_OVERWRITE, DESC_WGRAD_SEPARATE, DESC_OUTPROJ_SPLIT = 1, 2, 4, 8, 16
 DESC_INPROJ_SPLIT, DESC_L1_SPLIT, DESC_L2_SPLIT = 32, 64, 128   # TimDesc.reserved flags
 DESC_STREAM16, DESC_STREAM16_IN, DESC_STREAM16_OUT = 0x10000, 0x20000, 0x40000   # 16-bit residual gradient stream (fp16 backward)
+EUNSUPPORTED = -2                # include/timhip.h: TIMHIP_EUNSUPPORTED
+DESC_ATTN_KEEP_BITS = 0x80000   # the saved block carries the layer's attention keep-bits (timhip_attn_keep_bits)
 
 
 class TimCastItem(C.Structure):
@@ -159,6 +161,7 @@ _SIGS = {
     "timhip_grad_scale": (C.c_int, [vp, vp, i32, f32, vp, vp]),
     "timhip_reload_env": (None, []),
     "timhip_build_flags": (C.c_int, []),
+    "timhip_attn_keep_bits": (C.c_int, [C.POINTER(TimDesc), i32, vp, vp]),
     "timhip_gemm_p8_choice": (C.c_int, [i32, i32, i32, i32]),
     "timhip_dp_reduce": (C.c_int, [i32, vp, i32, C.c_longlong, f32, vp, vp]),
     "timhip_split3_many": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),

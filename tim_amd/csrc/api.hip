@@ -7,7 +7,7 @@
 namespace {
 
 struct SavedLayout {
-  size_t qkv, o, lse, y1, st1, x1t, u, h, y2, st2, ffn_mask, total;
+  size_t qkv, o, lse, y1, st1, x1t, u, h, y2, st2, ffn_mask, attn_keep, total;
 };
 
 SavedLayout saved_layout(const TimDesc& d) {
@@ -26,6 +26,7 @@ SavedLayout saved_layout(const TimDesc& d) {
   L.y2 = take(M * d.E * 4);
   L.st2 = take(M * 2 * 4);
   L.ffn_mask = take(M * d.FF / 8);   // keep-bits of the FFN dropout (FF % 64 == 0): written by norm1, read by the linear1 epilogue
+  L.attn_keep = take((size_t)d.B * d.H * d.S * 16);   // keep-bits of the attention dropout (timhip_attn_keep_bits, TIMHIP_DESC_ATTN_KEEP_BITS)
   L.total = off;
   return L;
 }
@@ -210,6 +211,27 @@ const char* timhip_strerror(int code) {
   }
 }
 
+int timhip_attn_keep_bits(const TimDesc* d, int nlayers, void* const* saved, void* stream) {
+  if (!d || !saved || nlayers <= 0) return TIMHIP_EINVAL;
+  // (the geometry whose kernels read them: 128-wide heads, 97 .. 128 feature keys - attn_fwd_mfma<.., 128, 4, true> and the fused
+  //  key-split backward; every other shape draws its masks in the kernels)
+  if (!h16_storage(d->precision) || !(d->p_drop > 0.f) || d->B <= 0 || d->S <= 0 || d->H <= 0 || d->E / d->H != 128 ||
+      (d->F + 31) / 32 != 4)
+    return TIMHIP_EUNSUPPORTED;
+  const SavedLayout L = saved_layout(*d);
+  for (int l0 = 0; l0 < nlayers; l0 += 8) {
+    unsigned long long* out[8] = {};
+    const int n = nlayers - l0 < 8 ? nlayers - l0 : 8;
+    for (int i = 0; i < n; ++i) {
+      if (!saved[l0 + i]) return TIMHIP_EINVAL;
+      out[i] = reinterpret_cast<unsigned long long*>((char*)saved[l0 + i] + L.attn_keep);
+    }
+    const int rc = tim_attn_keep_bits(*d, l0, n, out, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return TIMHIP_OK;
+}
+
 size_t timhip_layer_saved_bytes(const TimDesc* d) { return d ? saved_layout(*d).total : 0; }
 
 // test hook: where a field of the (otherwise opaque) saved block lives
@@ -225,6 +247,7 @@ int timhip_layer_saved_field(const TimDesc* d, int field, size_t* offset, size_t
     case TIMHIP_SAVED_H: *offset = L.h; *bytes = M * d->FF * ts; break;
     case TIMHIP_SAVED_Y2: *offset = L.y2; *bytes = M * d->E * 4; break;
     case TIMHIP_SAVED_FFN_KEEP_BITS: *offset = L.ffn_mask; *bytes = M * d->FF / 8; break;
+    case TIMHIP_SAVED_ATTN_KEEP_BITS: *offset = L.attn_keep; *bytes = (size_t)d->B * d->H * d->S * 16; break;
     default: return TIMHIP_EINVAL;
   }
   return TIMHIP_OK;
@@ -286,7 +309,9 @@ static int layer_fwd_impl(const TimDesc& d, const TimLayerParams* w, const float
     if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, x_in_T, E, w->in_w, 3 * E, M, 3 * E, 2 * E, e, 1, s))) return rc;
   } else if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, x_in_T, E, w->in_w, E, M, 3 * E, E, e, 1, s))) return rc;
   // 2. structured attention
-  if ((rc = tim_attention_fwd(d, qkv, o, lse, s))) return rc;
+  const unsigned long long* akeep = ((d.reserved & TIMHIP_DESC_ATTN_KEEP_BITS) && d.p_drop > 0.f)
+                                        ? reinterpret_cast<const unsigned long long*>(sv + L.attn_keep) : nullptr;
+  if ((rc = tim_attention_fwd(d, qkv, o, lse, s, akeep))) return rc;
   // 3. out-projection + dropout1 + residual
   e = epi0();
   e.out0 = y1; e.ld0 = E; e.bias = w->out_b; e.ldres = E;
@@ -464,7 +489,9 @@ static int layer_bwd_data_impl(const TimDesc& d, const TimLayerParams* w, const 
   e.out0 = Tc; e.ld0 = E;
   if ((rc = tim_gemm_nt(prec, TIMHIP_EPI_STORE_T, da, E, w->out_wt, E, M, E, E, e, 1, s))) return rc;
   // attention backward -> dqkv
-  if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, dqkv, ws + W.attn, W.lnp - W.attn, s))) return rc;
+  const unsigned long long* akeep = ((d.reserved & TIMHIP_DESC_ATTN_KEEP_BITS) && d.p_drop > 0.f)
+                                        ? reinterpret_cast<const unsigned long long*>(sv + L.attn_keep) : nullptr;
+  if ((rc = tim_attention_bwd(d, qkv, o, lse, Tc, dqkv, ws + W.attn, W.lnp - W.attn, s, akeep))) return rc;
   e = epi0();
   if (dx_in_add) {   // split form: the product stays 16-bit (and scaled); dy1 is already in dx_in
     e.out0 = dx_in_add; e.ld0 = E;

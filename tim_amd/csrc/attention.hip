@@ -236,11 +236,11 @@ int check_desc(const TimDesc& d) {
 
 }  // namespace
 
-int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
+int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s, const unsigned long long* kbits);
 int tim_attention_bwd_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
                            void* dqkv, hipStream_t s);
 int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
-                            void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);
+                            void* dqkv, void* ws, size_t ws_bytes, hipStream_t s, const unsigned long long* kbits);
 size_t tim_attention_bwd2_ws(const TimDesc& d);
 // attention_f32.hip: exact-fp32 MFMA kernels for the fp32 / bf16x3 modes
 int tim_attention_fwd_f32(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
@@ -248,14 +248,14 @@ int tim_attention_bwd_f32(const TimDesc& d, const void* qkv, const void* o, cons
                           void* ws, size_t ws_bytes, hipStream_t s);
 size_t tim_attention_f32_bwd_ws(const TimDesc& d);
 
-int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
+int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s, const unsigned long long* kbits) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse) return TIMHIP_EINVAL;
   // (bench.py's non-GEMM brackets: qkv read, o written, in the operand type)
   TimGemmScope timing((double)d.B * d.S * d.E * 4 * (h16_storage(d.precision) ? 2 : 4), s, 1);
   if (h16_storage(d.precision) && !(d.reserved & 1)) {  // reserved bit 0: force the fp32-arithmetic kernels
-    rc = tim_attention_fwd_mfma(d, qkv, o, lse, s);
+    rc = tim_attention_fwd_mfma(d, qkv, o, lse, s, kbits);
     if (rc != TIMHIP_EUNSUPPORTED) return rc;
   }
   if (f32_storage(d.precision) && !(d.reserved & 1)) {   // fp32 / bf16x3: f32 matrix cores
@@ -281,7 +281,7 @@ size_t tim_attention_bwd_ws(const TimDesc& d) {
 }
 
 int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
-                      void* dqkv, void* ws, size_t ws_bytes, hipStream_t s) {
+                      void* dqkv, void* ws, size_t ws_bytes, hipStream_t s, const unsigned long long* kbits) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!qkv || !o || !lse || !d_o || !dqkv || !ws) return TIMHIP_EINVAL;
@@ -289,7 +289,7 @@ int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const fl
   TimGemmScope timing((double)d.B * d.S * d.E * 8 * (h16_storage(d.precision) ? 2 : 4), s, 1);
   if (h16_storage(d.precision) && !(d.reserved & 1)) {
     if (!(d.reserved & 2)) {  // reserved bit 1: force the single-kernel MFMA backward
-      rc = tim_attention_bwd2_mfma(d, qkv, o, lse, d_o, dqkv, ws, ws_bytes, s);
+      rc = tim_attention_bwd2_mfma(d, qkv, o, lse, d_o, dqkv, ws, ws_bytes, s, kbits);
       if (rc != TIMHIP_EUNSUPPORTED) return rc;
     }
     rc = tim_attention_bwd_mfma(d, qkv, o, lse, d_o, dqkv, s);

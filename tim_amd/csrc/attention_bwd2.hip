@@ -21,6 +21,7 @@ struct AttnArgsM {
   uint32_t thr; float dscale; TimSeed seed; uint32_t site;
   int abl;  // tuning builds only (TimDesc.reserved >> 8): 1 no scratch stores, 2 no dqkv stores, 4 operand rows alias row 0
   int rsplit, rper;   // two-kernel form: the row blocks of a (window, head) over rsplit workgroups of rper row blocks (attention_mfma.hip)
+  const unsigned long long* kbits;   // keep-bits drawn ahead of the layer (attention_mfma.hip: tim_attn_keep_bits), or nullptr
 };
 #ifdef TIMHIP_TUNING
 #define ATT_ABL(a, bit) (((a).abl & (bit)) != 0)
@@ -74,7 +75,9 @@ __device__ __forceinline__ void keep_pair(const AttnArgsM& a, uint64_t rowbase, 
 //            written); waves 4 - 7: one (row block s - 1, head-dim block) dQ unit each, dS read back from LDS in tr_frag's k-order
 //            (same values, same accumulation order as the one-wave form); every thread: sweep s + 1
 // DESIGN.md section 5f has the per-phase clocks and what was tried on top.
-template <typename HT, int DH, int NJB, bool FUSED = false, bool KS = false>
+// KB (round 6, key-split form): a unit's keep factors from the layer's keep-bits - the 16 bits of (row, g, key block), requested
+// one pipeline step ahead - instead of two Philox calls per unit.
+template <typename HT, int DH, int NJB, bool FUSED = false, bool KS = false, bool KB = false>
 __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv, const HT* __restrict__ o,
                                                      const float* __restrict__ lse, const HT* __restrict__ d_o,
                                                      HT* __restrict__ dqkv, HT* __restrict__ dS_scr,
@@ -222,7 +225,13 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
         df[kk] = *reinterpret_cast<const vec8<HT>*>(sP + tile_off<128>(row, kk * 2 + g));
       }
     };
-    auto item_a = [&](int rb, int jb) {
+    // KB: the 16 keep-bits of (row block rb's row li, key half g, key block jb): bit 8 qp + 4 t' + t = key 32 jb + 16 qp + 8 t' + 4 g + t
+    auto load_kw = [&](int rb, int jb) -> uint32_t {
+      const int rowc = min(rb * 32 + li, S - 1);
+      return (uint32_t)*reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(a.kbits) +
+                                                                ((((size_t)bh * S + rowc) << 1) + g) * 8 + 2 * jb);
+    };
+    auto item_a = [&](int rb, int jb, uint32_t kw) {
       const int row = rb * 32 + li;
       const bool valid = row < S;
       const int rowc = valid ? row : S - 1;
@@ -241,7 +250,13 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
 #pragma unroll
       for (int qp2 = 0; qp2 < 2; ++qp2) {
         float kk2[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
-        if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp2, g, kk2[0], kk2[1]);
+        if constexpr (KB) {
+          const int ds = __float_as_int(a.dscale);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) kk2[h2][t] = __int_as_float(__builtin_amdgcn_sbfe((int)kw, 8 * qp2 + 4 * h2 + t, 1) & ds);
+        } else if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp2, g, kk2[0], kk2[1]);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -320,16 +335,20 @@ __global__ __launch_bounds__(512) void attn_bwd_rows(const HT* __restrict__ qkv,
     //      (one head-dim block each); every thread: sweep s + 1 into LDS.  Two barriers per step: Q / dO fragments read ->
     //      barrier -> the same space written.  Each SIMD hosts one wave of either kind.
     sweep_store(qv[0], dv[0], ov, kv, vv, 0);
+    uint32_t kw_cur = 0u, kw_next = 0u;
+    if constexpr (KB) { if (wave < 4) kw_cur = load_kw(0, wave); }
     lds_barrier();
     ATT_STAMP(2);
 #pragma unroll
     for (int s_ = 0; s_ <= NSW; ++s_) {
       if (s_ <= nrb) {
         if (s_ + 1 < nrb) load_okv(s_ + 1);
+        if constexpr (KB) { if (wave < 4 && s_ + 1 < nrb) kw_next = load_kw(s_ + 1, wave); }
         if (wave < 4 && s_ < nrb) read_frags(s_);
         lds_barrier();
         if (wave < 4) {
-          if (s_ < nrb && !ATT_ABL(a, 64)) item_a(s_, wave);
+          if (s_ < nrb && !ATT_ABL(a, 64)) item_a(s_, wave, kw_cur);
+          kw_cur = kw_next;
         } else {
           if (s_ >= 1 && !ATT_ABL(a, 32)) item_b(s_ - 1, wave - 4);
         }
@@ -728,6 +747,7 @@ AttnArgsM make_args2(const TimDesc& d) {
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
   a.abl = (d.reserved >> 8) & 0xff;
   a.rsplit = 1; a.rper = (d.S + 31) / 32;
+  a.kbits = nullptr;
   return a;
 }
 
@@ -750,12 +770,22 @@ static inline bool fused_fits(const TimDesc& d, bool ks) {
 
 template <typename HT, bool KS>
 int launch_bwd_fused(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, void* stamps,
-                     hipStream_t s) {
+                     hipStream_t s, const unsigned long long* kbits) {
   const int SP = (d.S + 31) & ~31;
   const size_t lds = (size_t)2 * 128 * 128 * 2 + (size_t)2 * SP * 128 * 2 + (KS ? (size_t)SP * 12 : 0);
+  AttnArgsM a = make_args2(d);
+  if constexpr (KS) {
+    if (kbits && a.thr != 0u) {
+      a.kbits = kbits;
+      (void)hipFuncSetAttribute((const void*)attn_bwd_rows<HT, 128, 4, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attn_bwd_rows<HT, 128, 4, true, true, true>), dim3(d.B * d.H), dim3(512), lds, s, (const HT*)qkv, (const HT*)o,
+                         lse, (const HT*)d_o, (HT*)dqkv, (HT*)stamps, (HT*)nullptr, a);
+      return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+    }
+  }
   (void)hipFuncSetAttribute((const void*)attn_bwd_rows<HT, 128, 4, true, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_bwd_rows<HT, 128, 4, true, KS>), dim3(d.B * d.H), dim3(512), lds, s, (const HT*)qkv, (const HT*)o, lse,
-                     (const HT*)d_o, (HT*)dqkv, (HT*)stamps, (HT*)nullptr, make_args2(d));
+                     (const HT*)d_o, (HT*)dqkv, (HT*)stamps, (HT*)nullptr, a);
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
@@ -795,7 +825,7 @@ size_t tim_attention_bwd2_ws(const TimDesc& d) {
 }
 
 int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,
-                            void* dqkv, void* ws, size_t ws_bytes, hipStream_t s) {
+                            void* dqkv, void* ws, size_t ws_bytes, hipStream_t s, const unsigned long long* kbits) {
   if (!h16_storage(d.precision) || (d.E % 8) != 0 || d.B * d.H > 65535) return TIMHIP_EUNSUPPORTED;
   const bool ks_ok = tim_knobs().attn_ks != 0 && fused_fits(d, true);
   if (ks_ok || fused_fits(d, false)) {   // (160 < S <= 192: the key-split form does not fit, the plain fused form still does)
@@ -803,8 +833,8 @@ int tim_attention_bwd2_mfma(const TimDesc& d, const void* qkv, const void* o, co
 #ifdef TIMHIP_TUNING
     if (((d.reserved >> 8) & 16) && ws && ws_bytes >= (size_t)d.B * d.H * 64) stamps = ws;
 #endif
-    if (ks_ok) DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, true>(d, qkv, o, lse, d_o, dqkv, stamps, s)));
-    DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, false>(d, qkv, o, lse, d_o, dqkv, stamps, s)));
+    if (ks_ok) DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, true>(d, qkv, o, lse, d_o, dqkv, stamps, s, kbits)));
+    DISPATCH_H16(d.precision, return (launch_bwd_fused<HT, false>(d, qkv, o, lse, d_o, dqkv, stamps, s, nullptr)));
   }
   if (!ws || ws_bytes < tim_attention_bwd2_ws(d)) return TIMHIP_EUNSUPPORTED;
   const int DHv = d.E / d.H, NJBv = (d.F + 31) / 32;

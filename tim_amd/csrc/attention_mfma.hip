@@ -27,6 +27,7 @@ struct AttnArgsM {
   float scale;
   uint32_t thr; float dscale; TimSeed seed; uint32_t site;
   int rsplit, rper;   // the 32-row blocks of a (window, head) are spread over rsplit workgroups of rper row blocks each (1: one workgroup)
+  const unsigned long long* kbits;   // keep-bits drawn ahead of the layer (tim_attn_keep_bits; round 6), or nullptr
 };
 
 __device__ __forceinline__ void keep4(const AttnArgsM& a, uint64_t rowbase, int key, float& k0, float& k1, float& k2,
@@ -66,7 +67,10 @@ __device__ __forceinline__ float quad_pick(float k0, float k1, float k2, float k
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <typename HT, int DH, int NJB>
+// KB (round 6): the dropout keep-bits of the layer were drawn ahead of it (a.kbits, two 64-bit words per row: tim_attn_keep_bits) -
+// a lane reads the word of its (row, key half g) with its q row and turns bits into factors (v_bfe_i32 + v_and per element)
+// instead of eight Philox calls per row block.  Same bits, same results.
+template <typename HT, int DH, int NJB, bool KB = false>
 __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv, HT* __restrict__ o,
                                                      float* __restrict__ lse, AttnArgsM a) {
   constexpr int FP = NJB * 32, NKK = DH / 16, NDB = DH / 32;
@@ -110,6 +114,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
     const int rowc = valid ? row : S - 1;
     const bool isq = rowc >= F;
     const HT* qp = base + (size_t)rowc * ld;
+    unsigned long long kw = 0ull;   // KB: this lane's keep-bits, bit 4 c + t = key 8 c + 4 g + t (requested ahead of the products)
+    if constexpr (KB) kw = a.kbits[((((size_t)b * a.H + h) * S + rowc) << 1) + g];
 
     // S^T = K Q^T : lane owns query row `row`, registers hold keys 32jb + (r&3) + 8(r>>2) + 4g
     f32x16_t sc[NJB];
@@ -173,7 +179,15 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma(const HT* __restrict__ qkv,
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         float ka[4] = {1.f, 1.f, 1.f, 1.f}, kb[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp, g, ka, kb);   // (both lanes of a pair take this branch)
+        if constexpr (KB) {
+          const int w32 = (int)(uint32_t)(kw >> (32 * (jb >> 1)));   // keys of key blocks 2 (jb >> 1), + 1: one dword
+          const int ds = __float_as_int(a.dscale);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            ka[t] = __int_as_float(__builtin_amdgcn_sbfe(w32, 16 * (jb & 1) + 8 * qp + t, 1) & ds);
+            kb[t] = __int_as_float(__builtin_amdgcn_sbfe(w32, 16 * (jb & 1) + 8 * qp + 4 + t, 1) & ds);
+          }
+        } else if (a.thr != 0u) keep_pair(a, rowbase, jb * 32 + 16 * qp, g, ka, kb);   // (both lanes of a pair take this branch)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           sc[jb][8 * qp + t] *= inv * ka[t];
@@ -517,6 +531,7 @@ AttnArgsM make_args(const TimDesc& d) {
   a.dscale = d.p_drop > 0.f ? 1.f / (1.f - d.p_drop) : 1.f;
   a.seed = d.seed; a.site = layer_site(d.layer, SITE_L_ATTN);
   a.rsplit = 1; a.rper = (d.S + 31) / 32;
+  a.kbits = nullptr;
   return a;
 }
 
@@ -546,14 +561,43 @@ static inline int attn_waves(int S) {
 }
 
 template <typename HT, int DH, int NJB>
-int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
+int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s, const unsigned long long* kbits) {
   const size_t lds = (size_t)2 * NJB * 32 * DH * 2;
-  (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HT, DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   AttnArgsM a = make_args(d);
   attn_row_split(d, 4, a.rsplit, a.rper);
+  if constexpr (DH == 128 && NJB == 4) {   // (the keep-bit form exists for the geometry tim_attn_keep_bits serves: C2a / C3 / C4)
+    if (kbits && a.thr != 0u) {
+      a.kbits = kbits;
+      (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HT, DH, NJB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attn_fwd_mfma<HT, DH, NJB, true>), dim3(d.B * d.H * a.rsplit), dim3(64 * attn_waves(32 * a.rper)), lds, s,
+                         (const HT*)qkv, (HT*)o, lse, a);
+      return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+    }
+  }
+  (void)hipFuncSetAttribute((const void*)attn_fwd_mfma<HT, DH, NJB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((attn_fwd_mfma<HT, DH, NJB>), dim3(d.B * d.H * a.rsplit), dim3(64 * attn_waves(32 * a.rper)), lds, s,
                      (const HT*)qkv, (HT*)o, lse, a);
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
+
+// keep-bits of the attention dropout, one thread per (window, head, token row): the 8 elements of Philox counter c are the keys
+// 8 c .. 8 c + 7; the MFMA kernels' lane (row, g) owns keys 8 c + 4 g + t - so the low nibble of a counter's keep-bits goes
+// to word g = 0 and the high nibble to word g = 1, both at bit 4 c
+struct KeepBitsArgs { unsigned long long* out[8]; TimSeed seed; uint32_t site[8]; uint32_t thr; int rows, nc, lp8; };
+__global__ __launch_bounds__(256) void attn_keep_bits_kernel(KeepBitsArgs k) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= k.rows) return;
+  const uint64_t c0 = (uint64_t)row * (uint64_t)k.lp8;
+  const uint32_t site = k.site[blockIdx.y];
+  unsigned long long w0 = 0ull, w1 = 0ull;
+  for (int c = 0; c < k.nc; ++c) {
+    const uint32_t bits = drop_bits8(k.seed, site, c0 + (uint64_t)c, k.thr);
+    w0 |= (unsigned long long)(bits & 15u) << (4 * c);
+    w1 |= (unsigned long long)(bits >> 4) << (4 * c);
+  }
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  u64x2 v; v[0] = w0; v[1] = w1;
+  *reinterpret_cast<u64x2*>(k.out[blockIdx.y] + 2 * (size_t)row) = v;
 }
 template <typename HT, int DH, int NJB>
 int launch_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv,
@@ -598,10 +642,22 @@ int launch_bwd(const TimDesc& d, const void* qkv, const void* o, const float* ls
     return TIMHIP_EUNSUPPORTED;                                                  \
   } while (0)
 
-int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s) {
+int tim_attention_fwd_mfma(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s, const unsigned long long* kbits) {
   if (!h16_storage(d.precision) || (d.E % 8) != 0) return TIMHIP_EUNSUPPORTED;
-  DISPATCH_H16(d.precision, ATTN_DISPATCH(launch_fwd, d, qkv, o, lse, s));
+  DISPATCH_H16(d.precision, ATTN_DISPATCH(launch_fwd, d, qkv, o, lse, s, kbits));
   return TIMHIP_EUNSUPPORTED;
+}
+
+int tim_attn_keep_bits(const TimDesc& d, int first_layer, int n, unsigned long long* const* out, hipStream_t s) {
+  if (n < 1 || n > 8 || !out) return TIMHIP_EINVAL;
+  KeepBitsArgs k;
+  for (int i = 0; i < 8; ++i) { k.out[i] = i < n ? out[i] : nullptr; k.site[i] = layer_site(first_layer + (i < n ? i : 0), SITE_L_ATTN); }
+  k.seed = d.seed; k.thr = drop_threshold(d.p_drop);
+  k.rows = d.B * d.H * d.S;
+  k.lp8 = round_up(d.F + 1, 8) / 8;
+  k.nc = k.lp8 < 16 ? k.lp8 : 16;   // keys 0 .. 127 (the self key of a 128-key window is drawn by the kernels themselves)
+  hipLaunchKernelGGL(attn_keep_bits_kernel, dim3((k.rows + 255) / 256, n), dim3(256), 0, s, k);
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
 int tim_attention_bwd_mfma(const TimDesc& d, const void* qkv, const void* o, const float* lse, const void* d_o,

@@ -461,9 +461,12 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
                       int split_row = 0, const float* w2 = nullptr, float* dgamma2 = nullptr, float* dbeta2 = nullptr);   // blocks from split_row on: second parameter set
 size_t tim_layernorm_bwd_ws(int rows, int cols);
 int tim_layernorm_bwd_blocks(int rows);   // partial rows one backward launch over `rows` rows writes
-int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s);
+// kbits (round 6): the layer's attention keep-bits as tim_attn_keep_bits wrote them (nullptr: the kernels draw their own)
+int tim_attention_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s, const unsigned long long* kbits = nullptr);
 int tim_attention_bwd(const TimDesc& d, const void* qkv, const void* o, const float* lse,
-                      const void* d_o, void* dqkv, void* ws, size_t ws_bytes, hipStream_t s);
+                      const void* d_o, void* dqkv, void* ws, size_t ws_bytes, hipStream_t s, const unsigned long long* kbits = nullptr);
+// attention_mfma.hip: keep-bits of layers first .. first + n - 1 (n <= 8) into out[i]: [B * H * S][2] 64-bit words
+int tim_attn_keep_bits(const TimDesc& d, int first_layer, int n, unsigned long long* const* out, hipStream_t s);
 size_t tim_attention_bwd_ws(const TimDesc& d);
 
 // operand storage: bf16 for TIMHIP_PREC_BF16, fp16 for TIMHIP_PREC_F16, fp32 for TIMHIP_PREC_FP32 and TIMHIP_PREC_BF16X3

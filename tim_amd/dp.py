@@ -91,6 +91,7 @@ class DataParallel(nn.Module):
         self.collective = "a2a"     # "rs_ag" | "a2a" | "allreduce": agreed by the whole group in _choose_collective, never changed afterwards
         self._why = ""
         self._wanted = None
+        self._stub = os.environ.get("TIM_AMD_DP_STUB", "0") == "1"
         rt = module.rt
         rt.bucket_hook = self._on_bucket
         rt.finish_hook = self._on_encoder_done
@@ -275,6 +276,12 @@ class DataParallel(nn.Module):
         reduce-scatter + all-gather, all-to-all + fp32 sum + all-gather on `wire_dtype`, or one fp32 all-reduce.  No per-rank
         fallback (see _choose_collective)."""
         W, n = self.world, flat.numel()
+        if self._stub:
+            # measurement mode (tools/dp_graph_check.py, TIM_AMD_DP_STUB=1): everything the wrapper does around an exchange - the
+            # comm-stream fork and join, the events, the per-layer hooks - with the collectives replaced by ONE one-element
+            # kernel: what is left of the wrapper's single-GPU cost when no byte is copied.  Never a training mode.
+            flat[:1].add_(0.0)
+            return
         if self.collective == "allreduce":
             dist.all_reduce(flat, group=self.pg)
             flat.mul_(1.0 / W)

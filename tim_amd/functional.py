@@ -757,13 +757,25 @@ class EncoderFn(torch.autograd.Function):
         ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
         ws = model._workspace(ws_bytes, dev)
         stack = model._stack_prefix
-        layer_saved = []
+        layer_saved = [torch.empty(saved_bytes, dtype=torch.uint8, device=dev) for _ in range(Lyr)]
+        # training, 128-wide heads with 97 .. 128 feature keys (C2a / C3 / C4): the keep-bits of every layer's attention dropout in
+        # ONE launch ahead of the stack (timhip_attn_keep_bits -> the layers' saved blocks); the attention forward and the fused
+        # backward then read 16 bytes per row instead of running Philox per (row, key) in both directions.  Same stream, same
+        # masks (tests/test_gpu_train_parity.py); TIM_AMD_ATTN_KEEP_BITS=0: the kernels draw their own (A/B switch)
+        keep_flag = 0
+        if p_enc > 0.0 and rt.h16 and os.environ.get("TIM_AMD_ATTN_KEEP_BITS", "1") != "0":
+            rc = L.load().timhip_attn_keep_bits(C.byref(desc), Lyr, _parr(layer_saved), st)
+            if rc == 0:
+                keep_flag = L.DESC_ATTN_KEEP_BITS
+                desc.reserved |= keep_flag
+            elif rc != L.EUNSUPPORTED:
+                L.check(rc, "timhip_attn_keep_bits")
         lparams = []
         for l in range(Lyr):
             pre = "%s.layers.%d." % (stack, l)
             lp = model._layer_params(rt, P, pre)
             lparams.append(lp)
-            sv = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            sv = layer_saved[l]
             desc.layer = l
             if l == 0:
                 call("timhip_layer_fwd", C.byref(desc), C.byref(lp[0]), ptr(xs_f[0]), ptr(xs_t[0]), ptr(xs_f[1]),
@@ -771,7 +783,6 @@ class EncoderFn(torch.autograd.Function):
             else:
                 call("timhip_layer_fwd_chained", C.byref(desc), C.byref(lp[0]), C.byref(lparams[l - 1][0]),
                      ptr(layer_saved[l - 1]), ptr(xs_t[l]), ptr(xs_f[l + 1]), ptr(xs_t[l + 1]), ptr(sv), st)
-            layer_saved.append(sv)
 
         # ---- heads (head.py:17-38).  fp16 model: the logits are produced with split operands from the fp32 rows of the last
         # layer; the backward gathers the fp16 rows it needs itself
@@ -832,6 +843,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.model, ctx.plan, ctx.P_names = model, plan, model._encoder_param_names
         ctx.dims = (B, T, d, S, F, M, nv, na)
         ctx.drop = (p_feat, p_seq, p_enc, seed)
+        ctx.keep_flag = keep_flag
         ctx.salt_epoch = _SALT["epoch"] if training else None
         ctx.emb_saved, ctx.layer_saved, ctx.head_saved, ctx.reg_saved = emb_saved, layer_saved, head_saved, reg_saved
         ctx.emb_pair = (u_all, stats_all) if pair else None
@@ -972,7 +984,7 @@ class EncoderFn(torch.autograd.Function):
         # weight-gradient GEMMs on a side stream (they overlap the data chain of the next layer);
         # each layer's bucket is handed to the hook as soon as its weight gradients are enqueued.
         desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0,
-                         (L.DESC_WGRAD_OVERWRITE if overwrite else 0) | (L.DESC_WGRAD_SEPARATE if rt.separate_wgrad else 0),
+                         (L.DESC_WGRAD_OVERWRITE if overwrite else 0) | (L.DESC_WGRAD_SEPARATE if rt.separate_wgrad else 0) | ctx.keep_flag,
                          gs_in)
         lib = L.load()
         dx2 = torch.empty_like(dx)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--precision", default="fp16")
     ap.add_argument("--quick", action="store_true", help="parity only, small batch (the test suite's form)")
+    ap.add_argument("--short", action="store_true", help="rs_ag / rs_ag with stubbed collectives / allreduce only (no a2a rows)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -117,11 +118,17 @@ def main():
     g_plain, _ = median_ms(gp, warm=10)
     print("PLAIN   eager %.3f ms (host issue %.3f)   replay %.3f ms" % (e_plain, i_plain, g_plain), flush=True)
     del gp
-    for coll, wire in (("rs_ag", torch.float32), ("a2a", torch.float32), ("a2a", torch.bfloat16), ("allreduce", torch.float32)):
+    # round 6: "stub" rows - the collectives replaced by a one-element kernel (tim_amd/dp.py: _stub): the wrapper's joins, events,
+    # per-layer hooks and launches WITHOUT the copies a one-rank collective amounts to
+    combos = [("rs_ag", torch.float32, False), ("rs_ag", torch.float32, True), ("allreduce", torch.float32, False)]
+    if not a.short:
+        combos += [("a2a", torch.float32, False), ("a2a", torch.bfloat16, False)]
+    for coll, wire, stub in combos:
         for bpe in (1, 2, 4, 99):
             m = fresh()
             w = DataParallel(m, force=True, buckets_per_exchange=bpe, wire_dtype=wire, collective=coll)
             assert w.collective == coll, (w.collective, w._why)
+            w._stub = stub
             Rw = [None]
             fw = lambda: bench.step_fn(w, batch, nv, na, Rw)   # noqa: E731
             e_ms, i_ms = median_ms(fw)
@@ -137,8 +144,8 @@ def main():
                     g_txt = "replay %.3f ms (+%.3f)" % (g_ms, g_ms - g_plain)
                 except Exception as e:  # noqa: BLE001
                     g_txt = "replay: capture failed (%s)" % str(e).replace("\n", " | ")[:200]
-            print("DP %-9s wire=%s buckets_per_exchange=%-3s  eager %.3f ms (+%.3f; host issue %.3f)   %s   comm stream busy %.3f ms"
-                  % (coll, "fp32" if wire == torch.float32 else "bf16", "all" if bpe == 99 else bpe, e_ms, e_ms - e_plain, i_ms, g_txt,
+            print("DP %-14s wire=%s buckets_per_exchange=%-3s  eager %.3f ms (+%.3f; host issue %.3f)   %s   comm stream busy %.3f ms"
+                  % (coll + (" STUB" if stub else ""), "fp32" if wire == torch.float32 else "bf16", "all" if bpe == 99 else bpe, e_ms, e_ms - e_plain, i_ms, g_txt,
                      comm_ms), flush=True)
             m.rt.bucket_hook = None
             m.rt.finish_hook = None
