@@ -564,7 +564,9 @@ template <typename HT, int DH, int NJB>
 int launch_fwd(const TimDesc& d, const void* qkv, void* o, float* lse, hipStream_t s, const unsigned long long* kbits) {
   const size_t lds = (size_t)2 * NJB * 32 * DH * 2;
   AttnArgsM a = make_args(d);
-  attn_row_split(d, 4, a.rsplit, a.rper);
+  // (few windows - B * H < 128, e.g. C2a at 8 windows per GPU - leave most CUs without a block: split down to TIMHIP_ATTN_SPLIT_MIN
+  //  row blocks per workgroup there; default 4 = one per wave of a full block)
+  attn_row_split(d, d.B * d.H < 128 ? tim_knobs().attn_split_min : 4, a.rsplit, a.rper);
   if constexpr (DH == 128 && NJB == 4) {   // (the keep-bit form exists for the geometry tim_attn_keep_bits serves: C2a / C3 / C4)
     if (kbits && a.thr != 0u) {
       a.kbits = kbits;

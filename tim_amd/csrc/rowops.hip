@@ -1277,15 +1277,21 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
 }
 
 // 16 rows per block, more when that would exceed the 768 co-resident blocks (3 per CU at the 154 VGPRs of the encoder's
-// act == 0 kernel): one balanced round
+// act == 0 kernel): one balanced round.  Round 6: FEWER for small row counts - 1240 rows (C2a at 8 windows per GPU, the reference
+// recipe on 8 GPUs) made 78 blocks of 16 rows on 256 CUs, 12.3 us for 18 MB; 4 / 8 / 12 rows per block keep about 500 blocks
 static int ln_bwd_rows_per_block(int rows) {
   if (tim_knobs().ln_rpb >= 4) return tim_knobs().ln_rpb / 4 * 4;   // (A/B knob)
   int rpb = 16;
   if (rows > 16 * 768) rpb = (((rows + 767) / 768) + 3) / 4 * 4;
+  else if (rows < 16 * 512) { rpb = (((rows + 511) / 512) + 3) / 4 * 4; if (rpb < 4) rpb = 4; }
   return rpb;
 }
 
-size_t tim_layernorm_bwd_ws(int rows, int cols) { return (size_t)((rows + 15) / 16) * 2 * cols * sizeof(float); }
+// (per-block partial sums [gamma | beta][cols] of one launch without atomics: as many rows as the launch has blocks)
+size_t tim_layernorm_bwd_ws(int rows, int cols) {
+  const int rpb = ln_bwd_rows_per_block(rows);
+  return (size_t)((rows + rpb - 1) / rpb) * 2 * cols * sizeof(float);
+}
 
 int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, int ldy, const float* stats,
                       int rows, int cols, int act, const float* w, float* dyf, int lddy, void* dyt, int ldt,

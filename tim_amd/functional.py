@@ -689,6 +689,31 @@ class EncoderFn(torch.autograd.Function):
         st = _stream()
         fe = "feature_encoding."
 
+        # ---- per-layer saved blocks and, in training, the keep-bits of every layer's attention dropout: ONE launch ahead of the
+        # stack (timhip_attn_keep_bits -> the layers' saved blocks; 128-wide heads with 97 .. 128 feature keys: C2a / C3 / C4).  The
+        # attention forward and the fused backward then read 16 bytes per row instead of running Philox per (row, key) in both
+        # directions.  Same stream of random numbers, same masks (tests/test_gpu_train_parity.py); TIM_AMD_ATTN_KEEP_BITS=0: the
+        # kernels draw their own (A/B switch).  TIM_AMD_KEEP_BITS_SIDE=1 (A/B switch): the launch - VALU-bound, 16 us, independent
+        # of the front end - on the runtime's side stream under the embedders / the weight refresh, joined in front of layer 0
+        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, rt.layer_split_flags(E, FF), None)
+        saved_bytes = L.load().timhip_layer_saved_bytes(C.byref(desc))
+        layer_saved = [torch.empty(saved_bytes, dtype=torch.uint8, device=dev) for _ in range(Lyr)]
+        keep_flag = 0
+        bits_pending = None
+        if p_enc > 0.0 and rt.h16 and os.environ.get("TIM_AMD_ATTN_KEEP_BITS", "1") != "0":
+            if os.environ.get("TIM_AMD_KEEP_BITS_SIDE", "0") == "1":
+                aux_s = rt.aux_stream(dev)
+                aux_s.wait_stream(torch.cuda.current_stream())   # (the blocks' previous owners are done)
+                rc = L.load().timhip_attn_keep_bits(C.byref(desc), Lyr, _parr(layer_saved), aux_s.cuda_stream)
+                bits_pending = aux_s
+            else:
+                rc = L.load().timhip_attn_keep_bits(C.byref(desc), Lyr, _parr(layer_saved), st)
+            if rc == 0:
+                keep_flag = L.DESC_ATTN_KEEP_BITS
+                desc.reserved |= keep_flag
+            elif rc != L.EUNSUPPORTED:
+                L.check(rc, "timhip_attn_keep_bits")
+
         # ---- modality embedders: e = LN(GELU(drop(x) W^T + b))  (encodings.py:21-26,140-153)
         # Two modalities: their rows are STACKED ([visual | audio], R = B * nf rows each) so that the casts, the projections and the
         # LayerNorms are one launch each (timhip_cast_rows_pair, the grouped GEMM, timhip_layernorm_fwd2; the backward's
@@ -752,24 +777,11 @@ class EncoderFn(torch.autograd.Function):
              ptr(te_c), T, _parr(mod_v), len(mod_v), p_seq, seed, L.SITE_SEQ, ptr(xs_f[0]), ptr(xs_t[0]), st)
 
         # ---- L post-norm encoder layers (transformers.py:44-45,92-111)
-        desc = L.TimDesc(B, S, F, d, E, H, FF, rt.prec, p_enc, seed, 0, rt.layer_split_flags(E, FF), None)
-        saved_bytes = L.load().timhip_layer_saved_bytes(C.byref(desc))
         ws_bytes = L.load().timhip_layer_workspace_bytes(C.byref(desc))
         ws = model._workspace(ws_bytes, dev)
         stack = model._stack_prefix
-        layer_saved = [torch.empty(saved_bytes, dtype=torch.uint8, device=dev) for _ in range(Lyr)]
-        # training, 128-wide heads with 97 .. 128 feature keys (C2a / C3 / C4): the keep-bits of every layer's attention dropout in
-        # ONE launch ahead of the stack (timhip_attn_keep_bits -> the layers' saved blocks); the attention forward and the fused
-        # backward then read 16 bytes per row instead of running Philox per (row, key) in both directions.  Same stream, same
-        # masks (tests/test_gpu_train_parity.py); TIM_AMD_ATTN_KEEP_BITS=0: the kernels draw their own (A/B switch)
-        keep_flag = 0
-        if p_enc > 0.0 and rt.h16 and os.environ.get("TIM_AMD_ATTN_KEEP_BITS", "1") != "0":
-            rc = L.load().timhip_attn_keep_bits(C.byref(desc), Lyr, _parr(layer_saved), st)
-            if rc == 0:
-                keep_flag = L.DESC_ATTN_KEEP_BITS
-                desc.reserved |= keep_flag
-            elif rc != L.EUNSUPPORTED:
-                L.check(rc, "timhip_attn_keep_bits")
+        if bits_pending is not None:   # the keep-bits launch of the side stream joins here
+            torch.cuda.current_stream().wait_stream(bits_pending)
         lparams = []
         for l in range(Lyr):
             pre = "%s.layers.%d." % (stack, l)
