@@ -459,12 +459,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pt_kernel(const HT* __restrict__ 
 // of the consumer group, which have no other vector-memory operation in the loop (loads return in order: a wave that also
 // issued DMA pieces would wait for its prefetches).  The loaded dword is never used.
 struct PlPrefetch { const void* base; uint32_t off; int on, dist; };
-// Residual prefetch (round 6): the "+ residual" epilogues read 160 x 256 fp32 values per tile (164 KB per CU, 40 MB per launch)
-// AFTER the main loop, in one burst with the 40 MB they write - while the loop itself leaves the fabric nearly idle (its
-// operands are L2 hits).  The consumer waves therefore touch the tile's residual lines during contraction steps start ..
-// start + 2 (one dword per 128-byte line and lane, 1280 lines per tile): the burst's reads then come from L2 / the Infinity
-// Cache instead of HBM.  mask bit j: this lane's line of pass j exists.
-struct PlResPf { const char* base; uint32_t off, stride; int mask, start; };
 
 // ONEBAR (gemm_nt_ld kernel with one barrier per contraction step): with no DMA instruction and no vmcnt wait in the consumer
 // waves, the antiphase of the two groups can come from program order instead of a second barrier -
@@ -477,7 +471,7 @@ struct PlResPf { const char* base; uint32_t off, stride; int mask, start; };
 //        before B_t).
 template <typename HT, int TMW, int G, bool ONEBAR = false>
 __device__ __forceinline__ void pl_consume(int nk, const char* lds, int a_frag, int b_frag, int c0, int c1, f32x4_t (&acc)[PP_TNW][TMW],
-                                           const PlPrefetch& pf, const PlResPf rp = PlResPf{nullptr, 0u, 0u, 0, 0}) {
+                                           const PlPrefetch& pf) {
   constexpr int BM = 32 * TMW;
   constexpr int ST_BYTES = (BM + PP_BN) * PP_ROWB;
   if constexpr (ONEBAR) {
@@ -533,20 +527,12 @@ __device__ __forceinline__ void pl_consume(int nk, const char* lds, int a_frag, 
   vec8<HT> xa[TMW], wb[PP_TNW], xb[TMW], wc[PP_TNW];
   int slot = 0;
   uint32_t pf_sink = 0;
-  uint32_t rp_sink = 0;
   for (int t = 0; t < nk; ++t) {
     if (pf.on && t + pf.dist < nk) {
       const char* g = reinterpret_cast<const char*>(pf.base) + pf.off + (size_t)(t + pf.dist) * PP_ROWB;
       // "+v": the sink stays one dedicated register from here to the wait after the loop - the data returns asynchronously, a
       // register the compiler considered dead after the asm would be reused (e.g. for the next address) and overwritten late
       asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(g) : "memory");
-    }
-    if (rp.mask) {   // (wave-uniform test first: one scalar branch per step in the launches without a residual)
-      const int j = t - rp.start;
-      if (j >= 0 && j < 3 && ((rp.mask >> j) & 1)) {
-        const char* g = rp.base + rp.off + (size_t)j * rp.stride;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(rp_sink) : "v"(g) : "memory");
-      }
     }
     const char* base = lds + slot * ST_BYTES;
 #pragma unroll
@@ -570,7 +556,7 @@ __device__ __forceinline__ void pl_consume(int nk, const char* lds, int a_frag, 
     slot = slot + 1 == PP_NST ? 0 : slot + 1;
   }
   if constexpr (G == 0) pp_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink), "+v"(rp_sink) :: "memory");   // the sink registers are free for reuse only now
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");   // the sink register is free for reuse only now
 }
 
 template <typename HT, int TMW, bool ONEBAR = false>
@@ -639,7 +625,7 @@ __device__ __forceinline__ void pl_load(const HT* __restrict__ A, int lda, const
 
 template <typename HT, int EPI, int TMW, bool ONEBAR = false>
 __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
-                                                         int M, int N, int K, EpiDev e, int pf_dist, int pf_mode, int respf = 0) {
+                                                         int M, int N, int K, EpiDev e, int pf_dist, int pf_mode) {
   constexpr int BM = 32 * TMW;
   constexpr int A_BYTES = BM * PP_ROWB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -684,20 +670,8 @@ __global__ __launch_bounds__(768) void gemm_nt_ld_kernel(const HT* __restrict__ 
       pf.off = (uint32_t)((size_t)min(n0 + row, N - 1) * ldb * 2);
     }
   }
-  PlResPf rp{nullptr, 0u, 0u, 0, 0};
-  if constexpr (EPI == TIMHIP_EPI_DROP_RES_F32 && !ONEBAR) {
-    if (respf > 0 && e.res && e.vec) {   // this lane's residual lines: line L = 512 j + 64 wave + lane -> (row L / 8, columns 32 (L % 8) ..)
-      const int l0 = wave * 64 + lane, row0 = l0 >> 3, col = n0 + (l0 & 7) * 32;
-      rp.base = reinterpret_cast<const char*>(e.res);
-      rp.off = (uint32_t)(((size_t)min(m0 + row0, M - 1) * e.ldres + min(col, N - 1)) * 4);
-      rp.stride = (uint32_t)((size_t)64 * e.ldres * 4);
-      rp.start = respf;
-      for (int j = 0; j < 3; ++j)
-        if (row0 + 64 * j < BM && m0 + row0 + 64 * j < M && col < N) rp.mask |= 1 << j;
-    }
-  }
-  if (wm == 0) pl_consume<HT, TMW, 0, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf, rp);
-  else pl_consume<HT, TMW, 1, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf, rp);
+  if (wm == 0) pl_consume<HT, TMW, 0, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
+  else pl_consume<HT, TMW, 1, ONEBAR>(nk, lds, a_frag, b_frag, c0, c1, acc, pf);
   __syncthreads();   // every wave is done with the stage ring: it becomes the epilogue's transposition space
   float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
   pp_epilogue<HT, EPI, TMW, 2>(e, acc, m0 + wm * 16 * TMW, n0 + wn * 64, M, N, ep, lane);
@@ -1455,7 +1429,7 @@ void launch_pp(const void* A, int lda, const void* B, int ldb, int M, int N, int
       return;
     }
     hipLaunchKernelGGL((gemm_nt_ld_kernel<HT, EPI, TMW>), grid, dim3(768), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e,
-                       pf_d_, kn.gemm_pf_mode, kn.gemm_respf);
+                       pf_d_, kn.gemm_pf_mode);
     return;
   }
   if constexpr (TMW == 5)

@@ -25,6 +25,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tim_amd",
 BUDGET = {
     "gemm.hip": [(r"gemm_nt_h16_kernel", 0), (r"gemm_nt_group_kernel", 0)],
     "gemm_pp.hip": [(r"gemm_nt_ld_kernel", 0), (r"gemm_nt_pp_kernel", 0),
+                    (r"gemm_nt_p8_kernel", 0),   # round 6: 196 (256-row tile) / 239 (320-row tile) VGPRs of 256
                     # the tile walk's epilogues re-derive their lane arithmetic per tile and scratch-store a few registers once per
                     # tile (measured with these counts: the walk wins 0.5 % of the step); the residual
                     # epilogue (EPI 4) is not on any BASELINE config's path (its shapes run one round: gemm_nt_ld_kernel)
@@ -32,7 +33,8 @@ BUDGET = {
     "wgrad_pp.hip": [(r"wgrad_ld_kernel", 0), (r"wgrad_pp_kernel", 0)],
     "wgrad.hip": [(r"wgrad_group_kernel", 0), (r"wgrad_tn_kernel", 0)],
     "attention_mfma.hip": [(r"attn_fwd_mfma", 0)],
-    "attention_bwd2.hip": [(r"attn_bwd_rowsIDF16_Li128ELi4ELb1E", 0)],          # the fp16 fused backward (C2a / C3 / C2b)
+    # the fp16 fused backward (C2a / C3 / C4), with the kernel's own draws and with the keep-bits of round 6
+    "attention_bwd2.hip": [(r"attn_bwd_rowsIDF16_Li128ELi4ELb1E", 0), (r"attn_bwd_rowsIDF16[_b]Li128ELi4ELb1ELb1ELb1E", 0)],
     "rowops.hip": [(r"ln_fwd8", 0), (r"ln_bwd_kernel", 0)],
 }
 

@@ -19,8 +19,9 @@ import socket
 import sys
 
 FAMILIES = [   # (family, regex on the kernel name)
-    ("nt_gemm", r"gemm_nt_ld_kernel|gemm_nt_ldp_kernel|gemm_nt_pp_kernel"),
+    ("nt_gemm", r"gemm_nt_ld_kernel|gemm_nt_ldp_kernel|gemm_nt_pp_kernel|gemm_nt_p8_kernel"),
     ("wgrad_layer", r"wgrad_ld_kernel|wgrad_pp_kernel"),
+    ("attention_keep_bits", r"attn_keep_bits"),
     ("attention_fwd", r"attn_fwd"),
     ("attention_bwd", r"attn_bwd"),
     ("layernorm_fwd", r"ln_fwd"),
@@ -109,7 +110,8 @@ def main():
             "ms_per_step": b.get("ms_per_step"), "value": b.get("value"), "step_mode": (b.get("step_mode") or "")[:32],
             "roofline_frac": (b.get("roofline") or {}).get("frac"), "whole_step_frac": (b.get("whole_step") or {}).get("frac_of_mfma_peak"),
             "eager": b.get("eager"), "forward_only": b.get("forward_only"), "parity": (b.get("parity") or {}).get("max_abs_logit_err"),
-            "secondary_replay_ms": {k: (b[k].get("graph_replay") or {}).get("ms_per_step") for k in ("c2b", "c1", "c3", "c4_train") if k in b}}
+            "secondary_replay_ms": {k: (b[k].get("graph_replay") or {}).get("ms_per_step") for k in ("c2a_b8", "c2a_train", "c2b", "c1", "c3", "c4_train") if k in b},
+            "repeat_ms": b.get("repeat_ms"), "non_gemm": b.get("non_gemm"), "launches_per_step": b.get("launches_per_step")}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: res[k] for k in ("kernel_time_us_per_step", "launches_per_step", "non_gemm_us_per_step")}))
 
