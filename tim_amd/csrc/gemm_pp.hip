@@ -782,7 +782,9 @@ template <int TM, int G> struct P8Share {
 };
 struct P8Tab { uint32_t offA[2][3], offB[2][2]; int dstA[2][3], dstB[2][2]; };
 
-template <typename HT, int TM, int G>
+// VAR (experiment arms, fp16 plain-store instances only - TIMHIP_GEMM_P8_VAR): bit 0 no s_setprio around the MFMA segments,
+// bit 1 the fragment reads are waited for AFTER the phase's first barrier (the guide's order) instead of before it
+template <typename HT, int TM, int G, int VAR = 0>
 __device__ __forceinline__ void p8_mainloop(const HT* __restrict__ A, const HT* __restrict__ B, int nk, const char* lds, uint32_t lds0,
                                             const P8Tab& tb, int a_frag, int b_frag, int c0, int c1, f32x4_t (&acc)[PP_TNW][TM]) {
   constexpr int BM = 32 * TM, KT = (BM + PP_BN) * PP_ROWB, HM = TM / 2;
@@ -821,7 +823,8 @@ __device__ __forceinline__ void p8_mainloop(const HT* __restrict__ A, const HT* 
   };
   auto mma = [&](auto qm_c, auto qn_c) {
     constexpr int qm = decltype(qm_c)::value, qn = decltype(qn_c)::value;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (VAR & 2) { pp_wait_lds(); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -829,8 +832,9 @@ __device__ __forceinline__ void p8_mainloop(const HT* __restrict__ A, const HT* 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[2 * qn + j][qm * HM + i] = mfma16x16<HT>(wb[j][kh], xa[i][kh], acc[2 * qn + j][qm * HM + i]);
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
   };
+  auto wait_reads = [&]() { if constexpr (!(VAR & 2)) pp_wait_lds(); };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   for (int t = 0; t < nk; ++t) {
@@ -841,32 +845,32 @@ __device__ __forceinline__ void p8_mainloop(const HT* __restrict__ A, const HT* 
     // phase 1: quadrant (0, 0)
     read_b(bb, 0); read_a(bb, 0);
     if (s1) stage_b(t + 1, oth, 0);
-    pp_wait_lds(); pp_barrier();
+    wait_reads(); pp_barrier();
     mma(I0{}, I0{});
     pp_barrier();
     // phase 2: quadrant (0, 1) - A fragments kept
     read_b(bb, 1);
     if (s2) stage_a(t + 2, cur, 0);
-    pp_wait_lds(); pp_barrier();
+    wait_reads(); pp_barrier();
     mma(I0{}, I1{});
     pp_barrier();
     // phase 3: quadrant (1, 1) - B fragments kept
     read_a(bb, 1);
     if (s2) stage_b(t + 2, cur, 1);
-    pp_wait_lds(); pp_barrier();
+    wait_reads(); pp_barrier();
     mma(I1{}, I1{});
     pp_barrier();
     // phase 4: quadrant (1, 0) - A fragments kept; the step's one counted wait: B0 of step t + 1 (and everything older) has landed
     read_b(bb, 0);
     if (s2) { stage_a(t + 2, cur, 1); glds_wait<2 * NA + NB>(); } else { glds_wait<0>(); }
-    pp_wait_lds(); pp_barrier();
+    wait_reads(); pp_barrier();
     mma(I1{}, I0{});
     pp_barrier();
   }
   if constexpr (G == 0) pp_barrier();   // as many barriers as group 1
 }
 
-template <typename HT, int EPI, int TM>
+template <typename HT, int EPI, int TM, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
                                                          int M, int N, int K, EpiDev e) {
   constexpr int BM = 32 * TM, A_BYTES = BM * PP_ROWB;
@@ -914,8 +918,8 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(const HT* __restrict__ 
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nk = K / 64;
-  if (wr == 0) p8_mainloop<HT, TM, 0>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
-  else p8_mainloop<HT, TM, 1>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+  if (wr == 0) p8_mainloop<HT, TM, 0, VAR>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+  else p8_mainloop<HT, TM, 1, VAR>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
   __syncthreads();   // every wave is done with the buffers: they become the epilogue's transposition space
   float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
   pp_epilogue<HT, EPI, TM, 2, PpNoSync, 2>(e, acc, m0 + wr * 16 * TM, n0 + wc * 64, M, N, ep, lane);
@@ -929,6 +933,16 @@ void launch_p8(const void* A, int lda, const void* B, int ldb, int M, int N, int
   if (attr_set.first())
     (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<HT, EPI, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   const dim3 grid(((M + BM - 1) / BM) * ((N + PP_BN - 1) / PP_BN));
+#ifdef TIMHIP_P8_VARIANTS   // experiment arms (tools/p8_ab.py with TIMHIP_GEMM_P8_VAR): plain-store fp16 instances only
+  if constexpr (EPI == TIMHIP_EPI_STORE_T && sizeof(HT) == 2 && __is_same(HT, f16_t)) {
+    static const int var = getenv("TIMHIP_GEMM_P8_VAR") ? atoi(getenv("TIMHIP_GEMM_P8_VAR")) : 0;
+    const int v = getenv("TIMHIP_GEMM_P8_VAR") ? atoi(getenv("TIMHIP_GEMM_P8_VAR")) : var;
+#define P8V(V) if (v == V) { (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<HT, EPI, TM, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      hipLaunchKernelGGL((gemm_nt_p8_kernel<HT, EPI, TM, V>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e); return; }
+    P8V(1) P8V(2) P8V(3)
+#undef P8V
+  }
+#endif
   hipLaunchKernelGGL((gemm_nt_p8_kernel<HT, EPI, TM>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
 }
 
