@@ -169,6 +169,8 @@ void read_knobs(TimKnobs& k) {
   k.gemm_pp_min = env_int("TIMHIP_GEMM_PP_MIN_TILES", 192);
   k.attn_ks = env_int("TIMHIP_ATTN_KS", 1);
   k.gemm_p8 = env_int("TIMHIP_GEMM_P8", 1);
+  k.ln_pair = env_int("TIMHIP_LN_PAIR", 1);
+  k.epi_pair = env_int("TIMHIP_EPI_PAIR", 1);
   k.attn_split_min = env_int("TIMHIP_ATTN_SPLIT_MIN", 4);
   if (k.attn_split_min < 1) k.attn_split_min = 1;
 }

@@ -296,6 +296,8 @@ struct TimKnobs {
   int attn_ks;        // TIMHIP_ATTN_KS      0: fused attention backward with the one-wave-per-row-block phase 1 (default 1: key-split)
   int gemm_pp_min;    // TIMHIP_GEMM_PP_MIN_TILES  fewest 160 x 256 tiles the one-block-per-CU NT kernels are used for (default 192)
   int attn_split_min; // TIMHIP_ATTN_SPLIT_MIN  attention forward, B * H < 128: fewest row blocks per workgroup when a (window, head) is split (default 4)
+  int epi_pair;       // TIMHIP_EPI_PAIR     dropout + residual NT epilogue: lane pairs share the Philox calls of their keep factors (default 1)
+  int ln_pair;        // TIMHIP_LN_PAIR      LayerNorm backward: lane pairs share the Philox calls of their dropout keep factors (default 1)
   int gemm_p8;        // TIMHIP_GEMM_P8      eight-phase 256 / 320 x 256 tiles for the multi-round NT shapes: 0 off, 1 by shape (default), 2 + the mulaux epilogue, 8 / 10 forced
 };
 const TimKnobs& tim_knobs();

@@ -723,6 +723,7 @@ static int prepare_gemm(int precision, int epi, const void* A, int lda, const vo
   e.ln_stats = te.ln_stats; e.ln_w = te.ln_w; e.ln_b = te.ln_b;
   e.acc_scale = te.acc_scale;
   e.a_wrap = te.a_wrap_k / 64;
+  e.pair = tim_knobs().epi_pair;
   if (e.ln_stats && (epi != TIMHIP_EPI_DROP_RES_F32 || !e.res || !e.ln_w || !e.ln_b)) return TIMHIP_EINVAL;
   if (epi == TIMHIP_EPI_RELU_SPLIT3_T && (!h16_storage(precision) || e.out1 || e.ld1 % 64 || e.ld1 < N || e.ld0 < 3 * e.ld1 || splitk > 1))
     return TIMHIP_EINVAL;   // three column blocks of width ld1 in a row of stride ld0

@@ -23,6 +23,7 @@ struct EpiDev {
   int vec;  // all leading dims % 4 == 0 and pointers 16 B aligned
   int vec8; // the operand-dtype outputs / aux of this epilogue also allow 8-element (16-byte) accesses
   long long slab_stride;  // EPI_STORE_F32 with split-K: split z writes out0 + z*slab_stride (elements)
+  int pair;     // dropout + residual epilogue of the one-block-per-CU kernels: lane pairs share their Philox calls (TIMHIP_EPI_PAIR, default 1)
   int a_wrap;   // 0, or the number of 64-deep contraction steps after which the A operand repeats (TimEpi.a_wrap_k / 64): the
                 // product of an activation matrix with a weight matrix split into [hi | lo] column blocks reads A twice
 };
@@ -115,11 +116,14 @@ __device__ __forceinline__ void epi_quad(const EpiDev& e, int m, int n, int N, f
                                          float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), bool has_ln = false,
                                          float2 pst = make_float2(0.f, 1.f),
                                          float4 pg = make_float4(1.f, 1.f, 1.f, 1.f),
-                                         float4 pbe = make_float4(0.f, 0.f, 0.f, 0.f)) {
+                                         float4 pbe = make_float4(0.f, 0.f, 0.f, 0.f), bool has_k = false,
+                                         float4 kpre = make_float4(1.f, 1.f, 1.f, 1.f)) {
   float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
   if (epi_uses_dropout(EPI) && e.thr != 0u) {
     // element index m*N + n, N % 4 == 0 wherever dropout is applied
-    if (e.mask)
+    if (has_k) {   // keep factors drawn by the caller (lane pairs sharing the Philox calls of two quads: pp_epilogue)
+      k0 = kpre.x; k1 = kpre.y; k2 = kpre.z; k3 = kpre.w;
+    } else if (e.mask)
       drop_mask4_bits((uint32_t)e.mask[(size_t)m * e.ldmask + (n >> 3)] >> (n & 4), e.scale, k0, k1, k2, k3);
     else
       drop_mask4(e.seed, e.site, ((uint64_t)m * (uint64_t)N + (uint64_t)n) >> 2, e.thr, e.scale, k0, k1, k2, k3);

@@ -160,15 +160,42 @@ __device__ __forceinline__ void pp_epilogue(const EpiDev& e, const f32x4_t (&acc
         }
       }
     } else {
-#pragma unroll
-      for (int it = 0; it < NITQ; ++it) {
+      // dropout + residual: a lane's four quads of a row block sit at the same columns of rows r, r + 4, r + 8, r + 12, and lanes
+      // 2 k / 2 k + 1 hold the two halves of one Philox counter's 8 elements in EVERY one of them.  Round 6: the even lane draws
+      // the counter of quad `it`, the odd lane that of quad `it + 1`, and they trade halves (two DPP moves) - 2 calls per lane and
+      // row block instead of 4, same counters, same bits (as in ln_bwd_kernel).  N % 8 == 0 keeps a pair inside one counter.
+      bool has_k = false;
+      if constexpr (EPI == TIMHIP_EPI_DROP_RES_F32 && (NITQ % 2) == 0) has_k = e.thr != 0u && !e.mask && e.vec && (N & 7) == 0 && e.pair;
+      auto quad = [&](int it, bool hk, float4 kf) {
         const int idx = it * 64 + lane;
         const int row = idx / CPR, ch = idx % CPR;
         const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
         const int m = mw0 + j * RBS + row, n = nw0 + ch * 4;
         if (m < M && n < N)
           epi_quad<EPI, HT>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PFD][PRE_RES ? it : 0], pre_b4 && n + 3 < N,
-                            bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j % PFD][PRE_RES ? it : 0], lng, lnb);
+                            bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j % PFD][PRE_RES ? it : 0], lng, lnb, hk, kf);
+      };
+      if (has_k) {
+        if constexpr ((NITQ % 2) == 0) {
+#pragma unroll
+          for (int it = 0; it < NITQ; it += 2) {   // (one pair's eight factors live at a time: the 12-wave kernel sits at its 168 registers)
+            const int idx = (it + (lane & 1)) * 64 + (lane & ~1);
+            const long long m_ = mw0 + j * RBS + idx / CPR, n_ = nw0 + (idx % CPR) * 4;
+            const Philox4 r = philox4x32_7(e.seed, e.site, (uint64_t)(m_ * (long long)N + n_) >> 3);
+            const bool odd = (lane & 1) != 0;
+            const uint32_t sa = odd ? r.x : r.z, sb = odd ? r.y : r.w;
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_mov_dpp((int)sb, 0xB1, 0xF, 0xF, true);
+            float4 ka, kb;
+            drop_mask4_words(odd ? pa : r.x, odd ? pb : r.y, e.thr, e.scale, ka.x, ka.y, ka.z, ka.w);
+            drop_mask4_words(odd ? r.z : pa, odd ? r.w : pb, e.thr, e.scale, kb.x, kb.y, kb.z, kb.w);
+            quad(it, true, ka);
+            quad(it + 1, true, kb);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < NITQ; ++it) quad(it, false, make_float4(1.f, 1.f, 1.f, 1.f));
       }
     }
     if constexpr (j + PFD < TMW) fetch_res(std::integral_constant<int, j + PFD>{});   // refill this block's ring entry

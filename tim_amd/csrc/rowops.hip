@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ dbeta, int rows_pb,
                                                      float* __restrict__ partial, const float* __restrict__ t_scale,
                                                      const T* __restrict__ addt, int ldadd, const float* __restrict__ add_scale,
-                                                     LnSplit sp) {
+                                                     LnSplit sp, int pair_sw) {
   extern __shared__ float red[];  // [4][2][cols]
   if (blockIdx.x * rows_pb >= sp.row) { w = sp.w2; dgamma = sp.dg2; dbeta = sp.db2; }
   const float ts = t_scale ? *t_scale : 1.f;   // factor on the operand-dtype copy (gradient scale of the fp16 mode)
@@ -530,6 +530,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
   };
   if (r0 + wave < r1) fetch(r0 + wave);
+  float kq[4] = {1.f, 1.f, 1.f, 1.f};
+  // (pairs of slots exist when the row is an even number of full 256-column slots; the library-wide switch rides in the sign of rows_pb)
+  const bool pair_ok = (cols % 512) == 0 && nv <= LN_MAXV && pair_sw;
 #pragma unroll 1
   for (int row = r0 + wave; row < r1; row += 4) {
     const float mean = stn.x, rstd = stn.y;
@@ -574,9 +577,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     s1 = wave_sum(s1) / (float)cols;
     s2 = wave_sum(s2) / (float)cols;
+    // Dropout keep factors of the operand copy.  A lane owns 4 consecutive columns per slot, a Philox counter covers 8: lanes 2 k and
+    // 2 k + 1 would draw the same counter in every slot.  Round 6 (PAIRED: an even number of full slots): the even lane draws slot
+    // i's counter, the odd lane slot i + 1's, and the two trade the halves the other one owns (two DPP moves) - half the Philox
+    // calls at the end of the row's dependent chain.  Same counters, same words, same bits (TIMHIP_LN_PAIR=0: every lane draws).
+    const bool paired = LN_MAXV >= 2 && pair_ok && thr != 0u && dyt != nullptr;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
+      float kp[4] = {ts, ts, ts, ts};
+      if constexpr (LN_MAXV >= 2) {
+        if (paired && (i & 1) == 0) {
+          const int isel = i + (lane & 1);
+          const Philox4 r = philox4x32_7(seed, site, ((uint64_t)row * cols + (uint64_t)((isel * 64 + (lane & ~1)) * 4)) >> 3);
+          const bool odd = (lane & 1) != 0;
+          const uint32_t sa = odd ? r.x : r.z, sb = odd ? r.y : r.w;       // what the partner owns of my counter
+          const uint32_t pa = (uint32_t)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+          const uint32_t pb = (uint32_t)__builtin_amdgcn_mov_dpp((int)sb, 0xB1, 0xF, 0xF, true);
+          // slot i: even lane its own (x, y), odd lane the even lane's (z, w); slot i + 1: even lane the odd lane's (x, y), odd its own (z, w)
+          drop_mask4_words(odd ? pa : r.x, odd ? pb : r.y, thr, scale, kp[0], kp[1], kp[2], kp[3]);
+          drop_mask4_words(odd ? r.z : pa, odd ? r.w : pb, thr, scale, kq[0], kq[1], kq[2], kq[3]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { kp[u] *= ts; kq[u] *= ts; }
+        } else if (paired) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) kp[u] = kq[u];
+        }
+      }
       if (i < nv && c < cols) {
         float o0 = rstd * (d[i].x - s1 - xh[i].x * s2), o1 = rstd * (d[i].y - s1 - xh[i].y * s2);
         float o2 = rstd * (d[i].z - s1 - xh[i].z * s2), o3 = rstd * (d[i].w - s1 - xh[i].w * s2);
@@ -587,8 +614,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           if (dyf) store4<float>(dyf + (size_t)row * lddy + c, o0, o1, o2, o3);
         }
         if (dyt) {
-          float k0 = ts, k1 = ts, k2 = ts, k3 = ts;
-          if (thr != 0u) {
+          float k0 = kp[0], k1 = kp[1], k2 = kp[2], k3 = kp[3];
+          if (thr != 0u && !paired) {
             drop_mask4(seed, site, ((uint64_t)row * cols + c) >> 2, thr, scale, k0, k1, k2, k3);
             k0 *= ts; k1 *= ts; k2 *= ts; k3 *= ts;
           }
@@ -1325,16 +1352,17 @@ int tim_layernorm_bwd(int precision, const float* dx, int lddx, const float* y, 
   const size_t shmem = (size_t)4 * 2 * cols * sizeof(float);
   const uint32_t thr = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const int pair_sw = tim_knobs().ln_pair;
 #define LN_BWD(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
-                                   (const T*)addt, ldadd, add_scale, sp)
+                                   (const T*)addt, ldadd, add_scale, sp, pair_sw)
   const int nv = (cols + 255) / 256;
 #define LN_BWD0(NV) hipLaunchKernelGGL((ln_bwd_kernel<T, NV, true>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (T*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
-                                   (const T*)addt, ldadd, add_scale, sp)
+                                   (const T*)addt, ldadd, add_scale, sp, pair_sw)
 #define LN_BWD16(NV, SV) hipLaunchKernelGGL((ln_bwd_kernel<HT, NV, true, SV>), grid, dim3(256), shmem, s, dx, lddx, y, ldy, stats, rows, \
                                    cols, act, w, dyf, lddy, (HT*)dyt, ldt, thr, scale, seed, site, dgamma, dbeta, rpb, partial_ws, t_scale, \
-                                   (const HT*)addt, ldadd, add_scale, sp)
+                                   (const HT*)addt, ldadd, add_scale, sp, pair_sw)
 #define LN_BWD16_NV(SV) do { if (nv <= 1) LN_BWD16(1, SV); else if (nv <= 2) LN_BWD16(2, SV); else if (nv <= 4) LN_BWD16(4, SV); else LN_BWD16(8, SV); } while (0)
   if (stream16) {
     DISPATCH_H16(precision, { if (stream16 == 1) LN_BWD16_NV(1); else if (stream16 == 2) LN_BWD16_NV(2); else LN_BWD16_NV(3); });

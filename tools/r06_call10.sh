@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 6, GPU call 10: dropout + residual NT epilogue with lane pairs sharing their Philox calls (TIMHIP_EPI_PAIR): tests + A/B
+TAG=${1:-r06j}
+OUT=/root/repo/gpurun_out/$TAG
+mkdir -p $OUT
+cd /root/repo
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_train_parity.py -x -q -k "pingpong or eight_phase or train_mode or operating_points or keep_bits or layer" > $OUT/pytest_subset.log 2>&1
+tail -2 $OUT/pytest_subset.log
+for P in 1 0 1 0 1 0; do
+  TIMHIP_EPI_PAIR=$P timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-per-shape --steps 20 --warmup 5 > $OUT/bench_epipair_${P}_$RANDOM.json 2> /dev/null
+done
+TAG=$TAG python - <<'PY'
+import json, os, glob
+for f in sorted(glob.glob("/root/repo/gpurun_out/%s/bench_epipair_*.json" % os.environ["TAG"])):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(os.path.basename(f), d["ms_per_step"], d["repeat_ms"], d["roofline"]["frac"], d["forward_only"]["ms_per_step"])
+    except Exception as e:
+        print(f, "failed", e)
+PY
+VARIANTS="pair:TIMHIP_EPI_PAIR=1;own:TIMHIP_EPI_PAIR=0" timeout 600 python tools/nt_env_ab.py 2>&1 | grep -E "out_proj fwd|ffn2 fwd|layer total"
