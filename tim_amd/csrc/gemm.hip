@@ -324,8 +324,11 @@ __device__ __forceinline__ void gemm_nt_h16_body(
         }
       }
     } else {
-#pragma unroll
-      for (int it = 0; it < 32 * CPR / 64; ++it) {
+      // (round 6, as in gemm_pp.hip's pp_epilogue: the dropout + residual epilogue's lane pairs share the Philox calls of two quads)
+      constexpr int NITQ_ = 32 * CPR / 64;
+      bool has_k = false;
+      if constexpr (EPI == TIMHIP_EPI_DROP_RES_F32 && (NITQ_ % 2) == 0) has_k = e.thr != 0u && !e.mask && e.vec && (N & 7) == 0 && e.pair;
+      auto quad = [&](int it, bool hk, float4 kf) {
         const int idx = it * 64 + lane;
         const int row = idx / CPR, ch = idx % CPR;
         const float4 v = *reinterpret_cast<const float4*>(ep + row * EP_LD + ch * 4);
@@ -334,7 +337,29 @@ __device__ __forceinline__ void gemm_nt_h16_body(
         if (m < M && n < N)
           epi_quad<EPI, HT>(e, m, n, N, v.x, v.y, v.z, v.w, pre_res && n + 3 < N, rbuf[j % PD][PRE_RES ? it : 0],
                                 pre_b4 && n + 3 < N, bias4, pre_ln && pre_gb && n + 3 < N, sbuf[j % PD][PRE_RES ? it : 0],
-                                lng, lnb);
+                                lng, lnb, hk, kf);
+      };
+      if (has_k) {
+        if constexpr ((NITQ_ % 2) == 0) {
+#pragma unroll
+          for (int it = 0; it < NITQ_; it += 2) {
+            const int idx = (it + (lane & 1)) * 64 + (lane & ~1);
+            const long long m_ = m0 + wm * (BM / WM) + j * 32 + idx / CPR, n_ = n0 + wn * (BN / WN) + (idx % CPR) * 4;
+            const Philox4 r = philox4x32_7(e.seed, e.site, (uint64_t)(m_ * (long long)N + n_) >> 3);
+            const bool odd = (lane & 1) != 0;
+            const uint32_t sa = odd ? r.x : r.z, sb = odd ? r.y : r.w;
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_mov_dpp((int)sa, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_mov_dpp((int)sb, 0xB1, 0xF, 0xF, true);
+            float4 ka, kb;
+            drop_mask4_words(odd ? pa : r.x, odd ? pb : r.y, e.thr, e.scale, ka.x, ka.y, ka.z, ka.w);
+            drop_mask4_words(odd ? r.z : pa, odd ? r.w : pb, e.thr, e.scale, kb.x, kb.y, kb.z, kb.w);
+            quad(it, true, ka);
+            quad(it + 1, true, kb);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < NITQ_; ++it) quad(it, false, make_float4(1.f, 1.f, 1.f, 1.f));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block of rows overwrites
