@@ -591,12 +591,20 @@ __global__ __launch_bounds__(256) void attn_keep_bits_kernel(KeepBitsArgs k) {
   if (row >= k.rows) return;
   const uint64_t c0 = (uint64_t)row * (uint64_t)k.lp8;
   const uint32_t site = k.site[blockIdx.y];
-  unsigned long long w0 = 0ull, w1 = 0ull;
-  for (int c = 0; c < k.nc; ++c) {
-    const uint32_t bits = drop_bits8(k.seed, site, c0 + (uint64_t)c, k.thr);
-    w0 |= (unsigned long long)(bits & 15u) << (4 * c);
-    w1 |= (unsigned long long)(bits >> 4) << (4 * c);
+  // (unrolled over the 16 possible counters: a thread's draws are independent, and a runtime-bounded loop ran their 7-round
+  //  dependency chains one after the other - 16 us for 6.2 M calls where the vector pipes need 6; the two 32-bit halves of a word
+  //  are built separately: no 64-bit shifts)
+  const uint64_t seed = k.seed;
+  uint32_t lo0 = 0u, hi0 = 0u, lo1 = 0u, hi1 = 0u;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c < k.nc) {
+      const uint32_t bits = drop_bits8(seed, site, c0 + (uint64_t)c, k.thr);
+      if (c < 8) { lo0 |= (bits & 15u) << (4 * c); lo1 |= (bits >> 4) << (4 * c); }
+      else { hi0 |= (bits & 15u) << (4 * (c - 8)); hi1 |= (bits >> 4) << (4 * (c - 8)); }
+    }
   }
+  const unsigned long long w0 = ((unsigned long long)hi0 << 32) | lo0, w1 = ((unsigned long long)hi1 << 32) | lo1;
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   u64x2 v; v[0] = w0; v[1] = w1;
   *reinterpret_cast<u64x2*>(k.out[blockIdx.y] + 2 * (size_t)row) = v;
