@@ -425,6 +425,16 @@ int timhip_layer_bwd_data(const TimDesc* d, const TimLayerParams* w, const void*
 int timhip_layer_bwd_weights(const TimDesc* d, const void* x_in_T, const void* saved, const void* dy,
                              const TimLayerGrads* g, void* workspace, size_t workspace_bytes,
                              void* stream);
+/* Round 6: the weight gradients of TWO layers (a, b: the arguments of timhip_layer_bwd_weights for each) as one grouped launch.
+ * A C2a layer's four products (transformers.py:73,102,107 under autograd) are 128 tiles of 256 x 256: two layers fill the 256
+ * CUs with one tile each, every block running the whole contraction.  timhip_layer_wgrad_pair_wins(d) = 1 when that is the
+ * case for this descriptor - then a host defers a layer's weight gradients until its neighbour's data chain has run (each
+ * layer's `dy` block and saved activations stay untouched until the pair call) - 0 otherwise (pairing gains nothing; the pair
+ * call may then return TIMHIP_EWORKSPACE, its workspace being sized for one layer). */
+int timhip_layer_bwd_weights_pair(const TimDesc* d, const void* x_in_T_a, const void* saved_a, const void* dy_a,
+                                  const TimLayerGrads* ga, const void* x_in_T_b, const void* saved_b, const void* dy_b,
+                                  const TimLayerGrads* gb, void* workspace, size_t workspace_bytes, void* stream);
+int timhip_layer_wgrad_pair_wins(const TimDesc* d);
 
 /* Split gradient stream between layers (optional, what tim_amd/functional.py uses inside the stack).  The gradient of a layer
  * boundary travels as an fp32 part plus an operand-dtype part: dx = dx_f32 + (1/S) * dx_add, S the fp16 gradient scale of

@@ -302,6 +302,45 @@ def test_wgrad_group(M, shapes, accumulate, prec, loaders, knobs):
             assert (db.cpu().double() - rb).abs().max().item() <= 2e-5 * max(1.0, rb.abs().max().item()) + 1e-4
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("M", [2048, 9920])
+def test_wgrad_group_eight_phase(M, accumulate, prec, knobs):
+    """round 6: the weight gradients of TWO encoder layers as one round of 256 x 256 eight-phase tiles (wgrad_p8_kernel) == the
+    per-product reference, == the one-block-per-CU kernel's results bit for bit in its biases' tolerance; TIMHIP_WGRAD_P8=0
+    sends the same group through the 128 x 256 kernel"""
+    rt = Runtime(prec)
+    shapes = [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)] * 2
+    items, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dY, dYr = to_op(rt, rnd(M, N, seed=120 + i) * 0.25)
+        X, Xr = to_op(rt, rnd(M, K, seed=140 + i) * 0.25)
+        dW = torch.full((N, K), 0.5, device=DEV)
+        db = None if i == 5 else torch.full((N,), 0.5, device=DEV)
+        items.append((dY, N, X, K, dW, db))
+        base = 0.5 if accumulate else 0.0
+        refs.append((base + dYr.to(DEV).double().t() @ Xr.to(DEV).double(), base + dYr.double().sum(0)))
+    rt.wgrad_group(items, M, accumulate=accumulate)
+    torch.cuda.synchronize()
+    got = [(dW.clone(), None if db is None else db.clone()) for (_, _, _, _, dW, db) in items]
+    for (dW, db), (rw, rb) in zip(got, refs):
+        assert (dW.double() - rw).abs().max().item() <= 2e-5 * max(1.0, rw.abs().max().item()) * (M / 512) ** 0.5 + 1e-4
+        if db is not None:
+            assert (db.cpu().double() - rb).abs().max().item() <= 2e-5 * max(1.0, rb.abs().max().item()) + 1e-4
+    # the same group through the 128 x 256 kernel: same products, another summation order inside the MFMA chain only
+    knobs(TIMHIP_WGRAD_P8="0")
+    for (_, _, _, _, dW, db) in items:
+        dW.fill_(0.5)
+        if db is not None:
+            db.fill_(0.5)
+    rt.wgrad_group(items, M, accumulate=accumulate)
+    torch.cuda.synchronize()
+    for (dW0, db0), (_, _, _, _, dW, db) in zip(got, items):
+        assert (dW0 - dW).abs().max().item() <= 1e-4 * max(1.0, dW.abs().max().item())
+        if db is not None:
+            assert (db0 - db).abs().max().item() <= 1e-4 * max(1.0, db.abs().max().item())
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("cols,act", [(1024, 0), (512, 2), (64, 1), (32, 2), (256, 0)])
 def test_layernorm_fwd_bwd(prec, cols, act):

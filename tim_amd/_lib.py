@@ -122,6 +122,9 @@ _SIGS = {
     "timhip_layer_bwd_data": (C.c_int, [C.POINTER(TimDesc), C.POINTER(TimLayerParams), vp, vp, vp, vp,
                                         C.POINTER(TimLayerGrads), vp, sz, vp]),
     "timhip_layer_bwd_weights": (C.c_int, [C.POINTER(TimDesc), vp, vp, vp, C.POINTER(TimLayerGrads), vp, sz, vp]),
+    "timhip_layer_bwd_weights_pair": (C.c_int, [C.POINTER(TimDesc), vp, vp, vp, C.POINTER(TimLayerGrads), vp, vp, vp,
+                                                C.POINTER(TimLayerGrads), vp, sz, vp]),
+    "timhip_layer_wgrad_pair_wins": (C.c_int, [C.POINTER(TimDesc)]),
     "timhip_assemble_fwd": (C.c_int, [i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, f32, u64, u32,
                                       vp, vp, vp]),
     "timhip_assemble_bwd": (C.c_int, [vp, i32, i32, i32, vp, i32, i32, f32, u64, u32, vp, vp, vp, vp, vp, vp]),

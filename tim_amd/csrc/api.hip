@@ -162,6 +162,7 @@ void read_knobs(TimKnobs& k) {
   k.gemm_dg = env_int("TIMHIP_GEMM_DG", 0); k.gemm_dg_offset = env_int("TIMHIP_GEMM_DG_OFFSET", 9);
   k.fuse_ln = env_int("TIMHIP_FUSE_LN", 0); k.fuse_ln_spin = env_int("TIMHIP_FUSE_LN_SPIN", 100000);
   k.wgrad_pp = env_int("TIMHIP_WGRAD_PP", 1); k.wgrad_ld = env_int("TIMHIP_WGRAD_LD", 1); k.wgrad_pf = env_int("TIMHIP_WGRAD_PF", 4);
+  k.wgrad_p8 = env_int("TIMHIP_WGRAD_P8", 1);
   k.attn_waves = env_int("TIMHIP_ATTN_WAVES", 0); k.attn_fused = env_int("TIMHIP_ATTN_FUSED", 1);
   k.ln_rpb = env_int("TIMHIP_LN_RPB", 0);
   k.gemm_tmw = env_int("TIMHIP_GEMM_TMW", 0);
@@ -549,6 +550,55 @@ int timhip_layer_bwd_weights(const TimDesc* dp, const void* x_in_T, const void* 
   if ((rc = wgrad(prec, yb + Y.du, FF, FF, sv + L.x1t, E, E, M, g->l1_w, g->l1_b, workspace, workspace_bytes, s, acc, gs_out))) return rc;
   if ((rc = wgrad(prec, yb + Y.da, E, E, sv + L.o, E, E, M, g->out_w, g->out_b, workspace, workspace_bytes, s, acc, gs_out))) return rc;
   return wgrad(prec, yb + Y.dqkv, 3 * E, 3 * E, x_in_T, E, E, M, g->in_w, g->in_b, workspace, workspace_bytes, s, acc, gs_out);
+}
+
+// The weight gradients of TWO layers in one grouped launch (round 6): at production batch sizes the eight products are 256 tiles of
+// 256 x 256 for the eight-phase kernel (wgrad_pp.hip: wgrad_p8_kernel), one per CU; any other shape takes the grouped kernels the
+// single-layer call takes (then as two rounds).  a / b: the arguments of timhip_layer_bwd_weights for the two layers (same
+// descriptor but for `layer`, which only names the dropout sites and is not read here).
+int timhip_layer_bwd_weights_pair(const TimDesc* dp, const void* x_in_T_a, const void* saved_a, const void* dy_a, const TimLayerGrads* ga,
+                                  const void* x_in_T_b, const void* saved_b, const void* dy_b, const TimLayerGrads* gb,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dp || !x_in_T_a || !saved_a || !dy_a || !ga || !x_in_T_b || !saved_b || !dy_b || !gb || !workspace) return TIMHIP_EINVAL;
+  const TimDesc& d = *dp;
+  int rc = check_layer_desc(d);
+  if (rc) return rc;
+  const int M = d.B * d.S, E = d.E, FF = d.FF, prec = d.precision;
+  if (!h16_storage(prec) || (d.reserved & TIMHIP_DESC_WGRAD_SEPARATE) || ((size_t)E * E) % 4 || ((size_t)E * FF) % 4) return TIMHIP_EUNSUPPORTED;
+  const SavedLayout L = saved_layout(d);
+  const DyLayout Y = dy_layout(d);
+  const int acc = (d.reserved & TIMHIP_DESC_WGRAD_OVERWRITE) ? 0 : 1;
+  const float* gs_out = (prec == TIMHIP_PREC_F16 && d.grad_scale) ? d.grad_scale + 1 : nullptr;
+  TimWgradItem it[8];
+  const void* xs[2] = {x_in_T_a, x_in_T_b};
+  const char* svs[2] = {(const char*)saved_a, (const char*)saved_b};
+  const char* ybs[2] = {(const char*)dy_a, (const char*)dy_b};
+  const TimLayerGrads* gs[2] = {ga, gb};
+  for (int h = 0; h < 2; ++h) {
+    const char* sv = svs[h]; const char* yb = ybs[h]; const TimLayerGrads* g = gs[h];
+    it[4 * h + 0] = TimWgradItem{yb + Y.df, sv + L.h, g->l2_w, g->l2_b, E, FF, E, FF};
+    it[4 * h + 1] = TimWgradItem{yb + Y.du, sv + L.x1t, g->l1_w, g->l1_b, FF, E, FF, E};
+    it[4 * h + 2] = TimWgradItem{yb + Y.da, sv + L.o, g->out_w, g->out_b, E, E, E, E};
+    it[4 * h + 3] = TimWgradItem{yb + Y.dqkv, xs[h], g->in_w, g->in_b, 3 * E, E, 3 * E, E};
+  }
+  return tim_wgrad_group_h16(prec, it, 8, M, acc, workspace, workspace_bytes, gs_out, (hipStream_t)stream);
+}
+
+// 1: timhip_layer_bwd_weights_pair runs this descriptor's two layers as ONE round of eight-phase tiles (hosts defer a layer's
+// weight gradients to its neighbour's only then); 0: no gain from pairing
+int timhip_layer_wgrad_pair_wins(const TimDesc* dp) {
+  if (!dp || check_layer_desc(*dp)) return 0;
+  const TimDesc& d = *dp;
+  if (!h16_storage(d.precision) || (d.reserved & TIMHIP_DESC_WGRAD_SEPARATE)) return 0;
+  const int E = d.E, FF = d.FF;
+  TimWgradItem it[8];
+  for (int h = 0; h < 2; ++h) {
+    it[4 * h + 0] = TimWgradItem{nullptr, nullptr, nullptr, nullptr, E, FF, E, FF};
+    it[4 * h + 1] = TimWgradItem{nullptr, nullptr, nullptr, nullptr, FF, E, FF, E};
+    it[4 * h + 2] = TimWgradItem{nullptr, nullptr, nullptr, nullptr, E, E, E, E};
+    it[4 * h + 3] = TimWgradItem{nullptr, nullptr, nullptr, nullptr, 3 * E, E, 3 * E, E};
+  }
+  return tim_wgrad_p8_wins(it, 8, d.B * d.S) ? 1 : 0;
 }
 
 // single-stream form: data chain followed by the weight gradients

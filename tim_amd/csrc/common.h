@@ -288,6 +288,7 @@ struct TimKnobs {
   int wgrad_pp;       // TIMHIP_WGRAD_PP     0: no one-block-per-CU weight-gradient grid
   int wgrad_ld;       // TIMHIP_WGRAD_LD     0: its 8-wave merged-phase form
   int wgrad_pf;       // TIMHIP_WGRAD_PF     its L2 prefetch distance (default 4)
+  int wgrad_p8;       // TIMHIP_WGRAD_P8     0: no eight-phase 256 x 256 weight-gradient grid (two layers per launch)
   int attn_waves;     // TIMHIP_ATTN_WAVES   waves per attention block (0: by shape)
   int attn_fused;     // TIMHIP_ATTN_FUSED   0: two-kernel attention backward
   int ln_rpb;         // TIMHIP_LN_RPB       rows per LayerNorm-backward block (0: by shape)
@@ -445,6 +446,9 @@ int tim_wgrad_group_h16(int precision, const TimWgradItem* it, int n, int M, int
 // wgrad_pp.hip: the grouped weight gradients as one-block-per-CU ping-pong blocks (no split of the contraction, no workspace)
 bool tim_wgrad_pp_wins(const TimWgradItem* it, int n, int M);
 int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int accumulate, const float* out_scale, hipStream_t s);
+// its eight-phase form (256 x 256 tiles; wins for groups of whole rounds of 256 such tiles: two encoder layers at C2a)
+bool tim_wgrad_p8_wins(const TimWgradItem* it, int n, int M);
+int tim_wgrad_group_p8(int precision, const TimWgradItem* it, int n, int M, int accumulate, const float* out_scale, hipStream_t s);
 int tim_colsum(int precision, const void* src, int rows, int cols, int ld, float* out, hipStream_t s);
 // mask_out != NULL: additionally writes the dropout keep-bits of a [rows, mask_cols] site (1 bit per element, row stride
 // mask_cols / 8 bytes, element index r * mask_cols + c as in the GEMM epilogues) - see drop_bits32

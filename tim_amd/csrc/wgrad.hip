@@ -433,6 +433,13 @@ int tim_wgrad_group_h16(int precision, const TimWgradItem* it, int n, int M, int
                         const float* out_scale, hipStream_t s) {
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
   if (!it || n < 1 || n > WG_MAX || M <= 0) return TIMHIP_EINVAL;
+  // two encoder layers of a production batch: one round of eight-phase 256 x 256 tiles (wgrad_pp.hip; TIMHIP_WGRAD_P8=0: A/B switch)
+  if (tim_wgrad_p8_wins(it, n, M)) {
+    double fl = 0.0;
+    for (int i = 0; i < n; ++i) fl += 2.0 * M * it[i].Nout * it[i].Kout;
+    TimGemmScope timing(fl, s);
+    return tim_wgrad_group_p8(precision, it, n, M, accumulate, out_scale, s);
+  }
   // an encoder layer of a production batch: the one-block-per-CU ping-pong grid (wgrad_pp.hip; TIMHIP_WGRAD_PP=0: A/B switch)
   if (tim_knobs().wgrad_pp != 0 && tim_wgrad_pp_wins(it, n, M)) {
     double fl = 0.0;

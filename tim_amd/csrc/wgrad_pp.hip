@@ -27,6 +27,8 @@
 // Hazard bookkeeping of MODES 0 / 2: see gemm_pp.hip (identical phase structure); of the loader form: at wl_consume below.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "mfma_tiles.h"
 
@@ -744,6 +746,218 @@ __global__ __launch_bounds__(512) void wgrad_pp_kernel(const WpGroup g) {
   nf_commit(g.out_scale, chk);
 }
 
+
+// ---- eight-phase form (wgrad_p8_kernel, round 6): 256 (n) x 256 (k) tiles ---------------------------------------------------------
+// The 128 x 256 tile above multiplies with 64 x 64 wave tiles: one transposing fragment read per MFMA, and with the LDS-DMA
+// writes the LDS is busier than the matrix pipes (1.04 - 1.09 PFLOP/s; the NT kernels with 80 / 128 / 160 x 64 wave tiles reach
+// 1.31 / 1.36 / 1.44 at this contraction length - profiles/r06_n_p8_longk.txt).  Here the schedule of gemm_pp.hip's eight-phase
+// kernel on the weight-gradient operands:
+//   * 8 waves = 2 (n) x 4 (k), wave tile n 128 x k 64 (8 x 4 MFMA tiles, 128 accumulator registers, 0.75 reads per MFMA), no
+//     loader waves; every block runs the whole M.  A layer is 128 such tiles, so the caller hands over TWO layers per launch
+//     (timhip_layer_bwd_weights_pair: 256 tiles = one per CU);
+//   * a 64-row contraction step is four quadrant phases (n half, k half) = (0,0) (0,1) (1,1) (1,0), 16 MFMAs each; the stage is
+//     FOUR sub-tiles [64 m][128 columns] in wgrad_pp's format, one per quadrant operand, so that each can be restaged on its
+//     own: Y_q = the n columns {wr 128 + q 64 + c} of both wave rows, X_q = the k columns {wc 64 + q 32 + c} of the four wave
+//     columns (the LDS-DMA source side does the gather: 128- / 64-byte runs);
+//   * two stage buffers (128 KiB); restaging one phase after a sub-tile's last fragment read, as in p8_mainloop: phase 1: X_0 of
+//     step t + 1 -> other buffer; phases 2 / 3 / 4: Y_0 / X_1 / Y_1 of step t + 2 -> this buffer; one counted wait per step.
+// Hazards: gemm_pp.hip (identical segment structure).  Bias gradients: one ones-MFMA per wave and step, see the kernel.
+constexpr int W8_T = 256, W8_SUB = WP_M * 256, W8_STAGE = 4 * W8_SUB;
+struct W8Tab { uint32_t offY[2][2], offX[2][2]; };
+
+// ABL (tuning builds, tools/wg_pair_ab.py): timing-only ablations - 1: no bias MFMAs, 2: the X pieces gathered in 128-byte runs
+// like the Y pieces (wrong columns), 4: no stores of the result, 8: fragment reads only in the first step, 16: no DMA after the prologue
+template <typename HT, int G, int ABL = 0>
+__device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_t sy, size_t sx, int nk, const char* lds, uint32_t lds0,
+                                            const W8Tab& tb, int wave, const int (&yo)[2], const int (&xo)[2], bool bias_on,
+                                            const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb) {
+  const uint32_t pw = (uint32_t)(2 * wave) * 1024u;
+  auto stage_y = [&](int kt, uint32_t buf, int q) {
+    const void* g = uniform_ptr(dY + (size_t)kt * sy);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i], buf + q * W8_SUB + pw + i * 1024);
+  };
+  auto stage_x = [&](int kt, uint32_t buf, int q) {
+    const void* g = uniform_ptr(X + (size_t)kt * sx);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i], buf + (2 + q) * W8_SUB + pw + i * 1024);
+  };
+  stage_y(0, lds0, 0); stage_x(0, lds0, 0); stage_x(0, lds0, 1); stage_y(0, lds0, 1);
+  if (nk > 1) { stage_y(1, lds0 + W8_STAGE, 0); stage_x(1, lds0 + W8_STAGE, 0); stage_x(1, lds0 + W8_STAGE, 1); stage_y(1, lds0 + W8_STAGE, 1); }
+  glds_wait<0>();
+  wp_barrier();
+  if constexpr (G == 1) wp_barrier();   // one segment behind group 0 from here on
+
+  vec8<HT> yf[4][2], xf[2][2], ones, yb;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { ones[u] = (HT)1.f; yb[u] = (HT)0.f; }
+  auto read_y = [&](const char* bb, int q) {
+    const char* sY = bb + q * W8_SUB;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        yf[j][kh] = cat8<HT>(tr_read<HT>(sY + (yo[0] ^ (j << 5)) + kh * (32 * 256)), tr_read<HT>(sY + (yo[1] ^ (j << 5)) + kh * (32 * 256)));
+  };
+  auto read_x = [&](const char* bb, int q) {
+    const char* sX = bb + (2 + q) * W8_SUB;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        xf[i][kh] = cat8<HT>(tr_read<HT>(sX + (xo[0] ^ (i << 5)) + kh * (32 * 256)), tr_read<HT>(sX + (xo[1] ^ (i << 5)) + kh * (32 * 256)));
+  };
+  auto mma = [&](auto qn_c, auto qk_c) {
+    constexpr int qn = decltype(qn_c)::value, qk = decltype(qk_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[2 * qk + i][4 * qn + j] = mfma16x16<HT>(xf[i][kh], yf[j][kh], acc[2 * qk + i][4 * qn + j]);
+    if constexpr (qn == 0 && qk == 0) {   // phase 1: this wave's share of the bias gradient (one 32-row half of one dY tile)
+      if (!(ABL & 1) && bias_on) accb = mfma16x16<HT>(ones, yb, accb);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    const char* bb = lds + b * W8_STAGE;
+    const uint32_t cur = lds0 + b * W8_STAGE, oth = lds0 + (b ^ 1) * W8_STAGE;
+    const bool s1 = t >= 1 && t + 1 < nk && !(ABL & 16), s2 = t + 2 < nk && !(ABL & 16);
+    const bool rd = !(ABL & 8) || t == 0;
+    // phase 1: quadrant (n 0, k 0)
+    if (rd) { read_x(bb, 0); read_y(bb, 0); }
+    if (bias_on) yb = cat8<HT>(tr_read<HT>(bb + bo[0]), tr_read<HT>(bb + bo[1]));
+    if (s1) stage_x(t + 1, oth, 0);
+    wp_wait_lds(); wp_barrier();
+    mma(I0{}, I0{});
+    wp_barrier();
+    // phase 2: (n 0, k 1) - Y fragments kept
+    if (rd) read_x(bb, 1);
+    if (s2) stage_y(t + 2, cur, 0);
+    wp_wait_lds(); wp_barrier();
+    mma(I0{}, I1{});
+    wp_barrier();
+    // phase 3: (n 1, k 1) - X fragments kept
+    if (rd) read_y(bb, 1);
+    if (s2) stage_x(t + 2, cur, 1);
+    wp_wait_lds(); wp_barrier();
+    mma(I1{}, I1{});
+    wp_barrier();
+    // phase 4: (n 1, k 0) - Y fragments kept; the step's one counted wait: X_0 of step t + 1 (and everything older) has landed
+    if (rd) read_x(bb, 0);
+    if (s2) { stage_y(t + 2, cur, 1); glds_wait<6>(); } else { glds_wait<0>(); }
+    wp_wait_lds(); wp_barrier();
+    mma(I1{}, I0{});
+    wp_barrier();
+  }
+  if constexpr (G == 0) wp_barrier();   // as many barriers as group 1
+}
+
+template <typename HT, int ABL = 0>
+__global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][Y_0 | Y_1 | X_0 | X_1], 16 KiB each
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = xcd_remap_wp(blockIdx.x, gridDim.x);
+  const char* pY = nullptr; const char* pX = nullptr;
+  int ldy = 0, ldx = 0, N = 0, K = 0, tl = t, tiles_k = 1;
+  float* dW = nullptr;
+  float* db = nullptr;
+#pragma unroll
+  for (int i = 0; i < WP_MAX; ++i) {   // static indexing of the kernel-argument arrays (uniform select)
+    if (i < g.n && t >= g.tile0[i]) {
+      pY = (const char*)g.dY[i]; pX = (const char*)g.X[i]; ldy = g.ldy[i]; ldx = g.ldx[i]; N = g.N[i]; K = g.K[i];
+      tl = t - g.tile0[i]; tiles_k = g.K[i] / W8_T;
+      dW = g.dW[i]; db = g.db[i];
+    }
+  }
+  const int n0 = (tl / tiles_k) * W8_T, k0 = (tl % tiles_k) * W8_T;   // k-tile fastest: consecutive blocks share the dY panel
+  const int wr = wave >> 2, wc = wave & 3;
+  const int gid = lane >> 4, p = lane & 15;
+  // this wave's two LDS-DMA pieces (1 KiB = 4 rows x 256 B) of every sub-tile: rows 8 wave .. 8 wave + 7; lane -> (row, 16-byte
+  // chunk), the chunk swizzled and the columns gathered on the SOURCE side
+  W8Tab tb;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (2 * wave + i) * 4 + gid, c = p ^ swz<128>(row);
+      tb.offY[q][i] = (uint32_t)(((size_t)row * ldy + n0 + (c >> 3) * 128 + q * 64 + (c & 7) * 8) * 2);
+      tb.offX[q][i] = (ABL & 2) ? (uint32_t)(((size_t)row * ldx + k0 + (c >> 3) * 128 + q * 64 + (c & 7) * 8) * 2)
+                                : (uint32_t)(((size_t)row * ldx + k0 + (c >> 2) * 64 + q * 32 + (c & 3) * 8) * 2);
+    }
+  // transposing reads: lane (gid, p) addresses row 8 gid + 4 r + (p >> 2) (r = 0, 1: the two reads of a fragment), the 4 columns
+  // 4 (p & 3) .. + 3 of MFMA tile 0 of the wave's columns in the sub-tile; tile i is at (offset ^ (i << 5))
+  int yo[2], xo[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = 8 * gid + 4 * r + (p >> 2);
+    yo[r] = tile_off<128>(row, wr * 8 + ((p & 3) >> 1)) + (p & 1) * 8;
+    xo[r] = tile_off<128>(row, wc * 4 + ((p & 3) >> 1)) + (p & 1) * 8;
+  }
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // bias gradient: the 16 dY tiles of 16 columns this n-row of tiles has in LDS are split between its tiles_k blocks (block kt:
+  // tiles [16 kt / tiles_k, 16 (kt + 1) / tiles_k)), and a block's tiles x two 32-row halves between its waves - one ones-MFMA per
+  // wave and step in phase 1 (both Y sub-tiles of the step are resident there), the two halves added through LDS at the end in a
+  // fixed order.  (As two tiles per wave of the k0 = 0 blocks only, those blocks - and with them the launch - ran 6 % longer.)
+  f32x4_t accb = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int kt = tl % tiles_k, bc0 = 16 * kt / tiles_k, bc1 = 16 * (kt + 1) / tiles_k;
+  const int bcol = bc0 + (wave >> 1), bkh = wave & 1;
+  const bool bias_on = db != nullptr && bcol < bc1;
+  int bo[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = 8 * gid + 4 * r + (p >> 2);
+    bo[r] = ((bcol >> 2) & 1) * W8_SUB + bkh * (32 * 256) + tile_off<128>(row, (bcol >> 3) * 8 + (bcol & 3) * 2 + ((p & 3) >> 1)) + (p & 1) * 8;
+  }
+  const int nk = g.M / WP_M;
+  const size_t sy = (size_t)WP_M * ldy * 2, sx = (size_t)WP_M * ldx * 2;
+  if (wr == 0) w8_mainloop<HT, 0, ABL>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+  else w8_mainloop<HT, 1, ABL>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+
+  // D[row = k: 4 gid + r][col = n: p] per MFMA tile (i: k tile, j: n tile): a lane owns 4 consecutive k of one row n of dW
+  const float alpha = g.out_scale ? *g.out_scale : 1.f;
+  float chk = 0.f;
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = n0 + wr * 128 + j * 16 + p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + wc * 64 + i * 16 + 4 * gid;
+      f4_t o = {acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha};
+      nf_note(chk, o[0]); nf_note(chk, o[1]); nf_note(chk, o[2]); nf_note(chk, o[3]);
+      f4_t* dst = reinterpret_cast<f4_t*>(dW + (size_t)n * K + k);
+      if (g.accumulate) o += *dst;
+      if (!(ABL & 4) || o[0] == 12345.678f) __builtin_nontemporal_store(o, dst);   // (streaming: see wgrad_ld_kernel)
+    }
+  }
+  if (db != nullptr) {   // (block-uniform) every row of the ones-product holds the column sums: take row 0; halves added in LDS
+    __syncthreads();     // every wave is done with the stage buffers
+    float* red = reinterpret_cast<float*>(lds);
+    if (bias_on && gid == 0) red[wave * 16 + p] = accb[0];
+    __syncthreads();
+    if (bias_on && gid == 0 && bkh == 0) {
+      const int n = n0 + bcol * 16 + p;
+      const float s = (red[wave * 16 + p] + red[(wave + 1) * 16 + p]) * alpha;
+      db[n] = g.accumulate ? db[n] + s : s;
+    }
+  }
+  nf_commit(g.out_scale, chk);
+  (void)N;
+}
+
 }  // namespace
 
 // Does the ping-pong grid suit this group?  Its blocks run the whole contraction (no split), one per CU: it needs about a
@@ -804,5 +1018,53 @@ int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int 
   } else {
     DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_pp_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
   }
+  return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+}
+
+// Does the eight-phase grid suit this group?  Whole 256 x 256 tiles, a contraction of whole 64-row steps, and rounds of 256
+// tiles filled to 90 %: at C2a that is the eight gradients of TWO encoder layers (TIMHIP_WGRAD_P8=0: off).
+bool tim_wgrad_p8_wins(const TimWgradItem* it, int n, int M) {
+  if (tim_knobs().wgrad_p8 == 0 || !it || n < 1 || n > WP_MAX || M < 2048 || (M % WP_M)) return false;
+  long long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (it[i].Nout % W8_T || it[i].Kout % W8_T || it[i].Nout <= 0 || it[i].Kout < 4 * W8_T) return false;   // (>= 4 k tiles: one bias MFMA per wave)
+    tiles += (long long)(it[i].Nout / W8_T) * (it[i].Kout / W8_T);
+  }
+  const long long rounds = (tiles + 255) / 256;
+  return tiles * 100 >= rounds * 256 * 90;
+}
+
+int tim_wgrad_group_p8(int precision, const TimWgradItem* it, int n, int M, int accumulate, const float* out_scale, hipStream_t s) {
+  if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
+  if (!it || n < 1 || n > WP_MAX || M < WP_M || (M % WP_M)) return TIMHIP_EINVAL;
+  WpGroup g;
+  g.n = n; g.M = M; g.accumulate = accumulate ? 1 : 0; g.out_scale = out_scale; g.pf_dist = 0;
+  g.tile0[0] = 0;
+  for (int i = 0; i < WP_MAX; ++i) {
+    if (i >= n) {
+      g.dY[i] = g.X[i] = nullptr; g.dW[i] = g.db[i] = nullptr; g.ldy[i] = g.ldx[i] = g.N[i] = g.K[i] = 0; g.tile0[i + 1] = g.tile0[i];
+      continue;
+    }
+    const TimWgradItem& t = it[i];
+    if (!t.dY || !t.X || !t.dW || t.Nout <= 0 || t.Kout < 4 * W8_T || t.Nout % W8_T || t.Kout % W8_T) return TIMHIP_EINVAL;
+    if ((t.ldy % 8) || (t.ldx % 8) || (((uintptr_t)t.dY | (uintptr_t)t.X | (uintptr_t)t.dW) & 15)) return TIMHIP_EALIGN;
+    if ((size_t)M * t.ldy * 2 >= (1ull << 32) || (size_t)M * t.ldx * 2 >= (1ull << 32)) return TIMHIP_EUNSUPPORTED;
+    g.dY[i] = t.dY; g.X[i] = t.X; g.dW[i] = t.dW; g.db[i] = t.db; g.ldy[i] = t.ldy; g.ldx[i] = t.ldx; g.N[i] = t.Nout; g.K[i] = t.Kout;
+    g.tile0[i + 1] = g.tile0[i] + (t.Nout / W8_T) * (t.Kout / W8_T);
+  }
+  const size_t shmem = (size_t)2 * W8_STAGE;
+  static PerDeviceOnce attr_set[2];
+  const int hi = precision == TIMHIP_PREC_F16 ? 1 : 0;
+  if (attr_set[hi].first())
+    DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_p8_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+#ifdef TIMHIP_TUNING
+  if (const char* v = getenv("TIMHIP_W8_ABL")) {
+#define W8A(X) case X: (void)hipFuncSetAttribute((const void*)wgrad_p8_kernel<f16_t, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((wgrad_p8_kernel<f16_t, X>), dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g); return TIMHIP_OK;
+    switch (atoi(v)) { W8A(1) W8A(2) W8A(4) W8A(8) W8A(16) W8A(24) W8A(7) default: break; }
+#undef W8A
+  }
+#endif
+  DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_p8_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }

@@ -1028,6 +1028,19 @@ class EncoderFn(torch.autograd.Function):
         else:
             ws_bytes = lib.timhip_layer_workspace_bytes(C.byref(desc))
             ws = model._workspace(ws_bytes, dev)
+        # round 6: where two layers' weight gradients are ONE round of eight-phase tiles (timhip_layer_wgrad_pair_wins: C2a at
+        # production batch sizes), a layer's weight gradients wait for its neighbour's data chain and the pair goes out as one
+        # launch on the same stream; each layer of a pair keeps its own `dy` block (TIM_AMD_WGRAD_PAIR=0: A/B switch)
+        pair = (not overlap and Lyr >= 2 and os.environ.get("TIM_AMD_WGRAD_PAIR", "1") != "0"
+                and lib.timhip_layer_wgrad_pair_wins(C.byref(desc)) == 1)
+        pending = None
+        if pair:
+            dws_bytes = lib.timhip_layer_data_workspace_bytes(C.byref(desc))
+            wws_bytes = lib.timhip_layer_wgrad_workspace_bytes(C.byref(desc))
+            dy_bytes = lib.timhip_layer_dy_bytes(C.byref(desc))
+            ws = model._workspace(dws_bytes, dev)
+            wws = model._workspace(wws_bytes, dev, slot="wgrad")
+            dys = [model._workspace(dy_bytes, dev, slot="dy0"), model._workspace(dy_bytes, dev, slot="dy1")]
         # LayerNorm dgamma / dbeta: every layer leaves per-block partials, one launch reduces them all at the end - unless a
         # data-parallel hook takes each layer's bucket as soon as the layer is done (then the layer call reduces its own)
         defer_ln = rt.bucket_hook is None and os.environ.get("TIM_AMD_NO_DEFER_LN", "0") != "1"   # (env: A/B switch)
@@ -1068,6 +1081,27 @@ class EncoderFn(torch.autograd.Function):
                 done[l] = dn
                 keep_alive.append(ctx.layer_saved[l])
                 grads.done("layer%d" % l, ready=dn)
+            elif pair:
+                dyb = dys[l & 1]
+                add_out = dxa[l & 1] if l > 0 else None
+                s_in, s_out = _stream16_io(l)
+                call("timhip_layer_bwd_data_split", C.byref(desc), C.byref(ctx.lparams[l][0]), ptr(ctx.layer_saved[l]),
+                     ptr(s_in), ptr(add_in), ptr(s_out), ptr(add_out), ptr(dyb), C.byref(lg), ptr(ws), dws_bytes, st)
+                add_in = add_out
+                if pending is None and l > 0:
+                    pending = (l, lg)      # its weight gradients go out with layer l - 1's
+                elif pending is not None:
+                    lp, lgp = pending
+                    call("timhip_layer_bwd_weights_pair", C.byref(desc), ptr(ctx.xs_t[lp]), ptr(ctx.layer_saved[lp]), ptr(dys[lp & 1]),
+                         C.byref(lgp), ptr(ctx.xs_t[l]), ptr(ctx.layer_saved[l]), ptr(dyb), C.byref(lg), ptr(wws), wws_bytes, st)
+                    grads.done("layer%d" % lp)
+                    grads.done("layer%d" % l)
+                    ctx.layer_saved[lp] = None
+                    pending = None
+                else:                      # an odd layer count: layer 0 on its own
+                    call("timhip_layer_bwd_weights", C.byref(desc), ptr(ctx.xs_t[l]), ptr(ctx.layer_saved[l]), ptr(dyb),
+                         C.byref(lg), ptr(wws), wws_bytes, st)
+                    grads.done("layer%d" % l)
             else:
                 add_out = dxa[l & 1] if l > 0 else None
                 s_in, s_out = _stream16_io(l)
@@ -1076,7 +1110,8 @@ class EncoderFn(torch.autograd.Function):
                 add_in = add_out
                 grads.done("layer%d" % l)
             dx, dx2 = dx2, dx
-            ctx.layer_saved[l] = None
+            if pending is None or pending[0] != l:
+                ctx.layer_saved[l] = None
 
         # LayerNorm parameter gradients of all layers: one reduction of the saved per-block partials (sets: norm2, norm1 per layer)
         dgs, dbs = [], []
