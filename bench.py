@@ -877,11 +877,22 @@ def main():
               (FF_, E_, 4 * FF_), (E_, FF_, 2 * E_), (E_, E_, 2 * E_), (E_, 3 * E_, 2 * E_)]                       # input gradients
         alg_nt = [M_ * k * 2 + n * k * 2 + M_ * ob for n, k, ob in nt]
         alg_tn = M_ * (E_ + FF_ + E_ + 3 * E_) * 2 + M_ * (FF_ + E_ + E_ + E_) * 2 + (2 * E_ * FF_ + 4 * E_ * E_) * 4
-        alg_avg = (sum(alg_nt) + alg_tn) / 9.0
+        # round 6: where the weight gradients of TWO layers go out as one launch (wgrad_p8_kernel, timhip_layer_bwd_weights_pair) the
+        # family is 16 NT + 1 TN launch per pair of layers: 51 launches of the 6-layer stack instead of 54
+        paired_tn = False
+        try:
+            import ctypes as _C
+            from tim_amd import _lib as L_
+            _d = L_.TimDesc(B, S_, cfg.F, cfg.d_model, E_, cfg.nhead, FF_, model.rt.prec, 0.1, 0, 0, 0, None)
+            paired_tn = (cfg.num_layers >= 2 and not model.rt.overlap_wgrad and os.environ.get("TIM_AMD_WGRAD_PAIR", "1") != "0"
+                         and L_.load().timhip_layer_wgrad_pair_wins(_C.byref(_d)) == 1)
+        except Exception:  # noqa: BLE001
+            paired_tn = False
+        alg_avg = (2 * sum(alg_nt) + 2 * alg_tn) / 17.0 if paired_tn else (sum(alg_nt) + alg_tn) / 9.0
         traffic = None  # HBM-side bytes per launch of the GEMM kernels, from the committed rocprofv3 PMC passes
         tnote = "no PMC summary committed for this configuration"
         try:
-            tfile = [f for f in ("r06_m_pmc_traffic.json", "r06_g_pmc_traffic.json", "r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            tfile = [f for f in ("r06_q_pmc_traffic.json", "r06_m_pmc_traffic.json", "r06_g_pmc_traffic.json", "r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
             if args.precision in ("bf16", "fp16") and args.workload == "C2a" and B == 64:
                 ntk, tnk = tj.get("gemm_nt_ld_kernel", tj.get("gemm_nt_pp_kernel")), tj.get("wgrad_ld_kernel", tj.get("wgrad_pp_kernel"))   # 8 NT + 1 grouped TN launch per layer
@@ -893,6 +904,9 @@ def main():
                     mb = sum(m["bytes_per_launch"] * wi for m, wi in zip(multi, w)) / max(sum(w), 1)
                     ntk = dict(ntk, bytes_per_launch=(5 * ntk["bytes_per_launch"] + 3 * mb) / 8.0)
                 traffic = round((8 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 9.0)
+                if paired_tn:
+                    tnk = tj["wgrad_p8_kernel"]   # (KeyError -> no citation: a PMC set from before the paired launch)
+                    traffic = round((16 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 17.0)
                 tnote = ("CITED, not measured in this run: average fabric-side bytes per GEMM launch from the committed rocprofv3 PMC "
                          "passes of this command on the builder's box (FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
                          "profiles/%s, tools/pmc_traffic.py; the x2 and the write counter calibrated on known byte counts, "
@@ -905,10 +919,12 @@ def main():
                            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": "cited" if traffic else None,
                            "algorithmic_bytes_per_launch": round(alg_avg),
                            "traffic_note": tnote + "; algorithmic bytes average %.0f MB per launch (NT %.0f MB on average, grouped "
-                                           "TN %.1f MB)" % (alg_avg / 1e6, sum(alg_nt) / 8e6, alg_tn / 1e6),
+                                           "TN %.1f MB%s)" % (alg_avg / 1e6, sum(alg_nt) / 8e6, alg_tn * (2 if paired_tn else 1) / 1e6,
+                                                              " = two layers per launch" if paired_tn else ""),
                            "kernel": "MFMA GEMM family: gemm_nt_ld_kernel (160 x 256 tiles, loader waves + L2 prefetch: the one-round shapes) / gemm_nt_p8_kernel (round 6: 256 / 320 x 256 tiles on the eight-phase schedule for the in-projection and linear1 forward; TIMHIP_GEMM_P8=0: the tile walk gemm_nt_ldp_kernel) / gemm_nt_%s_kernel (8 launches per layer) + the grouped TN weight-"
-                                     "gradient launch (wgrad_ld_kernel: the layer's 4 weight gradients as one grid) = the "
-                                     "72 GEMMs of the 6 encoder layers fwd+bwd in 54 launches, 2*M*N*K algorithmic FLOPs each; `achieved` = sum FLOPs / sum of their HIP-event durations inside "
+                                     "gradient launch (round 6: wgrad_p8_kernel, the 8 weight gradients of TWO layers as one round of 256 x 256 eight-phase tiles; "
+                                     "TIM_AMD_WGRAD_PAIR=0: wgrad_ld_kernel, a layer's 4 as one grid) = the "
+                                     "72 GEMMs of the 6 encoder layers fwd+bwd in 51 (54) launches, 2*M*N*K algorithmic FLOPs each; `achieved` = sum FLOPs / sum of their HIP-event durations inside "
                                      "the last timed step, events recorded on the stream each kernel is launched on (default: the "
                                      "whole backward on one stream; TIM_AMD_OVERLAP_WGRAD=1 moves the weight gradients to a second "
                                      "stream, which lengthens every launch); `achieved_other_streams` = the same events on one "

@@ -171,6 +171,40 @@ def test_c2a_production_batch_replay_is_the_eager_step_fp16(salt_off):
     _same(rep2, _snap(model, fn()), 1e-5)
 
 
+def test_c2a_paired_weight_gradients_are_the_single_layer_ones(salt_off, monkeypatch):
+    """round 6: at C2a B = 64 the backward hands the weight gradients of two layers to ONE launch of eight-phase tiles
+    (timhip_layer_bwd_weights_pair, wgrad_p8_kernel); TIM_AMD_WGRAD_PAIR=0 is the layer-by-layer path.  Same dropout salt: same
+    logits bit for bit (the forward is untouched), every gradient equal up to the summation order inside a 9920-row
+    contraction - and the pair path really is taken (timhip_layer_wgrad_pair_wins)."""
+    from tests.test_gpu_parity import build
+    from tim_amd.config import named_config
+    cfg = named_config("C2a")
+    B, nv, na = 64, 15, 10
+    sd, inp = H.synth_torch(cfg, B, nv, na, seed=4, dtype=torch.float32)
+    model = build(cfg, "fp16", sd).train()
+    static = {k: v.to(DEV).clone() for k, v in inp.items()}
+    R = []
+    fn = _step(model, static, nv, na, R)
+    names, real_call = [], F.call
+    monkeypatch.setattr(F, "call", lambda name, *a: (names.append(name), real_call(name, *a))[1])
+    word = F.graph_safe_dropout(DEV)
+    word.fill_(_i64(7 * K2 - F._SALT_STEP))
+    paired = _snap(model, fn())
+    n_pair = names.count("timhip_layer_bwd_weights_pair")
+    assert n_pair == cfg.num_layers // 2 and "timhip_layer_bwd_split" not in names
+    del names[:]
+    monkeypatch.setenv("TIM_AMD_WGRAD_PAIR", "0")
+    word.fill_(_i64(7 * K2 - F._SALT_STEP))
+    single = _snap(model, fn())
+    assert "timhip_layer_bwd_weights_pair" not in names and names.count("timhip_layer_bwd_split") == cfg.num_layers
+    for x, y in zip(paired[0], single[0]):
+        assert torch.equal(x, y)
+    assert paired[1].keys() == single[1].keys()
+    for k in paired[1]:
+        s_ = single[1][k].abs().max().item() + 1e-12
+        assert (paired[1][k] - single[1][k]).abs().max().item() <= 1e-4 * s_, k
+
+
 def test_detection_training_step_replay_is_the_eager_step(salt_off, monkeypatch):
     """bench.py's `c4_train` graph replay: the detection TRAINING step (det tim.py:272-337 + scripts/train.py:212-349) captured
     whole - query draw on the device (torch.randperm under capture, detection.py), on-device IoU labelling, encoder, focal +

@@ -55,3 +55,7 @@ for name, no, ko in tn:
 us = timeit(lambda: rt.wgrad_group(items, M, accumulate=False), 20)
 print("the four as the layer's ONE grouped launch (wgrad_ld_kernel, bias gradients included): %.1f us  %.0f TF   (hipBLASLt, four launches: %.1f us  %.0f TF)"
       % (us, fl / us / 1e6, t_lib, fl / t_lib / 1e6))
+items2 = items + [(Y, no, X, ko, torch.zeros((no, ko), device=dev), torch.zeros(no, device=dev)) for (Y, no, X, ko, _, _) in items]
+us2 = timeit(lambda: rt.wgrad_group(items2, M, accumulate=False), 20)
+print("round 6: TWO layers' eight products as one round of 256 eight-phase 256 x 256 tiles (wgrad_p8_kernel): %.1f us = %.1f us per layer  %.0f TF"
+      % (us2, us2 / 2, 2 * fl / us2 / 1e6))

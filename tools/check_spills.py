@@ -30,7 +30,7 @@ BUDGET = {
                     # tile (measured with these counts: the walk wins 0.5 % of the step); the residual
                     # epilogue (EPI 4) is not on any BASELINE config's path (its shapes run one round: gemm_nt_ld_kernel)
                     (r"gemm_nt_ldp_kernelIDF16[_b]Li4E", 35), (r"gemm_nt_ldp_kernelIDF16[_b]Li5E", 12), (r"gemm_nt_ldp_kernel", 8)],
-    "wgrad_pp.hip": [(r"wgrad_ld_kernel", 0), (r"wgrad_pp_kernel", 0)],
+    "wgrad_pp.hip": [(r"wgrad_ld_kernel", 0), (r"wgrad_pp_kernel", 0), (r"wgrad_p8_kernel", 0)],
     "wgrad.hip": [(r"wgrad_group_kernel", 0), (r"wgrad_tn_kernel", 0)],
     "attention_mfma.hip": [(r"attn_fwd_mfma", 0)],
     # the fp16 fused backward (C2a / C3 / C4), with the kernel's own draws and with the keep-bits of round 6

@@ -18,7 +18,7 @@ cd /root/repo
 python tools/rocpd_stats.py $OUT/prof/c2a_results.db > $OUT/kernel_stats.csv 2> $OUT/kernel_stats.err
 python tools/rocpd_timeline.py $OUT/prof/c2a_results.db 0 -2 > $OUT/timeline_c2a.txt 2>&1
 python tools/pmc_traffic.py $OUT/traffic $OUT/pmc_traffic.json > /dev/null 2> $OUT/pmc_traffic.err
-python tools/pmc_summary.py $OUT/sq gemm_nt_p8 gemm_nt_ldp gemm_nt_ld gemm_nt_pp wgrad_ld attn_fwd attn_bwd_rows attn_keep_bits ln_bwd ln_fwd8 gemm_nt_h16 > $OUT/pmc_sq_summary.txt 2>&1
+python tools/pmc_summary.py $OUT/sq gemm_nt_p8 gemm_nt_ldp gemm_nt_ld gemm_nt_pp wgrad_p8 wgrad_ld attn_fwd attn_bwd_rows attn_keep_bits ln_bwd ln_fwd8 gemm_nt_h16 > $OUT/pmc_sq_summary.txt 2>&1
 (hostname; cat /proc/loadavg; nproc) > $OUT/box.txt 2>&1
 python tools/evidence_summary.py $OUT 0 $OUT/summary.json > $OUT/summary.out 2>&1
 rm -rf $OUT/prof $OUT/traffic $OUT/sq

@@ -20,7 +20,7 @@ import sys
 
 FAMILIES = [   # (family, regex on the kernel name)
     ("nt_gemm", r"gemm_nt_ld_kernel|gemm_nt_ldp_kernel|gemm_nt_pp_kernel|gemm_nt_p8_kernel"),
-    ("wgrad_layer", r"wgrad_ld_kernel|wgrad_pp_kernel"),
+    ("wgrad_layer", r"wgrad_ld_kernel|wgrad_pp_kernel|wgrad_p8_kernel"),
     ("attention_keep_bits", r"attn_keep_bits"),
     ("attention_fwd", r"attn_fwd"),
     ("attention_bwd", r"attn_bwd"),
@@ -47,9 +47,10 @@ def fam_of(name):
 def main():
     d, steps, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
     fam = {}
-    if steps <= 0:   # infer: one grouped weight-gradient launch per encoder layer and step
+    if steps <= 0:   # infer: one grouped weight-gradient launch per encoder layer (round 6: per TWO layers, wgrad_p8_kernel) and step
         with open(os.path.join(d, "kernel_stats.csv")) as f:
-            steps = sum(int(r["calls"]) for r in csv.DictReader(f) if "wgrad_ld_kernel" in r["name"]) / float(L)
+            steps = sum(int(r["calls"]) * (2 if "wgrad_p8_kernel" in r["name"] else 1) for r in csv.DictReader(f)
+                        if "wgrad_ld_kernel" in r["name"] or "wgrad_p8_kernel" in r["name"]) / float(L)
     with open(os.path.join(d, "kernel_stats.csv")) as f:
         for r in csv.DictReader(f):
             if r["name"] == "TOTAL":

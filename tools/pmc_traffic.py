@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: {"fetch_kib": 0.0, "write_kib": 0.0, "n_f"
 def fam(name, row=None):
     # the encoder layers' launches: their NT GEMMs run the loader-wave ping-pong kernel (gemm_nt_ld_kernel; gemm_nt_pp_kernel with TIMHIP_GEMM_LD=0), their grouped weight gradient
     # wgrad_ld_kernel (wgrad_pp_kernel with TIMHIP_WGRAD_LD=0); the front end / heads / small models use gemm_nt_h16_kernel, gemm_nt_group_kernel, wgrad_group_kernel
-    for k in ("gemm_nt_p8_kernel", "attn_keep_bits_kernel", "gemm_nt_ldp_kernel", "gemm_nt_ld_kernel", "gemm_nt_pp_kernel", "wgrad_ld_kernel", "wgrad_pp_kernel", "gemm_nt_h16_kernel", "gemm_nt_group_kernel", "wgrad_group_kernel", "wgrad_tn_kernel",
+    for k in ("gemm_nt_p8_kernel", "attn_keep_bits_kernel", "gemm_nt_ldp_kernel", "gemm_nt_ld_kernel", "gemm_nt_pp_kernel", "wgrad_p8_kernel", "wgrad_ld_kernel", "wgrad_pp_kernel", "gemm_nt_h16_kernel", "gemm_nt_group_kernel", "wgrad_group_kernel", "wgrad_tn_kernel",
               "attn_fwd_mfma", "attn_bwd_mfma", "ln_fwd_kernel", "ln_bwd_kernel", "wgrad_reduce_kernel", "cast_weights_kernel",
               "attn_bwd_rows", "attn_bwd_keys", "ln_fwd8_kernel", "split3_kernel", "grad_scale_kernel"):
         if k in name:
