@@ -171,14 +171,16 @@ def test_c2a_production_batch_replay_is_the_eager_step_fp16(salt_off):
     _same(rep2, _snap(model, fn()), 1e-5)
 
 
-def test_c2a_paired_weight_gradients_are_the_single_layer_ones(salt_off, monkeypatch):
+@pytest.mark.parametrize("layers", [6, 3])
+def test_c2a_paired_weight_gradients_are_the_single_layer_ones(layers, salt_off, monkeypatch):
     """round 6: at C2a B = 64 the backward hands the weight gradients of two layers to ONE launch of eight-phase tiles
     (timhip_layer_bwd_weights_pair, wgrad_p8_kernel); TIM_AMD_WGRAD_PAIR=0 is the layer-by-layer path.  Same dropout salt: same
     logits bit for bit (the forward is untouched), every gradient equal up to the summation order inside a 9920-row
     contraction - and the pair path really is taken (timhip_layer_wgrad_pair_wins)."""
     from tests.test_gpu_parity import build
     from tim_amd.config import named_config
-    cfg = named_config("C2a")
+    import dataclasses
+    cfg = dataclasses.replace(named_config("C2a"), num_layers=layers)   # (3: an odd stack - layer 0 goes out on its own)
     B, nv, na = 64, 15, 10
     sd, inp = H.synth_torch(cfg, B, nv, na, seed=4, dtype=torch.float32)
     model = build(cfg, "fp16", sd).train()
@@ -192,6 +194,7 @@ def test_c2a_paired_weight_gradients_are_the_single_layer_ones(salt_off, monkeyp
     paired = _snap(model, fn())
     n_pair = names.count("timhip_layer_bwd_weights_pair")
     assert n_pair == cfg.num_layers // 2 and "timhip_layer_bwd_split" not in names
+    assert names.count("timhip_layer_bwd_weights") == cfg.num_layers % 2
     del names[:]
     monkeypatch.setenv("TIM_AMD_WGRAD_PAIR", "0")
     word.fill_(_i64(7 * K2 - F._SALT_STEP))

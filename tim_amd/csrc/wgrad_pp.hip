@@ -767,7 +767,10 @@ struct W8Tab { uint32_t offY[2][2], offX[2][2]; };
 
 // ABL (tuning builds, tools/wg_pair_ab.py): timing-only ablations - 1: no bias MFMAs, 2: the X pieces gathered in 128-byte runs
 // like the Y pieces (wrong columns), 4: no stores of the result, 8: fragment reads only in the first step, 16: no DMA after the prologue
-template <typename HT, int G, int ABL = 0>
+// SCH (tuning builds, schedule arms): 1: the phase-1 pieces (X_0 of step t + 1) go out in phase 2 with Y_0's - phase 1 has 26 of the
+// step's 58 fragment reads; 2: no s_setprio around the MFMA segments; 4: a phase's pieces before its fragment reads; 8: fragment reads
+// waited for behind the phase's first barrier
+template <typename HT, int G, int ABL = 0, int SCH = 0>
 __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_t sy, size_t sx, int nk, const char* lds, uint32_t lds0,
                                             const W8Tab& tb, int wave, const int (&yo)[2], const int (&xo)[2], bool bias_on,
                                             const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb) {
@@ -809,7 +812,8 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
   };
   auto mma = [&](auto qn_c, auto qk_c) {
     constexpr int qn = decltype(qn_c)::value, qk = decltype(qk_c)::value;
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (SCH & 8) { wp_wait_lds(); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (!(SCH & 2)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -820,8 +824,9 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
     if constexpr (qn == 0 && qk == 0) {   // phase 1: this wave's share of the bias gradient (one 32-row half of one dY tile)
       if (!(ABL & 1) && bias_on) accb = mfma16x16<HT>(ones, yb, accb);
     }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!(SCH & 2)) __builtin_amdgcn_s_setprio(0);
   };
+  auto wait_reads = [&]() { if constexpr (!(SCH & 8)) wp_wait_lds(); };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   for (int t = 0; t < nk; ++t) {
@@ -831,35 +836,40 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
     const bool s1 = t >= 1 && t + 1 < nk && !(ABL & 16), s2 = t + 2 < nk && !(ABL & 16);
     const bool rd = !(ABL & 8) || t == 0;
     // phase 1: quadrant (n 0, k 0)
+    if constexpr (SCH & 4) { if (s1 && !(SCH & 1)) stage_x(t + 1, oth, 0); }
     if (rd) { read_x(bb, 0); read_y(bb, 0); }
     if (bias_on) yb = cat8<HT>(tr_read<HT>(bb + bo[0]), tr_read<HT>(bb + bo[1]));
-    if (s1) stage_x(t + 1, oth, 0);
-    wp_wait_lds(); wp_barrier();
+    if constexpr (!(SCH & 4)) { if (s1 && !(SCH & 1)) stage_x(t + 1, oth, 0); }
+    wait_reads(); wp_barrier();
     mma(I0{}, I0{});
     wp_barrier();
     // phase 2: (n 0, k 1) - Y fragments kept
+    if constexpr (SCH & 4) { if (s1 && (SCH & 1)) stage_x(t + 1, oth, 0); if (s2) stage_y(t + 2, cur, 0); }
     if (rd) read_x(bb, 1);
-    if (s2) stage_y(t + 2, cur, 0);
-    wp_wait_lds(); wp_barrier();
+    if constexpr (!(SCH & 4)) { if (s1 && (SCH & 1)) stage_x(t + 1, oth, 0); if (s2) stage_y(t + 2, cur, 0); }
+    wait_reads(); wp_barrier();
     mma(I0{}, I1{});
     wp_barrier();
     // phase 3: (n 1, k 1) - X fragments kept
+    if constexpr (SCH & 4) { if (s2) stage_x(t + 2, cur, 1); }
     if (rd) read_y(bb, 1);
-    if (s2) stage_x(t + 2, cur, 1);
-    wp_wait_lds(); wp_barrier();
+    if constexpr (!(SCH & 4)) { if (s2) stage_x(t + 2, cur, 1); }
+    wait_reads(); wp_barrier();
     mma(I1{}, I1{});
     wp_barrier();
     // phase 4: (n 1, k 0) - Y fragments kept; the step's one counted wait: X_0 of step t + 1 (and everything older) has landed
+    if constexpr (SCH & 4) { if (s2) stage_y(t + 2, cur, 1); }
     if (rd) read_x(bb, 0);
-    if (s2) { stage_y(t + 2, cur, 1); glds_wait<6>(); } else { glds_wait<0>(); }
-    wp_wait_lds(); wp_barrier();
+    if constexpr (!(SCH & 4)) { if (s2) stage_y(t + 2, cur, 1); }
+    if (s2) glds_wait<6>(); else glds_wait<0>();
+    wait_reads(); wp_barrier();
     mma(I1{}, I0{});
     wp_barrier();
   }
   if constexpr (G == 0) wp_barrier();   // as many barriers as group 1
 }
 
-template <typename HT, int ABL = 0>
+template <typename HT, int ABL = 0, int SCH = 0>
 __global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][Y_0 | Y_1 | X_0 | X_1], 16 KiB each
   const int tid = threadIdx.x, lane = tid & 63;
@@ -923,8 +933,8 @@ __global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
   }
   const int nk = g.M / WP_M;
   const size_t sy = (size_t)WP_M * ldy * 2, sx = (size_t)WP_M * ldx * 2;
-  if (wr == 0) w8_mainloop<HT, 0, ABL>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
-  else w8_mainloop<HT, 1, ABL>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+  if (wr == 0) w8_mainloop<HT, 0, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+  else w8_mainloop<HT, 1, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
 
   // D[row = k: 4 gid + r][col = n: p] per MFMA tile (i: k tile, j: n tile): a lane owns 4 consecutive k of one row n of dW
   const float alpha = g.out_scale ? *g.out_scale : 1.f;
@@ -1063,6 +1073,12 @@ int tim_wgrad_group_p8(int precision, const TimWgradItem* it, int n, int M, int 
     hipLaunchKernelGGL((wgrad_p8_kernel<f16_t, X>), dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g); return TIMHIP_OK;
     switch (atoi(v)) { W8A(1) W8A(2) W8A(4) W8A(8) W8A(16) W8A(24) W8A(7) default: break; }
 #undef W8A
+  }
+  if (const char* v = getenv("TIMHIP_W8_SCH")) {
+#define W8S(X) case X: (void)hipFuncSetAttribute((const void*)wgrad_p8_kernel<f16_t, 0, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((wgrad_p8_kernel<f16_t, 0, X>), dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g); return TIMHIP_OK;
+    switch (atoi(v)) { W8S(1) W8S(2) W8S(4) W8S(5) W8S(8) W8S(3) default: break; }
+#undef W8S
   }
 #endif
   DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_p8_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
