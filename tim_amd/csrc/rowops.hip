@@ -1311,6 +1311,18 @@ static int ln_bwd_rows_per_block(int rows) {
   int rpb = 16;
   if (rows > 16 * 768) rpb = (((rows + 767) / 768) + 3) / 4 * 4;
   else if (rows < 16 * 512) { rpb = (((rows + 511) / 512) + 3) / 4 * 4; if (rpb < 4) rpb = 4; }
+  else {
+    // 512 - 768 blocks of 16 rows all run at once, 2 on some CUs and 3 on others: 9920 rows = 620 blocks = 2.42 per CU, and the launch
+    // ends with the CUs that hold 3.  20 rows per block = 496 blocks = 1.94 per CU: LayerNorm's in-step brackets 678 -> 640 us per
+    // step, the step -0.4 % (profiles/r06_s_ln_rpb_step_ab.txt; 40 rows = one block per CU: brackets -13 us, step +0.8 %).  Pick the
+    // fullest rounds of 256 among 16 / 20 / 24 rows (ties: the fewest rows).
+    double best = 0.0;
+    for (int c = 16; c <= 24; c += 4) {
+      const int blocks = (rows + c - 1) / c, rounds = (blocks + 255) / 256;
+      const double fill = (double)blocks / (rounds * 256.0);
+      if (fill > best + 0.02) { best = fill; rpb = c; }
+    }
+  }
   return rpb;
 }
 
