@@ -1288,7 +1288,9 @@ int tim_layernorm_fwd(int precision, const float* y, int rows, int cols, int ldy
   // encoder widths (512 / 1024 / 2048 columns, 16-byte aligned rows): the 8-columns-per-lane kernel
   const bool al8 = (ldy % 4) == 0 && (!xt || ldt % 8 == 0) && (!xf || ldx % 4 == 0) &&
                    ((((uintptr_t)y | (uintptr_t)xt | (uintptr_t)xf | (uintptr_t)w | (uintptr_t)b) & 15) == 0);
-  const dim3 grid8 = run_if ? dim3(min((int)grid.x, 256)) : grid;
+  // (the kernel walks rows grid-stride: a block of 4 waves takes `frpb` rows, one per wave and trip)
+  const int frpb = tim_knobs().ln_fwd_rpb >= 4 ? tim_knobs().ln_fwd_rpb / 4 * 4 : 4;
+  const dim3 grid8 = run_if ? dim3(min((int)grid.x, 256)) : dim3((rows + frpb - 1) / frpb);
 #define LN_FWD8(NS) hipLaunchKernelGGL((ln_fwd8_kernel<T, NS>), grid8, dim3(256), 0, s, y, rows, ldy, act, w, b, xf, ldx, (T*)xt, ldt, \
                                      stats, mbits, mwords, mthr, TimSeed(mask_seed), mask_site, run_if, sp)
   if (run_if && !(al8 && (cols == 512 || cols == 1024 || cols == 2048))) return TIMHIP_EUNSUPPORTED;   // (only the 8-column kernel has the switch)
