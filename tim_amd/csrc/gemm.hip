@@ -643,6 +643,15 @@ static inline bool tall_tile_wins(int M, int N, int splitk) {
   return (long long)((M + 159) / 160) * 160 <= (long long)((M + 127) / 128) * 128 + 32;
 }
 
+// LDS stages of the small-problem (64 x 128) instances: TIMHIP_GEMM_SMALL_NST = 2 / 3 / 4 forces; 0 (default) = by the block
+// count - as many stages as leave every block of the launch resident at once (24 KiB per stage, 160 KiB per CU)
+static inline int small_nst(long long blocks) {
+  const int k = tim_knobs().gemm_small_nst;
+  if (k >= 2 && k <= 4) return k;
+  if (k == 1) return 2;
+  return blocks <= 256 ? 4 : (blocks <= 512 ? 3 : 2);
+}
+
 // tile variants (bf16): 0 = default, others for tuning on selected epilogues
 template <int EPI>
 constexpr bool tunable() {
@@ -712,9 +721,15 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
       // the number of blocks - these launches are occupancy-bound, not staging-bound
       const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
       DISPATCH_H16(precision,
-        if (t128 <= 256 && M > 64)
-          launch_h16<HT, EPI, 64, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
-        else if (tall_tile_wins(M, N, splitk))
+        if (t128 <= 256 && M > 64) {
+          // (a block of such a launch is a CHAIN of K / 64 stage latencies: with two LDS stages one load is in flight while the
+          //  previous stage is multiplied - 0.1 us of MFMAs - so a step lasts a memory latency; deeper rings divide that.
+          //  TIMHIP_GEMM_SMALL_NST = 2 / 3 / 4 stages of 24 KiB: 3 / 2 / 1 blocks per CU)
+          const int nst = small_nst((long long)((M + 63) / 64) * ((N + 127) / 128) * splitk);
+          if (nst >= 4) launch_h16<HT, EPI, 64, 128, 1, 4, 64, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+          else if (nst == 3) launch_h16<HT, EPI, 64, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+          else launch_h16<HT, EPI, 64, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+        } else if (tall_tile_wins(M, N, splitk))
           launch_h16<HT, EPI, 160, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
         else
           launch_h16<HT, EPI, 128, 128, 2, 2, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s));
@@ -805,8 +820,11 @@ int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, h
     return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
   }
   const dim3 grid((unsigned)g.tile0[n]);
-  const size_t shmem = (size_t)2 * (64 + 128) * 64 * 2;
-#define GROUP(X) case X: DISPATCH_H16(precision, hipLaunchKernelGGL((gemm_nt_group_kernel<HT, X, 64, 128, 1, 4, 64, 2>), grid, dim3(256), shmem, s, g)); break;
+  const int nst = small_nst(g.tile0[n]);
+  const size_t shmem = (size_t)nst * (64 + 128) * 64 * 2;
+#define GROUP_N(X, NS) do { DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)gemm_nt_group_kernel<HT, X, 64, 128, 1, 4, 64, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    DISPATCH_H16(precision, hipLaunchKernelGGL((gemm_nt_group_kernel<HT, X, 64, 128, 1, 4, 64, NS>), grid, dim3(256), shmem, s, g)); } while (0)
+#define GROUP(X) case X: if (nst >= 4) GROUP_N(X, 4); else if (nst == 3) GROUP_N(X, 3); else GROUP_N(X, 2); break;
   switch (epi) {
     GROUP(TIMHIP_EPI_STORE_F32)
     GROUP(TIMHIP_EPI_ADD_F32)
@@ -815,6 +833,7 @@ int tim_gemm_nt_group(int precision, int epi, const TimGemmItem* items, int n, h
     default: return TIMHIP_EUNSUPPORTED;
   }
 #undef GROUP
+#undef GROUP_N
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
