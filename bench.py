@@ -892,7 +892,7 @@ def main():
         traffic = None  # HBM-side bytes per launch of the GEMM kernels, from the committed rocprofv3 PMC passes
         tnote = "no PMC summary committed for this configuration"
         try:
-            tfile = [f for f in ("r06_q_pmc_traffic.json", "r06_m_pmc_traffic.json", "r06_g_pmc_traffic.json", "r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            tfile = [f for f in ("r06_w_pmc_traffic.json", "r06_q_pmc_traffic.json", "r06_m_pmc_traffic.json", "r06_g_pmc_traffic.json", "r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
             if args.precision in ("bf16", "fp16") and args.workload == "C2a" and B == 64:
                 ntk, tnk = tj.get("gemm_nt_ld_kernel", tj.get("gemm_nt_pp_kernel")), tj.get("wgrad_ld_kernel", tj.get("wgrad_pp_kernel"))   # 8 NT + 1 grouped TN launch per layer
@@ -903,10 +903,11 @@ def main():
                     w = [m.get("launches", 1) for m in multi]
                     mb = sum(m["bytes_per_launch"] * wi for m, wi in zip(multi, w)) / max(sum(w), 1)
                     ntk = dict(ntk, bytes_per_launch=(5 * ntk["bytes_per_launch"] + 3 * mb) / 8.0)
-                traffic = round((8 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 9.0)
                 if paired_tn:
                     tnk = tj["wgrad_p8_kernel"]   # (KeyError -> no citation: a PMC set from before the paired launch)
                     traffic = round((16 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 17.0)
+                else:
+                    traffic = round((8 * ntk["bytes_per_launch"] + tnk["bytes_per_launch"]) / 9.0)
                 tnote = ("CITED, not measured in this run: average fabric-side bytes per GEMM launch from the committed rocprofv3 PMC "
                          "passes of this command on the builder's box (FETCH_SIZE x2 + WRITE_SIZE in separate passes, "
                          "profiles/%s, tools/pmc_traffic.py; the x2 and the write counter calibrated on known byte counts, "
