@@ -726,7 +726,12 @@ int launch(int precision, int variant, const void* A, int lda, const void* B, in
           //  previous stage is multiplied - 0.1 us of MFMAs - so a step lasts a memory latency; deeper rings divide that.
           //  TIMHIP_GEMM_SMALL_NST = 2 / 3 / 4 stages of 24 KiB: 3 / 2 / 1 blocks per CU)
           const int nst = small_nst((long long)((M + 63) / 64) * ((N + 127) / 128) * splitk);
-          if (nst >= 4) launch_h16<HT, EPI, 64, 128, 1, 4, 64, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+          // With the latency chain shortened, a step costs a wave its six LDS-DMA issue stalls and eight MFMAs: the launches of at
+          // most 256 blocks (one per CU: three SIMD slots of four idle) run the tile on EIGHT waves, 2 x 4 of 32 x 32 - half of both
+          // per wave: C2a at 8 windows per GPU 1.843 -> 1.790 ms, C1 0.832 -> 0.826 (profiles/r06_aa_small_gemm_w8_ab.txt; the
+          // two-blocks-per-CU launches gain nothing from it: r06_ab).  TIMHIP_GEMM_SMALL_W8=0: four waves.
+          if (nst >= 4 && tim_knobs().gemm_small_w8 != 0) launch_h16<HT, EPI, 64, 128, 2, 4, 64, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
+          else if (nst >= 4) launch_h16<HT, EPI, 64, 128, 1, 4, 64, 4, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
           else if (nst == 3) launch_h16<HT, EPI, 64, 128, 1, 4, 64, 3, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
           else launch_h16<HT, EPI, 64, 128, 1, 4, 64, 2, 1>(A, lda, B, ldb, M, N, K, e, splitk, s);
         } else if (tall_tile_wins(M, N, splitk))
