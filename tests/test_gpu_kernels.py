@@ -305,10 +305,12 @@ def test_wgrad_group(M, shapes, accumulate, prec, loaders, knobs):
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("M", [2048, 9920])
-def test_wgrad_group_eight_phase(M, accumulate, prec, knobs):
+@pytest.mark.parametrize("phases", [4, 2])
+def test_wgrad_group_eight_phase(M, accumulate, prec, phases, knobs):
     """round 6: the weight gradients of TWO encoder layers as one round of 256 x 256 eight-phase tiles (wgrad_p8_kernel) == the
     per-product reference, == the one-block-per-CU kernel's results bit for bit in its biases' tolerance; TIMHIP_WGRAD_P8=0
     sends the same group through the 128 x 256 kernel"""
+    knobs(TIMHIP_WGRAD_P8_PH=str(phases))   # (four 16-MFMA phases per contraction step, or two 32-MFMA ones)
     rt = Runtime(prec)
     shapes = [(1024, 2048), (2048, 1024), (1024, 1024), (3072, 1024)] * 2
     items, refs = [], []
@@ -328,7 +330,7 @@ def test_wgrad_group_eight_phase(M, accumulate, prec, knobs):
         if db is not None:
             assert (db.cpu().double() - rb).abs().max().item() <= 2e-5 * max(1.0, rb.abs().max().item()) + 1e-4
     # the same group through the 128 x 256 kernel: same products, another summation order inside the MFMA chain only
-    knobs(TIMHIP_WGRAD_P8="0")
+    knobs(TIMHIP_WGRAD_P8="0", TIMHIP_WGRAD_P8_PH=str(phases))
     for (_, _, _, _, dW, db) in items:
         dW.fill_(0.5)
         if db is not None:

@@ -162,7 +162,7 @@ void read_knobs(TimKnobs& k) {
   k.gemm_dg = env_int("TIMHIP_GEMM_DG", 0); k.gemm_dg_offset = env_int("TIMHIP_GEMM_DG_OFFSET", 9);
   k.fuse_ln = env_int("TIMHIP_FUSE_LN", 0); k.fuse_ln_spin = env_int("TIMHIP_FUSE_LN_SPIN", 100000);
   k.wgrad_pp = env_int("TIMHIP_WGRAD_PP", 1); k.wgrad_ld = env_int("TIMHIP_WGRAD_LD", 1); k.wgrad_pf = env_int("TIMHIP_WGRAD_PF", 4);
-  k.wgrad_p8 = env_int("TIMHIP_WGRAD_P8", 1);
+  k.wgrad_p8 = env_int("TIMHIP_WGRAD_P8", 1); k.wgrad_p8_ph = env_int("TIMHIP_WGRAD_P8_PH", 2);
   k.attn_waves = env_int("TIMHIP_ATTN_WAVES", 0); k.attn_fused = env_int("TIMHIP_ATTN_FUSED", 1);
   k.ln_rpb = env_int("TIMHIP_LN_RPB", 0);
   k.gemm_tmw = env_int("TIMHIP_GEMM_TMW", 0);

@@ -288,6 +288,7 @@ struct TimKnobs {
   int wgrad_pp;       // TIMHIP_WGRAD_PP     0: no one-block-per-CU weight-gradient grid
   int wgrad_ld;       // TIMHIP_WGRAD_LD     0: its 8-wave merged-phase form
   int wgrad_pf;       // TIMHIP_WGRAD_PF     its L2 prefetch distance (default 4)
+  int wgrad_p8_ph;    // TIMHIP_WGRAD_P8_PH  phases per contraction step of the eight-phase weight-gradient kernel: 2 (32 MFMAs each, default) or 4 (16 each, as first written)
   int wgrad_p8;       // TIMHIP_WGRAD_P8     0: no eight-phase 256 x 256 weight-gradient grid (two layers per launch)
   int attn_waves;     // TIMHIP_ATTN_WAVES   waves per attention block (0: by shape)
   int attn_fused;     // TIMHIP_ATTN_FUSED   0: two-kernel attention backward

@@ -869,7 +869,95 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
   if constexpr (G == 0) wp_barrier();   // as many barriers as group 1
 }
 
-template <typename HT, int ABL = 0, int SCH = 0>
+// Two phases per step (the default since it was measured: two layers 302.8 -> 286.3 us, the C2a step -1.0 %,
+// profiles/r06_ae_*; TIMHIP_WGRAD_P8_PH=4: the four-phase loop above): phase A = n-half 0 against BOTH k-halves (32 MFMAs: Y_0, X_0, X_1 read - 32
+// transposing reads - X kept), phase B = n-half 1 (32 MFMAs: Y_1 read).  Half the barriers per MFMA and no second read of X_0 (48
+// instead of 56 reads per step) for 16 fragment registers more.  Restaging, one phase after a sub-tile's last read: phase A of step
+// t: Y_1 of step t + 1 -> other buffer; phase B: Y_0, X_0, X_1 of step t + 2 -> this buffer, then the step's counted wait (the six
+// newest pieces stay in flight).  Hazards as in the four-phase loop (segments 2p / 2p + 1, group 1 one segment behind).
+template <typename HT, int G>
+__device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size_t sy, size_t sx, int nk, const char* lds, uint32_t lds0,
+                                             const W8Tab& tb, int wave, const int (&yo)[2], const int (&xo)[2], bool bias_on,
+                                             const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb) {
+  const uint32_t pw = (uint32_t)(2 * wave) * 1024u;
+  auto stage_y = [&](int kt, uint32_t buf, int q) {
+    const void* g = uniform_ptr(dY + (size_t)kt * sy);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i], buf + q * W8_SUB + pw + i * 1024);
+  };
+  auto stage_x = [&](int kt, uint32_t buf, int q) {
+    const void* g = uniform_ptr(X + (size_t)kt * sx);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i], buf + (2 + q) * W8_SUB + pw + i * 1024);
+  };
+  stage_y(0, lds0, 0); stage_x(0, lds0, 0); stage_x(0, lds0, 1); stage_y(0, lds0, 1);
+  if (nk > 1) { stage_y(1, lds0 + W8_STAGE, 0); stage_x(1, lds0 + W8_STAGE, 0); stage_x(1, lds0 + W8_STAGE, 1); stage_y(1, lds0 + W8_STAGE, 1); }
+  glds_wait<0>();
+  wp_barrier();
+  if constexpr (G == 1) wp_barrier();   // one segment behind group 0 from here on
+
+  vec8<HT> yf[4][2], xf[4][2], ones, yb;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { ones[u] = (HT)1.f; yb[u] = (HT)0.f; }
+  auto read_y = [&](const char* bb, int q) {
+    const char* sY = bb + q * W8_SUB;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        yf[j][kh] = cat8<HT>(tr_read<HT>(sY + (yo[0] ^ (j << 5)) + kh * (32 * 256)), tr_read<HT>(sY + (yo[1] ^ (j << 5)) + kh * (32 * 256)));
+  };
+  auto read_x = [&](const char* bb) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const char* sX = bb + (2 + q) * W8_SUB;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          xf[2 * q + i][kh] = cat8<HT>(tr_read<HT>(sX + (xo[0] ^ (i << 5)) + kh * (32 * 256)), tr_read<HT>(sX + (xo[1] ^ (i << 5)) + kh * (32 * 256)));
+    }
+  };
+  auto mma = [&](auto qn_c) {
+    constexpr int qn = decltype(qn_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i][4 * qn + j] = mfma16x16<HT>(xf[i][kh], yf[j][kh], acc[i][4 * qn + j]);
+    if constexpr (qn == 0) {   // this wave's share of the bias gradient (one 32-row half of one dY tile)
+      if (bias_on) accb = mfma16x16<HT>(ones, yb, accb);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    const char* bb = lds + b * W8_STAGE;
+    const uint32_t cur = lds0 + b * W8_STAGE, oth = lds0 + (b ^ 1) * W8_STAGE;
+    const bool s1 = t >= 1 && t + 1 < nk, s2 = t + 2 < nk;
+    // phase A: n-half 0, both k-halves
+    read_x(bb); read_y(bb, 0);
+    if (bias_on) yb = cat8<HT>(tr_read<HT>(bb + bo[0]), tr_read<HT>(bb + bo[1]));
+    if (s1) stage_y(t + 1, oth, 1);
+    wp_wait_lds(); wp_barrier();
+    mma(I0{});
+    wp_barrier();
+    // phase B: n-half 1 - X fragments kept; the step's one counted wait: Y_1 of step t + 1 (and everything older) has landed
+    read_y(bb, 1);
+    if (s2) { stage_y(t + 2, cur, 0); stage_x(t + 2, cur, 0); stage_x(t + 2, cur, 1); glds_wait<6>(); } else { glds_wait<0>(); }
+    wp_wait_lds(); wp_barrier();
+    mma(I1{});
+    wp_barrier();
+  }
+  if constexpr (G == 0) wp_barrier();   // as many barriers as group 1
+}
+
+template <typename HT, int ABL = 0, int SCH = 0, bool PH2 = false>
 __global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][Y_0 | Y_1 | X_0 | X_1], 16 KiB each
   const int tid = threadIdx.x, lane = tid & 63;
@@ -933,8 +1021,13 @@ __global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
   }
   const int nk = g.M / WP_M;
   const size_t sy = (size_t)WP_M * ldy * 2, sx = (size_t)WP_M * ldx * 2;
-  if (wr == 0) w8_mainloop<HT, 0, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
-  else w8_mainloop<HT, 1, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+  if constexpr (PH2) {
+    if (wr == 0) w8_mainloop2<HT, 0>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+    else w8_mainloop2<HT, 1>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+  } else {
+    if (wr == 0) w8_mainloop<HT, 0, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+    else w8_mainloop<HT, 1, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+  }
 
   // D[row = k: 4 gid + r][col = n: p] per MFMA tile (i: k tile, j: n tile): a lane owns 4 consecutive k of one row n of dW
   const float alpha = g.out_scale ? *g.out_scale : 1.f;
@@ -1081,6 +1174,13 @@ int tim_wgrad_group_p8(int precision, const TimWgradItem* it, int n, int M, int 
 #undef W8S
   }
 #endif
+  if (tim_knobs().wgrad_p8_ph != 4) {   // two 32-MFMA phases per step (TIMHIP_WGRAD_P8_PH=4: four 16-MFMA phases)
+    static PerDeviceOnce attr2[2];
+    if (attr2[hi].first())
+      DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_p8_kernel<HT, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    DISPATCH_H16(precision, hipLaunchKernelGGL((wgrad_p8_kernel<HT, 0, 0, true>), dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
+    return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
+  }
   DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_p8_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }

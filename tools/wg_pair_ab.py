@@ -37,17 +37,22 @@ for h in range(2):
         X = torch.randn(M, ko, generator=g).to(dev).half()
         items.append((Y, no, X, ko, torch.zeros((no, ko), device=dev), torch.zeros(no, device=dev)))
         fl += 2.0 * no * ko * M
-res = {"p8": [], "ld2": [], "ld1": []}
+res = {"p8": [], "p8_2": [], "ld2": [], "ld1": []}
 for r in range(R):
     setp8("1")
     res["p8"].append(timeit(lambda: rt.wgrad_group(items, M, accumulate=False)))
+    os.environ["TIMHIP_WGRAD_P8_PH"] = "2"
+    L.reload_env()
+    res["p8_2"].append(timeit(lambda: rt.wgrad_group(items, M, accumulate=False)))
+    os.environ["TIMHIP_WGRAD_P8_PH"] = "4"
+    L.reload_env()
     setp8("0")
     res["ld2"].append(timeit(lambda: rt.wgrad_group(items, M, accumulate=False)))
     res["ld1"].append(timeit(lambda: (rt.wgrad_group(items[:4], M, accumulate=False), rt.wgrad_group(items[4:], M, accumulate=False))))
 setp8("1")
 med = lambda v: sorted(v)[len(v) // 2]
 print("box: %s; two layers' weight gradients (%.0f GF), %d rounds x 10, us = median (min)" % (torch.cuda.get_device_name(0), fl / 1e9, R))
-for k, name in [("p8", "one launch, 256 eight-phase tiles of 256 x 256"), ("ld2", "one launch, 512 tiles of 128 x 256 (two rounds)"),
+for k, name in [("p8", "one launch, 256 eight-phase tiles of 256 x 256"), ("p8_2", "the same, two 32-MFMA phases per step"), ("ld2", "one launch, 512 tiles of 128 x 256 (two rounds)"),
                 ("ld1", "two launches of 256 tiles of 128 x 256")]:
     t = res[k]
     print("  %-52s %7.1f (%7.1f) us = %5.0f TF" % (name, med(t), min(t), fl / med(t) / 1e6))
