@@ -556,15 +556,16 @@ def test_gemm_pingpong_row_tile_forced(M, N, K, tmw, knobs):
 
 @pytest.mark.parametrize("prec", H16)
 @pytest.mark.parametrize("tm", [8, 10])
+@pytest.mark.parametrize("phases", [4, 2])
 @pytest.mark.parametrize("M,N,K", [(9920, 3072, 1024), (9920, 2048, 1024), (9925, 2048, 192), (3000, 512, 128), (7984, 3072, 1024),
                                    (300, 256, 64 * 5), (13120, 1024, 2048)])
-def test_gemm_eight_phase_kernel(prec, M, N, K, tm, knobs):
+def test_gemm_eight_phase_kernel(prec, M, N, K, tm, phases, knobs):
     """gemm_nt_p8_kernel (round 6): 256 x 256 (TM = 8) and 320 x 256 (TM = 10) tiles on the eight-phase schedule - four quadrant
     phases per contraction step, half-tiles restaged one phase after their last fragment read, one counted vmcnt per step -
     FORCED (TIMHIP_GEMM_P8 = 8 / 10) on the layer's multi-round shapes, on row counts neither tile divides (ragged last panel: 9925,
     7984, 300 rows), one / two rounds of tiles, 2 .. 32 contraction steps: the three epilogues it carries (16-bit store + bias,
     GELU + dropout with two outputs, multiply by the saved factor) against fp64, the others through their usual kernels"""
-    knobs(TIMHIP_GEMM_P8=str(tm))
+    knobs(TIMHIP_GEMM_P8=str(tm), TIMHIP_GEMM_P8_PH=str(phases))   # (phases per contraction step: four quadrants, or two row halves)
     for epi in (L.EPI_STORE_T, L.EPI_GELU_DROP_G2, L.EPI_MULAUX_T):
         assert L.load().timhip_gemm_p8_choice(epi, M, N, K) == tm     # really this kernel
     assert L.load().timhip_gemm_p8_choice(L.EPI_DROP_RES_F32, M, N, K) == 0

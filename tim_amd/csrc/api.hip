@@ -167,7 +167,7 @@ void read_knobs(TimKnobs& k) {
   k.ln_rpb = env_int("TIMHIP_LN_RPB", 0);
   k.gemm_tmw = env_int("TIMHIP_GEMM_TMW", 0);
   k.ln_rpb_small = env_int("TIMHIP_LN_RPB_SMALL", 0); k.ln_fwd_rpb = env_int("TIMHIP_LN_FWD_RPB", 0);
-  k.gemm_small_nst = env_int("TIMHIP_GEMM_SMALL_NST", 0); k.gemm_small_w8 = env_int("TIMHIP_GEMM_SMALL_W8", 1);
+  k.gemm_small_nst = env_int("TIMHIP_GEMM_SMALL_NST", 0); k.gemm_small_w8 = env_int("TIMHIP_GEMM_SMALL_W8", 1); k.gemm_p8_ph = env_int("TIMHIP_GEMM_P8_PH", 2);
   k.gemm_pp_min = env_int("TIMHIP_GEMM_PP_MIN_TILES", 192);
   k.attn_ks = env_int("TIMHIP_ATTN_KS", 1);
   k.gemm_p8 = env_int("TIMHIP_GEMM_P8", 1);

@@ -293,6 +293,7 @@ struct TimKnobs {
   int attn_waves;     // TIMHIP_ATTN_WAVES   waves per attention block (0: by shape)
   int attn_fused;     // TIMHIP_ATTN_FUSED   0: two-kernel attention backward
   int ln_rpb;         // TIMHIP_LN_RPB       rows per LayerNorm-backward block (0: by shape)
+  int gemm_p8_ph;     // TIMHIP_GEMM_P8_PH   phases per contraction step of the eight-phase NT kernel: 2 (4 TM MFMAs each, default) or 4 (2 TM each, as first written)
   int gemm_small_w8;  // TIMHIP_GEMM_SMALL_W8   0: four waves instead of eight (2 x 4 of 32 x 32) on the small-problem GEMM's 64 x 128 tile where four stages are taken
   int gemm_small_nst; // TIMHIP_GEMM_SMALL_NST  LDS stages of the small-problem GEMM instances (0: by the block count; 1 / 2: two, as before round 6)
   int ln_fwd_rpb;     // TIMHIP_LN_FWD_RPB   rows per block of the 8-columns-per-lane LayerNorm forward (0: by the row count)

@@ -897,6 +897,81 @@ __device__ __forceinline__ void p8_mainloop(const HT* __restrict__ A, const HT* 
   if constexpr (G == 0) pp_barrier();   // as many barriers as group 1
 }
 
+// Two phases per step (round 6, after the weight-gradient kernel's: wgrad_pp.hip w8_mainloop2): phase A = row-half 0 against BOTH
+// column halves (4 HM MFMAs: A0, B0, B1 read, B kept), phase B = row-half 1 (A1 read) - half the barriers per MFMA, B0 read once,
+// 16 fragment registers more.  Restaging one phase after a half-tile's last read: phase A of step t: A1 of step t + 1 -> other
+// buffer; phase B: A0, B0, B1 of step t + 2 -> this buffer, then the step's counted wait (those NA + 2 NB pieces stay in flight).
+template <typename HT, int TM, int G>
+__device__ __forceinline__ void p8_mainloop2(const HT* __restrict__ A, const HT* __restrict__ B, int nk, const char* lds, uint32_t lds0,
+                                             const P8Tab& tb, int a_frag, int b_frag, int c0, int c1, f32x4_t (&acc)[PP_TNW][TM]) {
+  constexpr int BM = 32 * TM, KT = (BM + PP_BN) * PP_ROWB, HM = TM / 2;
+  constexpr int NA = P8Share<TM, G>::NA, NB = P8Share<TM, G>::NB;
+  auto stage_a = [&](int kt, uint32_t buf, int h) {
+    const void* g = uniform_ptr(reinterpret_cast<const char*>(A) + (size_t)kt * PP_ROWB);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) glds16_s(g, tb.offA[h][i], buf + tb.dstA[h][i]);
+  };
+  auto stage_b = [&](int kt, uint32_t buf, int h) {
+    const void* g = uniform_ptr(reinterpret_cast<const char*>(B) + (size_t)kt * PP_ROWB);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) glds16_s(g, tb.offB[h][i], buf + tb.dstB[h][i]);
+  };
+  stage_a(0, lds0, 0); stage_b(0, lds0, 0); stage_b(0, lds0, 1); stage_a(0, lds0, 1);
+  if (nk > 1) { stage_a(1, lds0 + KT, 0); stage_b(1, lds0 + KT, 0); stage_b(1, lds0 + KT, 1); stage_a(1, lds0 + KT, 1); }
+  glds_wait<0>();
+  pp_barrier();
+  if constexpr (G == 1) pp_barrier();   // one segment behind group 0 from here on
+
+  vec8<HT> xa[HM][2], wb[4][2];
+  auto read_a = [&](const char* bb, int qm) {
+#pragma unroll
+    for (int i = 0; i < HM; ++i) {
+      xa[i][0] = *reinterpret_cast<const vec8<HT>*>(bb + a_frag + (qm * 8 * TM + i * 16) * PP_ROWB + c0);
+      xa[i][1] = *reinterpret_cast<const vec8<HT>*>(bb + a_frag + (qm * 8 * TM + i * 16) * PP_ROWB + c1);
+    }
+  };
+  auto read_b = [&](const char* bb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // (column quadrant qn = j / 2: rows qn * 32 + (j % 2) * 16 = j * 16 of the wave's 64)
+      wb[j][0] = *reinterpret_cast<const vec8<HT>*>(bb + b_frag + (j * 16) * PP_ROWB + c0);
+      wb[j][1] = *reinterpret_cast<const vec8<HT>*>(bb + b_frag + (j * 16) * PP_ROWB + c1);
+    }
+  };
+  auto mma = [&](auto qm_c) {
+    constexpr int qm = decltype(qm_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int i = 0; i < HM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j][qm * HM + i] = mfma16x16<HT>(wb[j][kh], xa[i][kh], acc[j][qm * HM + i]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    const char* bb = lds + b * KT;
+    const uint32_t cur = lds0 + b * KT, oth = lds0 + (b ^ 1) * KT;
+    const bool s1 = t >= 1 && t + 1 < nk, s2 = t + 2 < nk;
+    // phase A: row-half 0, both column halves
+    read_b(bb); read_a(bb, 0);
+    if (s1) stage_a(t + 1, oth, 1);
+    pp_wait_lds(); pp_barrier();
+    mma(I0{});
+    pp_barrier();
+    // phase B: row-half 1 - B fragments kept; the step's one counted wait: A1 of step t + 1 (and everything older) has landed
+    read_a(bb, 1);
+    if (s2) { stage_a(t + 2, cur, 0); stage_b(t + 2, cur, 0); stage_b(t + 2, cur, 1); glds_wait<NA + 2 * NB>(); } else { glds_wait<0>(); }
+    pp_wait_lds(); pp_barrier();
+    mma(I1{});
+    pp_barrier();
+  }
+  if constexpr (G == 0) pp_barrier();   // as many barriers as group 1
+}
+
 template <typename HT, int EPI, int TM, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ B, int ldb,
                                                          int M, int N, int K, EpiDev e) {
@@ -945,8 +1020,13 @@ __global__ __launch_bounds__(512) void gemm_nt_p8_kernel(const HT* __restrict__ 
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nk = K / 64;
-  if (wr == 0) p8_mainloop<HT, TM, 0, VAR>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
-  else p8_mainloop<HT, TM, 1, VAR>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+  if constexpr ((VAR & 4) != 0) {   // two phases per step (the default; TIMHIP_GEMM_P8_PH=4: four)
+    if (wr == 0) p8_mainloop2<HT, TM, 0>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+    else p8_mainloop2<HT, TM, 1>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+  } else {
+    if (wr == 0) p8_mainloop<HT, TM, 0, VAR>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+    else p8_mainloop<HT, TM, 1, VAR>(A, B, nk, lds, lds0, tb, a_frag, b_frag, c0, c1, acc);
+  }
   __syncthreads();   // every wave is done with the buffers: they become the epilogue's transposition space
   float* ep = reinterpret_cast<float*>(lds) + wave * (16 * 68);
   pp_epilogue<HT, EPI, TM, 2, PpNoSync, 2>(e, acc, m0 + wr * 16 * TM, n0 + wc * 64, M, N, ep, lane);
@@ -970,6 +1050,13 @@ void launch_p8(const void* A, int lda, const void* B, int ldb, int M, int N, int
 #undef P8V
   }
 #endif
+  if (tim_knobs().gemm_p8_ph != 4) {   // two phases per step: the default (in-projection forward 60.0 -> 56.8 us, linear1 forward 54.5 -> 51.9: profiles/r06_af_*)
+    static PerDeviceOnce attr2;
+    if (attr2.first())
+      (void)hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<HT, EPI, TM, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((gemm_nt_p8_kernel<HT, EPI, TM, 4>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
+    return;
+  }
   hipLaunchKernelGGL((gemm_nt_p8_kernel<HT, EPI, TM>), grid, dim3(512), shmem, s, (const HT*)A, lda, (const HT*)B, ldb, M, N, K, e);
 }
 

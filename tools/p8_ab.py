@@ -12,7 +12,8 @@ rt = Runtime("fp16")
 M, E, FF = 9920, 1024, 2048
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 shapes = [("in_proj fwd", 3 * E, E, L.EPI_STORE_T), ("ffn1 fwd", FF, E, L.EPI_GELU_DROP_G2), ("ffn2 dgrad", FF, E, L.EPI_MULAUX_T)]
-arms = [("ld/ldp (P8=0)", "0"), ("p8 by shape (P8=1)", "1"), ("p8 256 rows (P8=8)", "8"), ("p8 320 rows (P8=10)", "10")]
+arms = [("ld/ldp (P8=0)", "0"), ("p8 by shape (P8=1)", "1"), ("p8 256 rows (P8=8)", "8"), ("p8 320 rows (P8=10)", "10"),
+        ("p8 256 rows, two phases", "8:2"), ("p8 320 rows, two phases", "10:2")]
 
 
 def timeit(f, n=20):
@@ -28,7 +29,8 @@ def timeit(f, n=20):
 
 
 def setp8(v):
-    os.environ["TIMHIP_GEMM_P8"] = v
+    os.environ["TIMHIP_GEMM_P8"] = v.split(":")[0]
+    os.environ["TIMHIP_GEMM_P8_PH"] = v.split(":")[1] if ":" in v else "4"   # (phases per contraction step)
     L.reload_env()
 
 
