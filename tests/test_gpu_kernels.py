@@ -565,6 +565,8 @@ def test_gemm_eight_phase_kernel(prec, M, N, K, tm, phases, knobs):
     FORCED (TIMHIP_GEMM_P8 = 8 / 10) on the layer's multi-round shapes, on row counts neither tile divides (ragged last panel: 9925,
     7984, 300 rows), one / two rounds of tiles, 2 .. 32 contraction steps: the three epilogues it carries (16-bit store + bias,
     GELU + dropout with two outputs, multiply by the saved factor) against fp64, the others through their usual kernels"""
+    if phases == 4 and (M, N, K) not in ((9920, 3072, 1024), (9925, 2048, 192), (300, 256, 64 * 5)):
+        pytest.skip("the four-phase loop (TIMHIP_GEMM_P8_PH=4, not the default any more) is kept tested on three shapes")
     knobs(TIMHIP_GEMM_P8=str(tm), TIMHIP_GEMM_P8_PH=str(phases))   # (phases per contraction step: four quadrants, or two row halves)
     for epi in (L.EPI_STORE_T, L.EPI_GELU_DROP_G2, L.EPI_MULAUX_T):
         assert L.load().timhip_gemm_p8_choice(epi, M, N, K) == tm     # really this kernel
