@@ -304,7 +304,7 @@ def test_wgrad_group(M, shapes, accumulate, prec, loaders, knobs):
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("accumulate", [False, True])
-@pytest.mark.parametrize("M", [2048, 9920])
+@pytest.mark.parametrize("M", [2048, 9920, 7984, 2051])   # (7984 = C4's 16 x 499 rows, 2051: ragged last stages of 48 / 3 rows)
 @pytest.mark.parametrize("phases", [4, 2])
 def test_wgrad_group_eight_phase(M, accumulate, prec, phases, knobs):
     """round 6: the weight gradients of TWO encoder layers as one round of 256 x 256 eight-phase tiles (wgrad_p8_kernel) == the

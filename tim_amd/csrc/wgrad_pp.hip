@@ -773,15 +773,29 @@ struct W8Tab { uint32_t offY[2][2], offX[2][2]; };
 template <typename HT, int G, int ABL = 0, int SCH = 0>
 __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_t sy, size_t sx, int nk, const char* lds, uint32_t lds0,
                                             const W8Tab& tb, int wave, const int (&yo)[2], const int (&xo)[2], bool bias_on,
-                                            const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb) {
+                                            const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb, int mlast) {
   const uint32_t pw = (uint32_t)(2 * wave) * 1024u;
+  // (mlast: rows of the last stage, 64 = whole; a partial last stage re-reads row M - 1 for its rows past the end - finite data -
+  //  and the dY fragments of those rows are zeroed before they are multiplied: zero_tail)
+  const int lrow_ = (int)(threadIdx.x & 63) >> 4;
+  auto over_of = [&](int i) { return max((2 * wave + i) * 4 + lrow_ - (mlast - 1), 0); };
   auto stage_y = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(dY + (size_t)kt * sy);
+    if (mlast < WP_M && kt == nk - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i] - (uint32_t)over_of(i) * (uint32_t)(sy / WP_M), buf + q * W8_SUB + pw + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i], buf + q * W8_SUB + pw + i * 1024);
   };
   auto stage_x = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(X + (size_t)kt * sx);
+    if (mlast < WP_M && kt == nk - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i] - (uint32_t)over_of(i) * (uint32_t)(sx / WP_M), buf + (2 + q) * W8_SUB + pw + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i], buf + (2 + q) * W8_SUB + pw + i * 1024);
   };
@@ -827,6 +841,26 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
     if constexpr (!(SCH & 2)) __builtin_amdgcn_s_setprio(0);
   };
   auto wait_reads = [&]() { if constexpr (!(SCH & 8)) wp_wait_lds(); };
+  const int gid_ = (int)(threadIdx.x & 63) >> 4;
+  auto zero_tail = [&](int t, bool with_bias, int bkh) {   // last, partial stage: the dY rows >= M contribute nothing
+    if (!(mlast < WP_M && t == nk - 1)) return;
+    wp_wait_lds();
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const int nvalid = mlast - (kh * 32 + 8 * gid_);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (u >= nvalid) yf[j][kh][u] = (HT)0.f;
+    }
+    if (with_bias) {
+      const int nvalid = mlast - (bkh * 32 + 8 * gid_);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u >= nvalid) yb[u] = (HT)0.f;
+    }
+  };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   for (int t = 0; t < nk; ++t) {
@@ -840,7 +874,7 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
     if (rd) { read_x(bb, 0); read_y(bb, 0); }
     if (bias_on) yb = cat8<HT>(tr_read<HT>(bb + bo[0]), tr_read<HT>(bb + bo[1]));
     if constexpr (!(SCH & 4)) { if (s1 && !(SCH & 1)) stage_x(t + 1, oth, 0); }
-    wait_reads(); wp_barrier();
+    wait_reads(); zero_tail(t, bias_on, wave & 1); wp_barrier();
     mma(I0{}, I0{});
     wp_barrier();
     // phase 2: (n 0, k 1) - Y fragments kept
@@ -854,7 +888,7 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
     if constexpr (SCH & 4) { if (s2) stage_x(t + 2, cur, 1); }
     if (rd) read_y(bb, 1);
     if constexpr (!(SCH & 4)) { if (s2) stage_x(t + 2, cur, 1); }
-    wait_reads(); wp_barrier();
+    wait_reads(); zero_tail(t, false, 0); wp_barrier();
     mma(I1{}, I1{});
     wp_barrier();
     // phase 4: (n 1, k 0) - Y fragments kept; the step's one counted wait: X_0 of step t + 1 (and everything older) has landed
@@ -878,15 +912,29 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
 template <typename HT, int G>
 __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size_t sy, size_t sx, int nk, const char* lds, uint32_t lds0,
                                              const W8Tab& tb, int wave, const int (&yo)[2], const int (&xo)[2], bool bias_on,
-                                             const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb) {
+                                             const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb, int mlast) {
   const uint32_t pw = (uint32_t)(2 * wave) * 1024u;
+  // (mlast: rows of the last stage, 64 = whole; a partial last stage re-reads row M - 1 for its rows past the end - finite data -
+  //  and the dY fragments of those rows are zeroed before they are multiplied: zero_tail)
+  const int lrow_ = (int)(threadIdx.x & 63) >> 4;
+  auto over_of = [&](int i) { return max((2 * wave + i) * 4 + lrow_ - (mlast - 1), 0); };
   auto stage_y = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(dY + (size_t)kt * sy);
+    if (mlast < WP_M && kt == nk - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i] - (uint32_t)over_of(i) * (uint32_t)(sy / WP_M), buf + q * W8_SUB + pw + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i], buf + q * W8_SUB + pw + i * 1024);
   };
   auto stage_x = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(X + (size_t)kt * sx);
+    if (mlast < WP_M && kt == nk - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i] - (uint32_t)over_of(i) * (uint32_t)(sx / WP_M), buf + (2 + q) * W8_SUB + pw + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i], buf + (2 + q) * W8_SUB + pw + i * 1024);
   };
@@ -933,6 +981,25 @@ __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size
     }
     __builtin_amdgcn_s_setprio(0);
   };
+  const int gid_ = (int)(threadIdx.x & 63) >> 4;
+  auto zero_tail = [&](int t, bool with_bias, int bkh) {   // last, partial stage: the dY rows >= M contribute nothing
+    if (!(mlast < WP_M && t == nk - 1)) return;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const int nvalid = mlast - (kh * 32 + 8 * gid_);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (u >= nvalid) yf[j][kh][u] = (HT)0.f;
+    }
+    if (with_bias) {
+      const int nvalid = mlast - (bkh * 32 + 8 * gid_);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u >= nvalid) yb[u] = (HT)0.f;
+    }
+  };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   for (int t = 0; t < nk; ++t) {
@@ -944,13 +1011,13 @@ __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size
     read_x(bb); read_y(bb, 0);
     if (bias_on) yb = cat8<HT>(tr_read<HT>(bb + bo[0]), tr_read<HT>(bb + bo[1]));
     if (s1) stage_y(t + 1, oth, 1);
-    wp_wait_lds(); wp_barrier();
+    wp_wait_lds(); zero_tail(t, bias_on, wave & 1); wp_barrier();
     mma(I0{});
     wp_barrier();
     // phase B: n-half 1 - X fragments kept; the step's one counted wait: Y_1 of step t + 1 (and everything older) has landed
     read_y(bb, 1);
     if (s2) { stage_y(t + 2, cur, 0); stage_x(t + 2, cur, 0); stage_x(t + 2, cur, 1); glds_wait<6>(); } else { glds_wait<0>(); }
-    wp_wait_lds(); wp_barrier();
+    wp_wait_lds(); zero_tail(t, false, 0); wp_barrier();
     mma(I1{});
     wp_barrier();
   }
@@ -1019,14 +1086,14 @@ __global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
     const int row = 8 * gid + 4 * r + (p >> 2);
     bo[r] = ((bcol >> 2) & 1) * W8_SUB + bkh * (32 * 256) + tile_off<128>(row, (bcol >> 3) * 8 + (bcol & 3) * 2 + ((p & 3) >> 1)) + (p & 1) * 8;
   }
-  const int nk = g.M / WP_M;
+  const int nk = (g.M + WP_M - 1) / WP_M, mlast = g.M - (nk - 1) * WP_M;   // (rows of the last stage: 1 .. 64)
   const size_t sy = (size_t)WP_M * ldy * 2, sx = (size_t)WP_M * ldx * 2;
   if constexpr (PH2) {
-    if (wr == 0) w8_mainloop2<HT, 0>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
-    else w8_mainloop2<HT, 1>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+    if (wr == 0) w8_mainloop2<HT, 0>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
+    else w8_mainloop2<HT, 1>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
   } else {
-    if (wr == 0) w8_mainloop<HT, 0, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
-    else w8_mainloop<HT, 1, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb);
+    if (wr == 0) w8_mainloop<HT, 0, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
+    else w8_mainloop<HT, 1, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
   }
 
   // D[row = k: 4 gid + r][col = n: p] per MFMA tile (i: k tile, j: n tile): a lane owns 4 consecutive k of one row n of dW
@@ -1124,10 +1191,10 @@ int tim_wgrad_group_pp(int precision, const TimWgradItem* it, int n, int M, int 
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
 
-// Does the eight-phase grid suit this group?  Whole 256 x 256 tiles, a contraction of whole 64-row steps, and rounds of 256
+// Does the eight-phase grid suit this group?  Whole 256 x 256 tiles (any contraction length: a ragged last stage is handled) and rounds of 256
 // tiles filled to 90 %: at C2a that is the eight gradients of TWO encoder layers (TIMHIP_WGRAD_P8=0: off).
 bool tim_wgrad_p8_wins(const TimWgradItem* it, int n, int M) {
-  if (tim_knobs().wgrad_p8 == 0 || !it || n < 1 || n > WP_MAX || M < 2048 || (M % WP_M)) return false;
+  if (tim_knobs().wgrad_p8 == 0 || !it || n < 1 || n > WP_MAX || M < 2048) return false;
   long long tiles = 0;
   for (int i = 0; i < n; ++i) {
     if (it[i].Nout % W8_T || it[i].Kout % W8_T || it[i].Nout <= 0 || it[i].Kout < 4 * W8_T) return false;   // (>= 4 k tiles: one bias MFMA per wave)
@@ -1139,7 +1206,7 @@ bool tim_wgrad_p8_wins(const TimWgradItem* it, int n, int M) {
 
 int tim_wgrad_group_p8(int precision, const TimWgradItem* it, int n, int M, int accumulate, const float* out_scale, hipStream_t s) {
   if (!h16_storage(precision)) return TIMHIP_EUNSUPPORTED;
-  if (!it || n < 1 || n > WP_MAX || M < WP_M || (M % WP_M)) return TIMHIP_EINVAL;
+  if (!it || n < 1 || n > WP_MAX || M < 2 * WP_M) return TIMHIP_EINVAL;
   WpGroup g;
   g.n = n; g.M = M; g.accumulate = accumulate ? 1 : 0; g.out_scale = out_scale; g.pf_dist = 0;
   g.tile0[0] = 0;
