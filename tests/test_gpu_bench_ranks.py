@@ -27,7 +27,8 @@ def test_two_ranks_one_json_line():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 80 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 80 * 25 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-2
-    assert d["roofline"]["launches_timed"] == 54 and d["roofline"]["achieved"] > 0
+    # 48 NT launches + the weight gradients of the six layers as three paired launches (round 6; layer by layer: 54)
+    assert d["roofline"]["launches_timed"] == 51 and d["roofline"]["achieved"] > 0
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
 
 
