@@ -770,7 +770,7 @@ struct W8Tab { uint32_t offY[2][2], offX[2][2]; };
 // SCH (tuning builds, schedule arms): 1: the phase-1 pieces (X_0 of step t + 1) go out in phase 2 with Y_0's - phase 1 has 26 of the
 // step's 58 fragment reads; 2: no s_setprio around the MFMA segments; 4: a phase's pieces before its fragment reads; 8: fragment reads
 // waited for behind the phase's first barrier
-template <typename HT, int G, int ABL = 0, int SCH = 0>
+template <typename HT, int G, int ABL = 0, int SCH = 0, bool RAG = false>
 __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_t sy, size_t sx, int nk, const char* lds, uint32_t lds0,
                                             const W8Tab& tb, int wave, const int (&yo)[2], const int (&xo)[2], bool bias_on,
                                             const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb, int mlast) {
@@ -781,7 +781,7 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
   auto over_of = [&](int i) { return max((2 * wave + i) * 4 + lrow_ - (mlast - 1), 0); };
   auto stage_y = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(dY + (size_t)kt * sy);
-    if (mlast < WP_M && kt == nk - 1) {
+    if (RAG && mlast < WP_M && kt == nk - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i] - (uint32_t)over_of(i) * (uint32_t)(sy / WP_M), buf + q * W8_SUB + pw + i * 1024);
       return;
@@ -791,7 +791,7 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
   };
   auto stage_x = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(X + (size_t)kt * sx);
-    if (mlast < WP_M && kt == nk - 1) {
+    if (RAG && mlast < WP_M && kt == nk - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i] - (uint32_t)over_of(i) * (uint32_t)(sx / WP_M), buf + (2 + q) * W8_SUB + pw + i * 1024);
       return;
@@ -843,7 +843,7 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
   auto wait_reads = [&]() { if constexpr (!(SCH & 8)) wp_wait_lds(); };
   const int gid_ = (int)(threadIdx.x & 63) >> 4;
   auto zero_tail = [&](int t, bool with_bias, int bkh) {   // last, partial stage: the dY rows >= M contribute nothing
-    if (!(mlast < WP_M && t == nk - 1)) return;
+    if (!(RAG && mlast < WP_M && t == nk - 1)) return;
     wp_wait_lds();
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -909,7 +909,7 @@ __device__ __forceinline__ void w8_mainloop(const char* dY, const char* X, size_
 // instead of 56 reads per step) for 16 fragment registers more.  Restaging, one phase after a sub-tile's last read: phase A of step
 // t: Y_1 of step t + 1 -> other buffer; phase B: Y_0, X_0, X_1 of step t + 2 -> this buffer, then the step's counted wait (the six
 // newest pieces stay in flight).  Hazards as in the four-phase loop (segments 2p / 2p + 1, group 1 one segment behind).
-template <typename HT, int G>
+template <typename HT, int G, bool RAG = false>
 __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size_t sy, size_t sx, int nk, const char* lds, uint32_t lds0,
                                              const W8Tab& tb, int wave, const int (&yo)[2], const int (&xo)[2], bool bias_on,
                                              const int (&bo)[2], f32x4_t (&acc)[4][8], f32x4_t& accb, int mlast) {
@@ -920,7 +920,7 @@ __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size
   auto over_of = [&](int i) { return max((2 * wave + i) * 4 + lrow_ - (mlast - 1), 0); };
   auto stage_y = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(dY + (size_t)kt * sy);
-    if (mlast < WP_M && kt == nk - 1) {
+    if (RAG && mlast < WP_M && kt == nk - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) glds16_s(g, tb.offY[q][i] - (uint32_t)over_of(i) * (uint32_t)(sy / WP_M), buf + q * W8_SUB + pw + i * 1024);
       return;
@@ -930,7 +930,7 @@ __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size
   };
   auto stage_x = [&](int kt, uint32_t buf, int q) {
     const void* g = uniform_ptr(X + (size_t)kt * sx);
-    if (mlast < WP_M && kt == nk - 1) {
+    if (RAG && mlast < WP_M && kt == nk - 1) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) glds16_s(g, tb.offX[q][i] - (uint32_t)over_of(i) * (uint32_t)(sx / WP_M), buf + (2 + q) * W8_SUB + pw + i * 1024);
       return;
@@ -983,7 +983,7 @@ __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size
   };
   const int gid_ = (int)(threadIdx.x & 63) >> 4;
   auto zero_tail = [&](int t, bool with_bias, int bkh) {   // last, partial stage: the dY rows >= M contribute nothing
-    if (!(mlast < WP_M && t == nk - 1)) return;
+    if (!(RAG && mlast < WP_M && t == nk - 1)) return;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
       const int nvalid = mlast - (kh * 32 + 8 * gid_);
@@ -1024,7 +1024,9 @@ __device__ __forceinline__ void w8_mainloop2(const char* dY, const char* X, size
   if constexpr (G == 0) wp_barrier();   // as many barriers as group 1
 }
 
-template <typename HT, int ABL = 0, int SCH = 0, bool PH2 = false>
+// RAG: the contraction length is not a multiple of 64 (an instance of its own: the ragged-stage branches cost the whole-stage
+// launches 2 - 5 % when they were run-time conditions - profiles/r06_al_wgrad_pair_ab.txt)
+template <typename HT, int ABL = 0, int SCH = 0, bool PH2 = false, bool RAG = false>
 __global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][Y_0 | Y_1 | X_0 | X_1], 16 KiB each
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1089,11 +1091,11 @@ __global__ __launch_bounds__(512) void wgrad_p8_kernel(const WpGroup g) {
   const int nk = (g.M + WP_M - 1) / WP_M, mlast = g.M - (nk - 1) * WP_M;   // (rows of the last stage: 1 .. 64)
   const size_t sy = (size_t)WP_M * ldy * 2, sx = (size_t)WP_M * ldx * 2;
   if constexpr (PH2) {
-    if (wr == 0) w8_mainloop2<HT, 0>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
-    else w8_mainloop2<HT, 1>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
+    if (wr == 0) w8_mainloop2<HT, 0, RAG>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
+    else w8_mainloop2<HT, 1, RAG>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
   } else {
-    if (wr == 0) w8_mainloop<HT, 0, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
-    else w8_mainloop<HT, 1, ABL, SCH>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
+    if (wr == 0) w8_mainloop<HT, 0, ABL, SCH, RAG>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
+    else w8_mainloop<HT, 1, ABL, SCH, RAG>(pY, pX, sy, sx, nk, lds, lds0, tb, wave, yo, xo, bias_on, bo, acc, accb, mlast);
   }
 
   // D[row = k: 4 gid + r][col = n: p] per MFMA tile (i: k tile, j: n tile): a lane owns 4 consecutive k of one row n of dW
@@ -1241,13 +1243,15 @@ int tim_wgrad_group_p8(int precision, const TimWgradItem* it, int n, int M, int 
 #undef W8S
   }
 #endif
-  if (tim_knobs().wgrad_p8_ph != 4) {   // two 32-MFMA phases per step (TIMHIP_WGRAD_P8_PH=4: four 16-MFMA phases)
-    static PerDeviceOnce attr2[2];
-    if (attr2[hi].first())
-      DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_p8_kernel<HT, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    DISPATCH_H16(precision, hipLaunchKernelGGL((wgrad_p8_kernel<HT, 0, 0, true>), dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
-    return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
-  }
-  DISPATCH_H16(precision, hipLaunchKernelGGL(wgrad_p8_kernel<HT>, dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g));
+  const bool two = tim_knobs().wgrad_p8_ph != 4;   // two 32-MFMA phases per step (TIMHIP_WGRAD_P8_PH=4: four 16-MFMA phases)
+  const bool rag = (M % WP_M) != 0;
+#define W8_LAUNCH(PH2_, RAG_) do { \
+    DISPATCH_H16(precision, (void)hipFuncSetAttribute((const void*)wgrad_p8_kernel<HT, 0, 0, PH2_, RAG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    DISPATCH_H16(precision, hipLaunchKernelGGL((wgrad_p8_kernel<HT, 0, 0, PH2_, RAG_>), dim3((unsigned)g.tile0[n]), dim3(512), shmem, s, g)); } while (0)
+  if (two && rag) W8_LAUNCH(true, true);
+  else if (two) W8_LAUNCH(true, false);
+  else if (rag) W8_LAUNCH(false, true);
+  else W8_LAUNCH(false, false);
+#undef W8_LAUNCH
   return hipGetLastError() == hipSuccess ? TIMHIP_OK : TIMHIP_ELAUNCH;
 }
