@@ -892,7 +892,7 @@ def main():
         traffic = None  # HBM-side bytes per launch of the GEMM kernels, from the committed rocprofv3 PMC passes
         tnote = "no PMC summary committed for this configuration"
         try:
-            tfile = [f for f in ("r06_ag_pmc_traffic.json", "r06_ac_pmc_traffic.json", "r06_w_pmc_traffic.json", "r06_q_pmc_traffic.json", "r06_m_pmc_traffic.json", "r06_g_pmc_traffic.json", "r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+            tfile = [f for f in ("r06_am_pmc_traffic.json", "r06_ag_pmc_traffic.json", "r06_ac_pmc_traffic.json", "r06_w_pmc_traffic.json", "r06_q_pmc_traffic.json", "r06_m_pmc_traffic.json", "r06_g_pmc_traffic.json", "r05_k_pmc_traffic.json", "r05_j_pmc_traffic.json", "r04_pmc_traffic.json", "r03_g_pmc_traffic.json", "r03_f_pmc_traffic.json", "r03_e_pmc_traffic.json", "r03_d_pmc_traffic.json", "r03_c_pmc_traffic.json", "r03_a_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
             if args.precision in ("bf16", "fp16") and args.workload == "C2a" and B == 64:
                 ntk, tnk = tj.get("gemm_nt_ld_kernel", tj.get("gemm_nt_pp_kernel")), tj.get("wgrad_ld_kernel", tj.get("wgrad_pp_kernel"))   # 8 NT + 1 grouped TN launch per layer
